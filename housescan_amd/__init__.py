@@ -1,0 +1,12 @@
+"""housescan_amd -- MI355X-native KinectFusion core behind a C ABI (include/hskinfu.h).
+
+Importing the package loads libhskinfu.so; it fails loudly if the HIP library has not been built.
+"""
+from . import _lib
+
+_lib.load()
+
+from .kinfu import (KinfuError, KinfuTracker, bilateral_tables, default_config,  # noqa: E402
+                    synth_depth, synth_pose)
+
+__all__ = ["KinfuError", "KinfuTracker", "default_config", "synth_depth", "synth_pose", "bilateral_tables"]

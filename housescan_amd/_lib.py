@@ -1,0 +1,104 @@
+"""ctypes binding of libhskinfu.so (the C ABI declared in include/hskinfu.h).
+
+The library is the product; there is NO fallback: if the shared object is missing the import fails loudly, and
+`hsk_create` fails with HSK_ERR_NOGPU when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhskinfu.so")
+
+HSK_LEVELS = 3
+HSK_NSTAGES = 4
+HSK_KEY_NONE = 0x7FFFFFFF
+
+
+class HskConfig(C.Structure):
+    """Mirror of `hsk_config` (include/hskinfu.h)."""
+
+    _fields_ = [
+        ("vol_x", C.c_int), ("vol_y", C.c_int), ("vol_z", C.c_int),
+        ("vol_size_m", C.c_float * 3),
+        ("trunc_dist_m", C.c_float),
+        ("width", C.c_int), ("height", C.c_int),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("icp_iters", C.c_int * HSK_LEVELS),
+        ("icp_dist_thresh_m", C.c_float),
+        ("icp_angle_thresh_sin", C.c_float),
+        ("integrate_move_thresh", C.c_float),
+        ("init_pose", C.c_float * 16),
+        ("device_id", C.c_int),
+        ("own_z0", C.c_int), ("own_z1", C.c_int), ("halo", C.c_int),
+        ("use_graph", C.c_int),
+    ]
+
+
+# every symbol include/hskinfu.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int)
+SYMBOLS = {
+    "hsk_default_config": (None, [C.POINTER(HskConfig), C.c_int]),
+    "hsk_create": (C.c_int, [C.POINTER(HskConfig), C.POINTER(_P)]),
+    "hsk_destroy": (None, [_P]),
+    "hsk_reset": (C.c_int, [_P]),
+    "hsk_last_error": (C.c_char_p, [_P]),
+    "hsk_process_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, _I]),
+    "hsk_process_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, _I]),
+    "hsk_integrate": (C.c_int, [_P, _P, C.c_int, C.c_int, _F]),
+    "hsk_raycast": (C.c_int, [_P, _F, _P, _P, _P]),
+    "hsk_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "hsk_icp_accumulate": (C.c_int, [_P, C.c_int, _F, C.c_int, C.c_int, _D]),
+    "hsk_icp_solve": (C.c_int, [_D, _F, _I]),
+    "hsk_count_updates": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, C.POINTER(C.c_uint64)]),
+    "hsk_download_tsdf": (C.c_int, [_P, _P]),
+    "hsk_upload_tsdf": (C.c_int, [_P, _P]),
+    "hsk_stored_planes": (C.c_int, [_P, _I, _I]),
+    "hsk_get_pose": (C.c_int, [_P, _F]),
+    "hsk_set_pose": (C.c_int, [_P, _F]),
+    "hsk_download_map": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "hsk_upload_map": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "hsk_download_depth_level": (C.c_int, [_P, C.c_int, _P]),
+    "hsk_download_scaled_depth": (C.c_int, [_P, _P]),
+    "hsk_extract_cloud": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "hsk_mgpu_frame_begin": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "hsk_mgpu_icp_accumulate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "hsk_mgpu_icp_update": (C.c_int, [_P, _P]),
+    "hsk_mgpu_integrate": (C.c_int, [_P]),
+    "hsk_mgpu_raycast_local": (C.c_int, [_P, _P]),
+    "hsk_mgpu_raycast_resolve": (C.c_int, [_P, _P, _P]),
+    "hsk_mgpu_frame_end": (C.c_int, [_P, _P, _P, _F, _I]),
+    "hsk_mgpu_frame_index": (C.c_int, [_P]),
+    "hsk_stream": (_P, [_P]),
+    "hsk_set_stream": (C.c_int, [_P, _P]),
+    "hsk_synchronize": (C.c_int, [_P]),
+    "hsk_set_profiling": (C.c_int, [_P, C.c_int]),
+    "hsk_stage_ms": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
+    "hsk_bilateral_tables": (C.c_int, [_F, _F]),
+    "hsk_synth_pose": (C.c_int, [C.c_int, _F]),
+    "hsk_synth_render": (C.c_int, [_F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "hsk_write_pcd_xyz": (C.c_int, [C.c_char_p, _P, C.c_size_t]),
+    "hsk_voxel_downsample": (C.c_int, [_P, C.c_size_t, C.c_float, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhskinfu.so and bind every symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C housescan_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

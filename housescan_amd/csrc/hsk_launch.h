@@ -1,0 +1,36 @@
+// hsk_launch.h -- launcher prototypes shared between the kernel translation units and the C-ABI layer.
+#pragma once
+#include "hsk_dev.h"
+
+// volume
+void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
+                      int H, Intr in, bool count_only, unsigned long long* counter);
+void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
+                    float* vmap, float* nmap, int* keys);
+void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
+                    int* bits, int P);
+void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vmap, float* nmap, int P);
+void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,
+                    unsigned long long* row_offset, unsigned long long* total, float* xyz, unsigned long long cap,
+                    int pass);
+
+// image
+void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
+                            uint16_t* dst, float* scaled);
+void launch_scale_depth(hipStream_t s, const uint16_t* src, int W, int H, Intr in, float* scaled);
+void launch_pyrdown(hipStream_t s, const uint16_t* src, int W, int H, uint16_t* dst);
+void launch_vmap_nmap(hipStream_t s, const uint16_t* depth, int W, int H, Intr in, float* vmap, float* nmap);
+void launch_transform_maps(hipStream_t s, const float* vs, const float* ns, int P, const TrackState* st, float* vd,
+                           float* nd);
+void launch_resize_maps(hipStream_t s, const float* vs, const float* ns, int W, int H, float* vd, float* nd,
+                        const TrackState* st);
+int icp_num_blocks(int W, int rows);
+void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
+                           int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,
+                           int row1, double* partials);
+void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, double* out27);
+void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st);
+void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st);
+void launch_begin_frame(hipStream_t s, TrackState* st);
+bool host_solve6(const double* in27, float* x6);
+void host_pose_update(float* R, float* t, const float* x6);

@@ -1,0 +1,819 @@
+// hskinfu_api.hip -- the C ABI (include/hskinfu.h) over the gfx950 kernels: context, device memory layout,
+// the tracker state machine of SURVEY.md A.2 and its hipGraph replay, stage-level entry points, z-slab
+// building blocks.  Host-side restatement of the role the external PCL KinFu app plays for HouseScan
+// (/root/reference/README.md:13-14); the depth-frame type is HoniHelper.hs:20's (Vector Word16,(w,h)).
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/hskinfu.h"
+#include "hsk_dev.h"
+#include "hsk_launch.h"
+
+static thread_local std::string g_create_err;
+
+struct hsk_ctx {
+  hsk_config cfg;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  VolParams vp;
+  ImgLevel lv[HSK_NLEVELS];
+  float init_R[9], init_t[3];
+  // device memory (all sized once at create; nothing is allocated on the frame path)
+  void* d_vol = nullptr;
+  size_t vol_bytes = 0;
+  uint16_t* d_raw = nullptr;
+  uint16_t* d_dep[HSK_NLEVELS] = {};
+  float* d_scaled = nullptr;
+  float* d_vcur[HSK_NLEVELS] = {};
+  float* d_ncur[HSK_NLEVELS] = {};
+  float* d_vmod[HSK_NLEVELS] = {};
+  float* d_nmod[HSK_NLEVELS] = {};
+  TrackState* d_st = nullptr;
+  TrackState* h_st = nullptr;  // pinned
+  double* d_partials = nullptr;
+  double* d_sums = nullptr;
+  float* d_ws = nullptr;
+  float* d_wc = nullptr;
+  int* d_keys = nullptr;
+  uint16_t* h_stage = nullptr;  // pinned staging for the incoming depth frame
+  unsigned long long* d_counter = nullptr;
+  unsigned* d_rowcnt = nullptr;
+  unsigned long long* d_rowoff = nullptr;
+  int frame = 0;
+  std::string err;
+  // hipGraph of the steady-state frame
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  bool graph_ready = false;
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[HSK_NSTAGES + 1] = {};
+  double stage_ms[HSK_NSTAGES] = {};
+  uint64_t prof_frames = 0;
+};
+
+#define HIPCHK(k, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      char buf_[512];                                                                          \
+      snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (k)->err = buf_;                                                                         \
+      return HSK_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+static int fail(hsk_ctx* k, int code, const char* msg) {
+  if (k) k->err = msg;
+  return code;
+}
+
+static void pose16_to_rt(const float m[16], float R[9], float t[3]) {
+  for (int i = 0; i < 3; ++i) {
+    R[i * 3] = m[i * 4];
+    R[i * 3 + 1] = m[i * 4 + 1];
+    R[i * 3 + 2] = m[i * 4 + 2];
+    t[i] = m[i * 4 + 3];
+  }
+}
+static void rt_to_pose16(const float R[9], const float t[3], float m[16]) {
+  for (int i = 0; i < 3; ++i) {
+    m[i * 4] = R[i * 3];
+    m[i * 4 + 1] = R[i * 3 + 1];
+    m[i * 4 + 2] = R[i * 3 + 2];
+    m[i * 4 + 3] = t[i];
+  }
+  m[12] = m[13] = m[14] = 0.0f;
+  m[15] = 1.0f;
+}
+
+extern "C" void hsk_default_config(hsk_config* c, int n) {
+  memset(c, 0, sizeof(*c));
+  c->vol_x = c->vol_y = c->vol_z = n;
+  c->vol_size_m[0] = c->vol_size_m[1] = c->vol_size_m[2] = 3.0f;
+  c->trunc_dist_m = 0.03f;
+  c->width = 640;
+  c->height = 480;
+  c->fx = c->fy = 525.0f;
+  c->cx = 319.5f;
+  c->cy = 239.5f;
+  c->icp_iters[0] = 10;
+  c->icp_iters[1] = 5;
+  c->icp_iters[2] = 4;
+  c->icp_dist_thresh_m = 0.10f;
+  c->icp_angle_thresh_sin = 0.3420201433256687f;
+  c->integrate_move_thresh = 0.0f;
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  float t[3] = {c->vol_size_m[0] / 2.0f, c->vol_size_m[1] / 2.0f, c->vol_size_m[2] / 2.0f - 1.2f * c->vol_size_m[2] / 2.0f};
+  rt_to_pose16(R, t, c->init_pose);
+  c->device_id = 0;
+  c->own_z0 = 0;
+  c->own_z1 = n;
+  c->halo = 0;
+  c->use_graph = 1;
+}
+
+extern "C" int hsk_bilateral_tables(float ws[169], float wc[512]) {
+  const float sig_s = 4.5f, sig_c = 30.0f;
+  const float s2 = 0.5f / (sig_s * sig_s);
+  const float c2 = 0.5f / (sig_c * sig_c);
+  for (int dy = -6; dy <= 6; ++dy)
+    for (int dx = -6; dx <= 6; ++dx) {
+      const float arg = (float)(dx * dx + dy * dy) * s2;
+      ws[(dy + 6) * 13 + (dx + 6)] = (float)std::exp(-(double)arg);
+    }
+  for (int k = 0; k < 512; ++k) {
+    const float arg = (float)(k * k) * c2;
+    wc[k] = (float)std::exp(-(double)arg);
+  }
+  return HSK_OK;
+}
+
+static void free_all(hsk_ctx* k) {
+  if (!k) return;
+  (void)hipSetDevice(k->cfg.device_id);
+  if (k->gexec) (void)hipGraphExecDestroy(k->gexec);
+  if (k->graph) (void)hipGraphDestroy(k->graph);
+  auto F = [](void* p) {
+    if (p) (void)hipFree(p);
+  };
+  F(k->d_vol);
+  F(k->d_raw);
+  F(k->d_scaled);
+  for (int l = 0; l < HSK_NLEVELS; ++l) {
+    F(k->d_dep[l]);
+    F(k->d_vcur[l]);
+    F(k->d_ncur[l]);
+    F(k->d_vmod[l]);
+    F(k->d_nmod[l]);
+  }
+  F(k->d_st);
+  F(k->d_partials);
+  F(k->d_sums);
+  F(k->d_ws);
+  F(k->d_wc);
+  F(k->d_keys);
+  F(k->d_counter);
+  F(k->d_rowcnt);
+  F(k->d_rowoff);
+  if (k->h_st) (void)hipHostFree(k->h_st);
+  if (k->h_stage) (void)hipHostFree(k->h_stage);
+  for (auto& e : k->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (k->own_stream && k->stream) (void)hipStreamDestroy(k->stream);
+}
+
+static int upload_state(hsk_ctx* k) {
+  HIPCHK(k, hipMemcpyAsync(k->d_st, k->h_st, sizeof(TrackState), hipMemcpyHostToDevice, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+static int download_state(hsk_ctx* k) {
+  HIPCHK(k, hipMemcpyAsync(k->h_st, k->d_st, sizeof(TrackState), hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+
+static int do_reset(hsk_ctx* k) {
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  HIPCHK(k, hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream));
+  memset(k->h_st, 0, sizeof(TrackState));
+  memcpy(k->h_st->R, k->init_R, sizeof(k->init_R));
+  memcpy(k->h_st->t, k->init_t, sizeof(k->init_t));
+  memcpy(k->h_st->Rp, k->init_R, sizeof(k->init_R));
+  memcpy(k->h_st->tp, k->init_t, sizeof(k->init_t));
+  k->frame = 0;
+  return upload_state(k);
+}
+
+extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
+  if (!c || !out) {
+    g_create_err = "hsk_create: null argument";
+    return HSK_ERR_ARG;
+  }
+  *out = nullptr;
+  if (c->vol_x <= 0 || c->vol_y <= 0 || c->vol_z <= 0 || (c->vol_x % 4) != 0 || c->width <= 0 || c->height <= 0 ||
+      (c->width % 4) != 0 || (c->height % 4) != 0 || c->own_z0 < 0 || c->own_z1 > c->vol_z || c->own_z0 >= c->own_z1 ||
+      c->halo < 0) {
+    g_create_err = "hsk_create: invalid configuration (vol_x and image dims must be multiples of 4; 0 <= own_z0 < own_z1 <= vol_z)";
+    return HSK_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_err = "hsk_create: no HIP device available (this library has no CPU fallback)";
+    return HSK_ERR_NOGPU;
+  }
+  if (c->device_id < 0 || c->device_id >= ndev) {
+    g_create_err = "hsk_create: device_id out of range";
+    return HSK_ERR_ARG;
+  }
+  hsk_ctx* k = new hsk_ctx();
+  k->cfg = *c;
+  auto bail = [&](int code) {
+    g_create_err = k->err;
+    free_all(k);
+    delete k;
+    return code;
+  };
+#define CK(call)                                   \
+  do {                                             \
+    int r_ = [&]() -> int {                        \
+      HIPCHK(k, call);                             \
+      return HSK_OK;                               \
+    }();                                           \
+    if (r_ != HSK_OK) return bail(r_);             \
+  } while (0)
+  CK(hipSetDevice(c->device_id));
+  CK(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+  k->own_stream = true;
+  // geometry
+  VolParams& vp = k->vp;
+  vp.X = c->vol_x;
+  vp.Y = c->vol_y;
+  vp.Z = c->vol_z;
+  vp.zo0 = c->own_z0;
+  vp.zo1 = c->own_z1;
+  vp.zs0 = c->own_z0 - c->halo < 0 ? 0 : c->own_z0 - c->halo;
+  const int zs1 = c->own_z1 + c->halo > c->vol_z ? c->vol_z : c->own_z1 + c->halo;
+  vp.nzs = zs1 - vp.zs0;
+  for (int i = 0; i < 3; ++i) vp.size[i] = c->vol_size_m[i];
+  vp.cell[0] = vp.size[0] / (float)vp.X;
+  vp.cell[1] = vp.size[1] / (float)vp.Y;
+  vp.cell[2] = vp.size[2] / (float)vp.Z;
+  float m = vp.cell[0] > vp.cell[1] ? vp.cell[0] : vp.cell[1];
+  m = m > vp.cell[2] ? m : vp.cell[2];
+  const float lo = 2.1f * m;
+  vp.tau = c->trunc_dist_m > lo ? c->trunc_dist_m : lo;
+  vp.tau_inv = 1.0f / vp.tau;
+  for (int l = 0; l < HSK_NLEVELS; ++l) {
+    const float s = (float)(1 << l);
+    k->lv[l].W = c->width >> l;
+    k->lv[l].H = c->height >> l;
+    k->lv[l].in = Intr{c->fx / s, c->fy / s, c->cx / s, c->cy / s};
+  }
+  pose16_to_rt(c->init_pose, k->init_R, k->init_t);
+  // memory
+  k->vol_bytes = (size_t)vp.X * vp.Y * vp.nzs * 4;
+  CK(hipMalloc(&k->d_vol, k->vol_bytes));
+  const size_t P0 = (size_t)c->width * c->height;
+  CK(hipMalloc((void**)&k->d_raw, P0 * 2));
+  CK(hipMalloc((void**)&k->d_scaled, P0 * 4));
+  for (int l = 0; l < HSK_NLEVELS; ++l) {
+    const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
+    CK(hipMalloc((void**)&k->d_dep[l], P * 2));
+    CK(hipMalloc((void**)&k->d_vcur[l], P * 12));
+    CK(hipMalloc((void**)&k->d_ncur[l], P * 12));
+    CK(hipMalloc((void**)&k->d_vmod[l], P * 12));
+    CK(hipMalloc((void**)&k->d_nmod[l], P * 12));
+  }
+  CK(hipMalloc((void**)&k->d_st, sizeof(TrackState)));
+  CK(hipHostMalloc((void**)&k->h_st, sizeof(TrackState), hipHostMallocDefault));
+  CK(hipHostMalloc((void**)&k->h_stage, P0 * 2, hipHostMallocDefault));
+  const int nb0 = icp_num_blocks(c->width, c->height);
+  CK(hipMalloc((void**)&k->d_partials, (size_t)nb0 * 27 * sizeof(double)));
+  CK(hipMalloc((void**)&k->d_sums, 27 * sizeof(double)));
+  CK(hipMalloc((void**)&k->d_ws, 169 * 4));
+  CK(hipMalloc((void**)&k->d_wc, 512 * 4));
+  CK(hipMalloc((void**)&k->d_keys, P0 * 4));
+  CK(hipMalloc((void**)&k->d_counter, 16));
+  {
+    float ws[169], wc[512];
+    hsk_bilateral_tables(ws, wc);
+    CK(hipMemcpy(k->d_ws, ws, sizeof(ws), hipMemcpyHostToDevice));
+    CK(hipMemcpy(k->d_wc, wc, sizeof(wc), hipMemcpyHostToDevice));
+  }
+  for (auto& e : k->ev) CK(hipEventCreate(&e));
+#undef CK
+  int r = do_reset(k);
+  if (r != HSK_OK) return bail(r);
+  *out = k;
+  return HSK_OK;
+}
+
+extern "C" void hsk_destroy(hsk_ctx* k) {
+  if (!k) return;
+  if (k->stream) (void)hipStreamSynchronize(k->stream);
+  free_all(k);
+  delete k;
+}
+
+extern "C" int hsk_reset(hsk_ctx* k) {
+  if (!k) return HSK_ERR_ARG;
+  return do_reset(k);
+}
+
+extern "C" const char* hsk_last_error(const hsk_ctx* k) { return k ? k->err.c_str() : g_create_err.c_str(); }
+
+extern "C" void* hsk_stream(hsk_ctx* k) { return k ? (void*)k->stream : nullptr; }
+extern "C" int hsk_set_stream(hsk_ctx* k, void* stream) {
+  if (!k) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  if (k->stream) HIPCHK(k, hipStreamSynchronize(k->stream));
+  if (k->own_stream && k->stream) (void)hipStreamDestroy(k->stream);
+  k->stream = (hipStream_t)stream;
+  k->own_stream = false;
+  return HSK_OK;
+}
+extern "C" int hsk_synchronize(hsk_ctx* k) {
+  if (!k) return HSK_ERR_ARG;
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// frame building blocks (enqueue only; no host synchronisation)
+// ------------------------------------------------------------------------------------------------------
+static void enqueue_preprocess(hsk_ctx* k) {
+  hipStream_t s = k->stream;
+  launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_ws, k->d_wc, k->d_dep[0], k->d_scaled);
+  for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_dep[l]);
+  for (int l = 0; l < HSK_NLEVELS; ++l)
+    launch_vmap_nmap(s, k->d_dep[l], k->lv[l].W, k->lv[l].H, k->lv[l].in, k->d_vcur[l], k->d_ncur[l]);
+}
+
+static void enqueue_icp(hsk_ctx* k) {
+  hipStream_t s = k->stream;
+  for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
+    const int nb = icp_num_blocks(k->lv[l].W, k->lv[l].H);
+    for (int it = 0; it < k->cfg.icp_iters[l]; ++it) {
+      launch_icp_accumulate(s, k->d_vcur[l], k->d_ncur[l], k->d_vmod[l], k->d_nmod[l], k->lv[l].W, k->lv[l].H,
+                            k->lv[l].in, k->d_st, k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, 0, k->lv[l].H,
+                            k->d_partials);
+      launch_icp_reduce_update(s, k->d_partials, nb, k->d_st);
+    }
+  }
+}
+
+static void enqueue_integrate(hsk_ctx* k) {
+  launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
+                   k->d_counter);
+}
+
+static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys) {
+  hipStream_t s = k->stream;
+  launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys);
+  for (int l = 1; l < HSK_NLEVELS; ++l)
+    launch_resize_maps(s, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l], k->d_nmod[l],
+                       k->d_st);
+}
+
+// integration gate (A.2 step 5); evaluated on the host, only when the threshold is positive
+static bool gate_passes(const TrackState* st, float thr) {
+  if (!(thr > 0.0f)) return true;
+  float tr = 0.0f;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) tr += st->R[j * 3 + i] * st->Rp[j * 3 + i];
+  float cs = (tr - 1.0f) / 2.0f;
+  cs = cs > 1.0f ? 1.0f : (cs < -1.0f ? -1.0f : cs);
+  const float rnorm = acosf(cs);
+  const float d0 = st->t[0] - st->tp[0], d1 = st->t[1] - st->tp[1], d2 = st->t[2] - st->tp[2];
+  const float tnorm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+  return (rnorm + tnorm) / 2.0f >= thr;
+}
+
+// the steady-state frame: everything between the depth copy and the pose read-back
+static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
+  hipStream_t s = k->stream;
+  if (with_events) (void)hipEventRecord(k->ev[0], s);
+  enqueue_preprocess(k);
+  launch_begin_frame(s, k->d_st);
+  if (with_events) (void)hipEventRecord(k->ev[1], s);
+  enqueue_icp(k);
+  if (with_events) (void)hipEventRecord(k->ev[2], s);
+  enqueue_integrate(k);
+  if (with_events) (void)hipEventRecord(k->ev[3], s);
+  enqueue_raycast_and_resize(k, nullptr);
+  if (with_events) (void)hipEventRecord(k->ev[4], s);
+}
+
+static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
+  // depth is already in d_raw (enqueued on the stream)
+  hipStream_t s = k->stream;
+  const bool gated = k->cfg.integrate_move_thresh > 0.0f;
+  if (k->frame == 0) {
+    enqueue_preprocess(k);
+    enqueue_integrate(k);
+    for (int l = 0; l < HSK_NLEVELS; ++l)
+      launch_transform_maps(s, k->d_vcur[l], k->d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l], k->d_nmod[l]);
+    int r = download_state(k);
+    if (r != HSK_OK) return r;
+    HIPCHK(k, hipGetLastError());
+    k->frame = 1;
+    if (pose_out) rt_to_pose16(k->h_st->R, k->h_st->t, pose_out);
+    if (tracked) *tracked = 0;
+    return HSK_OK;
+  }
+  if (gated) {
+    // host decides whether to integrate: one extra synchronisation, only in this non-default mode
+    enqueue_preprocess(k);
+    launch_begin_frame(s, k->d_st);
+    enqueue_icp(k);
+    int r = download_state(k);
+    if (r != HSK_OK) return r;
+    if (!k->h_st->lost) {
+      if (gate_passes(k->h_st, k->cfg.integrate_move_thresh)) enqueue_integrate(k);
+      enqueue_raycast_and_resize(k, nullptr);
+    }
+  } else if (k->prof) {
+    enqueue_tracked_frame(k, true);
+  } else if (k->cfg.use_graph) {
+    if (!k->graph_ready) {
+      HIPCHK(k, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      enqueue_tracked_frame(k, false);
+      HIPCHK(k, hipStreamEndCapture(s, &k->graph));
+      HIPCHK(k, hipGraphInstantiate(&k->gexec, k->graph, nullptr, nullptr, 0));
+      k->graph_ready = true;
+    }
+    HIPCHK(k, hipGraphLaunch(k->gexec, s));
+  } else {
+    enqueue_tracked_frame(k, false);
+  }
+  int r = download_state(k);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipGetLastError());
+  if (k->prof && !gated) {
+    for (int i = 0; i < HSK_NSTAGES; ++i) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, k->ev[i], k->ev[i + 1]) == hipSuccess) k->stage_ms[i] += ms;
+    }
+    k->prof_frames += 1;
+  }
+  if (k->h_st->lost) {
+    r = do_reset(k);
+    if (r != HSK_OK) return r;
+    if (pose_out) rt_to_pose16(k->h_st->R, k->h_st->t, pose_out);
+    if (tracked) *tracked = 0;
+    return HSK_OK;
+  }
+  k->frame += 1;
+  if (pose_out) rt_to_pose16(k->h_st->R, k->h_st->t, pose_out);
+  if (tracked) *tracked = 1;
+  return HSK_OK;
+}
+
+static int check_dims(hsk_ctx* k, const void* depth, int w, int h) {
+  if (!k) return HSK_ERR_ARG;
+  if (!depth) return fail(k, HSK_ERR_ARG, "depth pointer is null");
+  if (w != k->cfg.width || h != k->cfg.height) return fail(k, HSK_ERR_ARG, "depth frame size does not match the context");
+  return HSK_OK;
+}
+
+static int stage_depth_host(hsk_ctx* k, const uint16_t* depth) {
+  const size_t bytes = (size_t)k->cfg.width * k->cfg.height * 2;
+  memcpy(k->h_stage, depth, bytes);  // caller's buffer may be freed on return (HoniHelper's Vector is only pinned in unsafeWith)
+  HIPCHK(k, hipMemcpyAsync(k->d_raw, k->h_stage, bytes, hipMemcpyHostToDevice, k->stream));
+  return HSK_OK;
+}
+
+extern "C" int hsk_process_frame(hsk_ctx* k, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked) {
+  int r = check_dims(k, depth, w, h);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  r = stage_depth_host(k, depth);
+  if (r != HSK_OK) return r;
+  return frame_common(k, pose_out, tracked);
+}
+
+extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float pose_out[16], int* tracked) {
+  int r = check_dims(k, depth_dev, w, h);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
+  return frame_common(k, pose_out, tracked);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stage-level entry points
+// ------------------------------------------------------------------------------------------------------
+static int set_pose_internal(hsk_ctx* k, const float pose[16]) {
+  int r = download_state(k);
+  if (r != HSK_OK) return r;
+  pose16_to_rt(pose, k->h_st->R, k->h_st->t);
+  k->h_st->lost = 0;
+  return upload_state(k);
+}
+
+extern "C" int hsk_get_pose(hsk_ctx* k, float pose[16]) {
+  if (!k || !pose) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  int r = download_state(k);
+  if (r != HSK_OK) return r;
+  rt_to_pose16(k->h_st->R, k->h_st->t, pose);
+  return HSK_OK;
+}
+extern "C" int hsk_set_pose(hsk_ctx* k, const float pose[16]) {
+  if (!k || !pose) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  return set_pose_internal(k, pose);
+}
+
+extern "C" int hsk_integrate(hsk_ctx* k, const uint16_t* depth, int w, int h, const float pose[16]) {
+  int r = check_dims(k, depth, w, h);
+  if (r != HSK_OK) return r;
+  if (!pose) return fail(k, HSK_ERR_ARG, "pose is null");
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  r = set_pose_internal(k, pose);
+  if (r != HSK_OK) return r;
+  r = stage_depth_host(k, depth);
+  if (r != HSK_OK) return r;
+  launch_scale_depth(k->stream, k->d_raw, w, h, k->lv[0].in, k->d_scaled);
+  enqueue_integrate(k);
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  HIPCHK(k, hipGetLastError());
+  return HSK_OK;
+}
+
+extern "C" int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h, const float pose[16], uint64_t* n_upd) {
+  int r = check_dims(k, depth, w, h);
+  if (r != HSK_OK) return r;
+  if (!pose || !n_upd) return fail(k, HSK_ERR_ARG, "null argument");
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  r = set_pose_internal(k, pose);
+  if (r != HSK_OK) return r;
+  r = stage_depth_host(k, depth);
+  if (r != HSK_OK) return r;
+  launch_scale_depth(k->stream, k->d_raw, w, h, k->lv[0].in, k->d_scaled);
+  HIPCHK(k, hipMemsetAsync(k->d_counter, 0, 8, k->stream));
+  launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter);
+  unsigned long long c = 0;
+  HIPCHK(k, hipMemcpyAsync(&c, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  *n_upd = c;
+  return HSK_OK;
+}
+
+extern "C" int hsk_raycast(hsk_ctx* k, const float pose[16], float* vmap, float* nmap, int32_t* keys) {
+  if (!k || !pose || !vmap || !nmap) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  int r = set_pose_internal(k, pose);
+  if (r != HSK_OK) return r;
+  const size_t P = (size_t)k->lv[0].W * k->lv[0].H;
+  launch_raycast(k->stream, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0],
+                 k->d_keys);
+  for (int l = 1; l < HSK_NLEVELS; ++l)
+    launch_resize_maps(k->stream, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l],
+                       k->d_nmod[l], k->d_st);
+  HIPCHK(k, hipMemcpyAsync(vmap, k->d_vmod[0], P * 12, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipMemcpyAsync(nmap, k->d_nmod[0], P * 12, hipMemcpyDeviceToHost, k->stream));
+  if (keys) HIPCHK(k, hipMemcpyAsync(keys, k->d_keys, P * 4, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  HIPCHK(k, hipGetLastError());
+  return HSK_OK;
+}
+
+extern "C" int hsk_preprocess(hsk_ctx* k, const uint16_t* depth, int w, int h) {
+  int r = check_dims(k, depth, w, h);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  r = stage_depth_host(k, depth);
+  if (r != HSK_OK) return r;
+  enqueue_preprocess(k);
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  HIPCHK(k, hipGetLastError());
+  return HSK_OK;
+}
+
+extern "C" int hsk_icp_accumulate(hsk_ctx* k, int level, const float pose_est[16], int row0, int row1, double out27[27]) {
+  if (!k || !pose_est || !out27) return HSK_ERR_ARG;
+  if (level < 0 || level >= HSK_NLEVELS) return fail(k, HSK_ERR_ARG, "level out of range");
+  if (row0 < 0 || row1 > k->lv[level].H || row0 >= row1) return fail(k, HSK_ERR_ARG, "row range out of bounds");
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  // estimate goes to (R,t); the previous pose (Rp,tp) is left as the tracker stored it
+  int r = download_state(k);
+  if (r != HSK_OK) return r;
+  TrackState saved = *k->h_st;
+  pose16_to_rt(pose_est, k->h_st->R, k->h_st->t);
+  k->h_st->lost = 0;
+  r = upload_state(k);
+  if (r != HSK_OK) return r;
+  const int nb = icp_num_blocks(k->lv[level].W, row1 - row0);
+  launch_icp_accumulate(k->stream, k->d_vcur[level], k->d_ncur[level], k->d_vmod[level], k->d_nmod[level],
+                        k->lv[level].W, k->lv[level].H, k->lv[level].in, k->d_st, k->cfg.icp_dist_thresh_m,
+                        k->cfg.icp_angle_thresh_sin, row0, row1, k->d_partials);
+  launch_icp_reduce(k->stream, k->d_partials, nb, k->d_sums);
+  HIPCHK(k, hipMemcpyAsync(out27, k->d_sums, 27 * sizeof(double), hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  *k->h_st = saved;
+  return upload_state(k);
+}
+
+extern "C" int hsk_icp_solve(const double in27[27], float x6[6], int* ok) {
+  if (!in27 || !x6 || !ok) return HSK_ERR_ARG;
+  *ok = host_solve6(in27, x6) ? 1 : 0;
+  if (!*ok)
+    for (int i = 0; i < 6; ++i) x6[i] = 0.0f;
+  return HSK_OK;
+}
+
+extern "C" int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz) {
+  if (!k) return HSK_ERR_ARG;
+  if (z0) *z0 = k->vp.zs0;
+  if (nz) *nz = k->vp.nzs;
+  return HSK_OK;
+}
+
+extern "C" int hsk_download_tsdf(hsk_ctx* k, int16_t* out) {
+  if (!k || !out) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  HIPCHK(k, hipMemcpyAsync(out, k->d_vol, k->vol_bytes, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
+  if (!k || !in) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  HIPCHK(k, hipMemcpyAsync(k->d_vol, in, k->vol_bytes, hipMemcpyHostToDevice, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+
+static float* map_ptr(hsk_ctx* k, int kind, int level) {
+  switch (kind) {
+    case 0: return k->d_vcur[level];
+    case 1: return k->d_ncur[level];
+    case 2: return k->d_vmod[level];
+    case 3: return k->d_nmod[level];
+  }
+  return nullptr;
+}
+extern "C" int hsk_download_map(hsk_ctx* k, int kind, int level, float* out) {
+  if (!k || !out || level < 0 || level >= HSK_NLEVELS || kind < 0 || kind > 3) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const size_t P = (size_t)k->lv[level].W * k->lv[level].H;
+  HIPCHK(k, hipMemcpyAsync(out, map_ptr(k, kind, level), P * 12, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+extern "C" int hsk_upload_map(hsk_ctx* k, int kind, int level, const float* in) {
+  if (!k || !in || level < 0 || level >= HSK_NLEVELS || kind < 0 || kind > 3) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const size_t P = (size_t)k->lv[level].W * k->lv[level].H;
+  HIPCHK(k, hipMemcpyAsync(map_ptr(k, kind, level), in, P * 12, hipMemcpyHostToDevice, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+extern "C" int hsk_download_depth_level(hsk_ctx* k, int level, uint16_t* out) {
+  if (!k || !out || level < 0 || level >= HSK_NLEVELS) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const size_t P = (size_t)k->lv[level].W * k->lv[level].H;
+  HIPCHK(k, hipMemcpyAsync(out, k->d_dep[level], P * 2, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+extern "C" int hsk_download_scaled_depth(hsk_ctx* k, float* out) {
+  if (!k || !out) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  HIPCHK(k, hipMemcpyAsync(out, k->d_scaled, (size_t)k->lv[0].W * k->lv[0].H * 4, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+
+extern "C" int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_points) {
+  if (!k || !n_points) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);
+  if (!k->d_rowcnt) {
+    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
+    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
+  }
+  launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
+  unsigned long long total = 0;
+  HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  *n_points = (size_t)total;
+  if (!xyz || cap_points == 0 || total == 0) return HSK_OK;
+  const size_t nw = total < cap_points ? (size_t)total : cap_points;
+  float* d_xyz = nullptr;
+  HIPCHK(k, hipMalloc((void**)&d_xyz, nw * 12));
+  launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, d_xyz, nw, 1);
+  hipError_t e = hipMemcpyAsync(xyz, d_xyz, nw * 12, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  (void)hipFree(d_xyz);
+  HIPCHK(k, e);
+  return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// profiling
+// ------------------------------------------------------------------------------------------------------
+extern "C" int hsk_set_profiling(hsk_ctx* k, int on) {
+  if (!k) return HSK_ERR_ARG;
+  k->prof = on != 0;
+  return HSK_OK;
+}
+extern "C" int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int reset) {
+  if (!k) return HSK_ERR_ARG;
+  if (sum_ms)
+    for (int i = 0; i < HSK_NSTAGES; ++i) sum_ms[i] = k->stage_ms[i];
+  if (n_frames) *n_frames = k->prof_frames;
+  if (reset) {
+    for (int i = 0; i < HSK_NSTAGES; ++i) k->stage_ms[i] = 0.0;
+    k->prof_frames = 0;
+  }
+  return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// multi-GPU (z-slab) building blocks: enqueue-only, the host runs its collective between them
+// ------------------------------------------------------------------------------------------------------
+extern "C" int hsk_mgpu_frame_index(const hsk_ctx* k) { return k ? k->frame : -1; }
+
+extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, int h) {
+  int r = check_dims(k, depth_dev, w, h);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
+  enqueue_preprocess(k);
+  if (k->frame == 0) {
+    enqueue_integrate(k);
+    for (int l = 0; l < HSK_NLEVELS; ++l)
+      launch_transform_maps(k->stream, k->d_vcur[l], k->d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l],
+                            k->d_nmod[l]);
+  } else {
+    launch_begin_frame(k->stream, k->d_st);
+  }
+  return HSK_OK;
+}
+
+extern "C" int hsk_mgpu_icp_accumulate(hsk_ctx* k, int level, int row0, int row1, void* sums27_dev) {
+  if (!k || !sums27_dev || level < 0 || level >= HSK_NLEVELS) return HSK_ERR_ARG;
+  if (row0 < 0 || row1 > k->lv[level].H || row0 > row1) return fail(k, HSK_ERR_ARG, "row range out of bounds");
+  if (row0 == row1) {
+    HIPCHK(k, hipMemsetAsync(sums27_dev, 0, 27 * sizeof(double), k->stream));
+    return HSK_OK;
+  }
+  const int nb = icp_num_blocks(k->lv[level].W, row1 - row0);
+  launch_icp_accumulate(k->stream, k->d_vcur[level], k->d_ncur[level], k->d_vmod[level], k->d_nmod[level],
+                        k->lv[level].W, k->lv[level].H, k->lv[level].in, k->d_st, k->cfg.icp_dist_thresh_m,
+                        k->cfg.icp_angle_thresh_sin, row0, row1, k->d_partials);
+  launch_icp_reduce(k->stream, k->d_partials, nb, (double*)sums27_dev);
+  return HSK_OK;
+}
+
+extern "C" int hsk_mgpu_icp_update(hsk_ctx* k, const void* sums27_dev) {
+  if (!k || !sums27_dev) return HSK_ERR_ARG;
+  launch_icp_update(k->stream, (const double*)sums27_dev, k->d_st);
+  return HSK_OK;
+}
+
+extern "C" int hsk_mgpu_integrate(hsk_ctx* k) {
+  if (!k) return HSK_ERR_ARG;
+  enqueue_integrate(k);
+  return HSK_OK;
+}
+
+extern "C" int hsk_mgpu_raycast_local(hsk_ctx* k, void* keys_dev) {
+  if (!k || !keys_dev) return HSK_ERR_ARG;
+  launch_raycast(k->stream, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0],
+                 k->d_keys);
+  HIPCHK(k, hipMemcpyAsync(keys_dev, k->d_keys, (size_t)k->lv[0].W * k->lv[0].H * 4, hipMemcpyDeviceToDevice, k->stream));
+  return HSK_OK;
+}
+
+extern "C" int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, void* maps_bits_dev) {
+  if (!k || !keys_min_dev || !maps_bits_dev) return HSK_ERR_ARG;
+  launch_resolve(k->stream, k->d_keys, (const int*)keys_min_dev, k->d_vmod[0], k->d_nmod[0], (int*)maps_bits_dev,
+                 k->lv[0].W * k->lv[0].H);
+  return HSK_OK;
+}
+
+extern "C" int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev, float pose_out[16],
+                                  int* tracked) {
+  if (!k) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const bool first = (k->frame == 0);
+  if (!first) {
+    if (!keys_min_dev || !maps_bits_dev) return fail(k, HSK_ERR_ARG, "composite buffers are null");
+    launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0],
+                 k->lv[0].W * k->lv[0].H);
+    for (int l = 1; l < HSK_NLEVELS; ++l)
+      launch_resize_maps(k->stream, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l],
+                         k->d_nmod[l], k->d_st);
+  }
+  int r = download_state(k);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipGetLastError());
+  if (first) {
+    k->frame = 1;
+    if (pose_out) rt_to_pose16(k->h_st->R, k->h_st->t, pose_out);
+    if (tracked) *tracked = 0;
+    return HSK_OK;
+  }
+  if (k->h_st->lost) {
+    r = do_reset(k);
+    if (r != HSK_OK) return r;
+    if (pose_out) rt_to_pose16(k->h_st->R, k->h_st->t, pose_out);
+    if (tracked) *tracked = 0;
+    return HSK_OK;
+  }
+  k->frame += 1;
+  if (pose_out) rt_to_pose16(k->h_st->R, k->h_st->t, pose_out);
+  if (tracked) *tracked = 1;
+  return HSK_OK;
+}

@@ -1,0 +1,567 @@
+// kernels_image.hip -- image-space kernels for gfx950: bilateral + scaleDepth, pyrDown, vertex/normal maps
+// (SURVEY.md A.3/A.4), map resize / transform (A.2/A.3), and the projective-association point-to-plane ICP
+// with its wavefront reduction and on-device 6x6 solve (A.5).
+#pragma clang fp contract(off)
+#include "hsk_dev.h"
+#include "hsk_launch.h"
+
+// ------------------------------------------------------------------------------------------------------
+// bilateral (13x13) fused with scaleDepth.  16x16 pixel tile per block, 28x28 depth tile + both weight
+// tables staged in LDS; every pixel sums its taps in the fixed dy-major / dx-minor order of the spec.
+// ------------------------------------------------------------------------------------------------------
+#define BIL_R 6
+#define BIL_T 16
+#define BIL_S (BIL_T + 2 * BIL_R)
+
+__global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* __restrict__ src, int W, int H, Intr in,
+                                                         const float* __restrict__ ws_tab,
+                                                         const float* __restrict__ wc_tab,
+                                                         unsigned short* __restrict__ dst, float* __restrict__ scaled) {
+  __shared__ int tile[BIL_S][BIL_S + 1];  // -1 marks "outside the image"
+  __shared__ float ws[13 * 13];
+  __shared__ float wc[512];
+  const int tid = threadIdx.y * BIL_T + threadIdx.x;
+  const int bx = blockIdx.x * BIL_T, by = blockIdx.y * BIL_T;
+  for (int i = tid; i < BIL_S * BIL_S; i += 256) {
+    const int ly = i / BIL_S, lx = i % BIL_S;
+    const int gx = bx + lx - BIL_R, gy = by + ly - BIL_R;
+    tile[ly][lx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? (int)src[gy * W + gx] : -1;
+  }
+  for (int i = tid; i < 169; i += 256) ws[i] = ws_tab[i];
+  for (int i = tid; i < 512; i += 256) wc[i] = wc_tab[i];
+  __syncthreads();
+  const int x = bx + threadIdx.x, y = by + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const int value = tile[threadIdx.y + BIL_R][threadIdx.x + BIL_R];
+  // scaleDepth (A.4)
+  {
+    const float xl = ((float)x - in.cx) / in.fx;
+    const float yl = ((float)y - in.cy) / in.fy;
+    const float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+    scaled[y * W + x] = ((float)value * lambda) / 1000.0f;
+  }
+  if (value == 0) {
+    dst[y * W + x] = 0;
+    return;
+  }
+  float sum1 = 0.0f, sum2 = 0.0f;
+  for (int dy = 0; dy < 13; ++dy) {
+#pragma unroll
+    for (int dx = 0; dx < 13; ++dx) {
+      const int tmp = tile[threadIdx.y + dy][threadIdx.x + dx];
+      if (tmp >= 0) {
+        int dd = value - tmp;
+        dd = dd < 0 ? -dd : dd;
+        const float wcv = dd < 512 ? wc[dd] : 0.0f;
+        const float w = ws[dy * 13 + dx] * wcv;
+        sum1 = sum1 + (float)tmp * w;
+        sum2 = sum2 + w;
+      }
+    }
+  }
+  int res = __float2int_rn(sum1 / sum2);
+  res = res < 0 ? 0 : (res > 32767 ? 32767 : res);
+  dst[y * W + x] = (unsigned short)res;
+}
+
+void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
+                            uint16_t* dst, float* scaled) {
+  dim3 block(BIL_T, BIL_T), grid((W + BIL_T - 1) / BIL_T, (H + BIL_T - 1) / BIL_T);
+  hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, ws, wc, dst, scaled);
+}
+
+// scaleDepth alone (stage-level integrate entry point)
+__global__ void k_scale_depth(const unsigned short* __restrict__ src, int W, int H, Intr in, float* __restrict__ scaled) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const float xl = ((float)x - in.cx) / in.fx;
+  const float yl = ((float)y - in.cy) / in.fy;
+  const float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+  scaled[y * W + x] = ((float)src[y * W + x] * lambda) / 1000.0f;
+}
+void launch_scale_depth(hipStream_t s, const uint16_t* src, int W, int H, Intr in, float* scaled) {
+  dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
+  hipLaunchKernelGGL(k_scale_depth, grid, block, 0, s, src, W, H, in, scaled);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pyrDown (A.3): integer 5x5 gated mean
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_pyrdown(const unsigned short* __restrict__ src, int W, int H, unsigned short* __restrict__ dst) {
+  const int w2 = W >> 1, h2 = H >> 1;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w2 || y >= h2) return;
+  const int center = src[(2 * y) * W + 2 * x];
+  const int y0 = max(2 * y - 2, 0), y1 = min(2 * y + 2, H - 1);
+  const int x0 = max(2 * x - 2, 0), x1 = min(2 * x + 2, W - 1);
+  int sum = 0, count = 0;
+  for (int cy = y0; cy <= y1; ++cy)
+    for (int cx = x0; cx <= x1; ++cx) {
+      const int val = src[cy * W + cx];
+      const int d = abs(val - center);
+      if (d < 90) {
+        sum += val;
+        ++count;
+      }
+    }
+  dst[y * w2 + x] = (unsigned short)(sum / count);
+}
+void launch_pyrdown(hipStream_t s, const uint16_t* src, int W, int H, uint16_t* dst) {
+  dim3 block(64, 4), grid((W / 2 + 63) / 64, (H / 2 + 3) / 4);
+  hipLaunchKernelGGL(k_pyrdown, grid, block, 0, s, src, W, H, dst);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// vertex + normal maps (A.3), fused: the two forward neighbours are re-projected instead of re-read
+// ------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ bool vertex_of(const unsigned short* __restrict__ d, int W, int u, int v, float cx,
+                                                 float cy, float fx_inv, float fy_inv, float& X, float& Y, float& Z) {
+  const float z = (float)d[v * W + u] / 1000.0f;
+  if (z != 0.0f) {
+    X = (z * ((float)u - cx)) * fx_inv;
+    Y = (z * ((float)v - cy)) * fy_inv;
+    Z = z;
+    return true;
+  }
+  X = Y = Z = HSK_NANF;
+  return false;
+}
+
+__global__ void k_vmap_nmap(const unsigned short* __restrict__ depth, int W, int H, Intr in, float* __restrict__ vmap,
+                            float* __restrict__ nmap) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+  if (u >= W || v >= H) return;
+  const size_t P = (size_t)W * H, i = (size_t)v * W + u;
+  const float fx_inv = 1.0f / in.fx, fy_inv = 1.0f / in.fy;
+  float x0, y0, z0;
+  const bool ok0 = vertex_of(depth, W, u, v, in.cx, in.cy, fx_inv, fy_inv, x0, y0, z0);
+  vmap[i] = x0;
+  vmap[P + i] = y0;
+  vmap[2 * P + i] = z0;
+  float n0 = HSK_NANF, n1 = HSK_NANF, n2 = HSK_NANF;
+  if (ok0 && u < W - 1 && v < H - 1) {
+    float x1, y1, z1, x2, y2, z2;
+    const bool ok1 = vertex_of(depth, W, u + 1, v, in.cx, in.cy, fx_inv, fy_inv, x1, y1, z1);
+    const bool ok2 = vertex_of(depth, W, u, v + 1, in.cx, in.cy, fx_inv, fy_inv, x2, y2, z2);
+    if (ok1 && ok2) {
+      const float ax = x1 - x0, ay = y1 - y0, az = z1 - z0;
+      const float bx = x2 - x0, by = y2 - y0, bz = z2 - z0;
+      const float r0 = ay * bz - az * by;
+      const float r1 = az * bx - ax * bz;
+      const float r2 = ax * by - ay * bx;
+      const float inv = 1.0f / sqrtf(hsk_dot3(r0, r1, r2, r0, r1, r2));
+      n0 = r0 * inv;
+      n1 = r1 * inv;
+      n2 = r2 * inv;
+    }
+  }
+  nmap[i] = n0;
+  nmap[P + i] = n1;
+  nmap[2 * P + i] = n2;
+}
+void launch_vmap_nmap(hipStream_t s, const uint16_t* depth, int W, int H, Intr in, float* vmap, float* nmap) {
+  dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
+  hipLaunchKernelGGL(k_vmap_nmap, grid, block, 0, s, depth, W, H, in, vmap, nmap);
+}
+
+// tranformMaps (A.2, first frame): v_g = R v + t, n_g = R n, pose taken from the device state
+__global__ void k_transform_maps(const float* __restrict__ vs, const float* __restrict__ ns, int P,
+                                 const TrackState* __restrict__ st, float* __restrict__ vd, float* __restrict__ nd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float* R = st->R;
+  const float vx = vs[i], vy = vs[P + i], vz = vs[2 * P + i];
+  float ox = HSK_NANF, oy = HSK_NANF, oz = HSK_NANF;
+  if (!hsk_isnan(vx)) {
+    ox = ((R[0] * vx + R[1] * vy) + R[2] * vz) + st->t[0];
+    oy = ((R[3] * vx + R[4] * vy) + R[5] * vz) + st->t[1];
+    oz = ((R[6] * vx + R[7] * vy) + R[8] * vz) + st->t[2];
+  }
+  vd[i] = ox;
+  vd[P + i] = oy;
+  vd[2 * P + i] = oz;
+  const float nx = ns[i], ny = ns[P + i], nz = ns[2 * P + i];
+  float qx = HSK_NANF, qy = HSK_NANF, qz = HSK_NANF;
+  if (!hsk_isnan(nx)) {
+    qx = (R[0] * nx + R[1] * ny) + R[2] * nz;
+    qy = (R[3] * nx + R[4] * ny) + R[5] * nz;
+    qz = (R[6] * nx + R[7] * ny) + R[8] * nz;
+  }
+  nd[i] = qx;
+  nd[P + i] = qy;
+  nd[2 * P + i] = qz;
+}
+void launch_transform_maps(hipStream_t s, const float* vs, const float* ns, int P, const TrackState* st, float* vd,
+                           float* nd) {
+  hipLaunchKernelGGL(k_transform_maps, dim3((P + 255) / 256), dim3(256), 0, s, vs, ns, P, st, vd, nd);
+}
+
+// resizeVMap + resizeNMap (A.3) in one launch
+__global__ void k_resize_maps(const float* __restrict__ vs, const float* __restrict__ ns, int W, int H,
+                              float* __restrict__ vd, float* __restrict__ nd, const TrackState* __restrict__ st) {
+  const int w2 = W >> 1, h2 = H >> 1;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w2 || y >= h2) return;
+  if (st->lost) return;
+  const size_t P = (size_t)W * H, P2 = (size_t)w2 * h2;
+  const size_t i00 = (size_t)(2 * y) * W + 2 * x, i01 = i00 + 1, i10 = i00 + W, i11 = i10 + 1;
+  const size_t o = (size_t)y * w2 + x;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float* src = m == 0 ? vs : ns;
+    float* dst = m == 0 ? vd : nd;
+    float a = HSK_NANF, b = HSK_NANF, c = HSK_NANF;
+    if (!(hsk_isnan(src[i00]) || hsk_isnan(src[i01]) || hsk_isnan(src[i10]) || hsk_isnan(src[i11]))) {
+      a = (((src[i00] + src[i01]) + src[i10]) + src[i11]) / 4.0f;
+      b = (((src[P + i00] + src[P + i01]) + src[P + i10]) + src[P + i11]) / 4.0f;
+      c = (((src[2 * P + i00] + src[2 * P + i01]) + src[2 * P + i10]) + src[2 * P + i11]) / 4.0f;
+      if (m == 1) {
+        const float inv = 1.0f / sqrtf(hsk_dot3(a, b, c, a, b, c));
+        a = a * inv;
+        b = b * inv;
+        c = c * inv;
+      }
+    }
+    dst[o] = a;
+    dst[P2 + o] = b;
+    dst[2 * P2 + o] = c;
+  }
+}
+void launch_resize_maps(hipStream_t s, const float* vs, const float* ns, int W, int H, float* vd, float* nd,
+                        const TrackState* st) {
+  dim3 block(64, 4), grid((W / 2 + 63) / 64, (H / 2 + 3) / 4);
+  hipLaunchKernelGGL(k_resize_maps, grid, block, 0, s, vs, ns, W, H, vd, nd, st);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ICP (A.5).  Per pixel: transform, project into the previous camera, gate, build the 7-vector row.  The
+// 27 products are formed in binary64 (exact) and snapped to multiples of 2^-26, which makes every partial
+// sum exact: the wave64 shuffle tree, the cross-wave LDS step, the cross-block step and (multi-GPU) the
+// RCCL all-reduce all give the same bits as a sequential sum.
+// ------------------------------------------------------------------------------------------------------
+#define ICP_PX 4      // pixels per lane
+#define ICP_BLOCK 256
+
+static __device__ __forceinline__ double quant26(double x) { return rint(x * 67108864.0) * (1.0 / 67108864.0); }
+
+__global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __restrict__ vcur,
+                                                              const float* __restrict__ ncur,
+                                                              const float* __restrict__ vprev,
+                                                              const float* __restrict__ nprev, int W, int H, Intr in,
+                                                              const TrackState* __restrict__ st, float dist_thresh,
+                                                              float angle_thresh, int row0, int row1,
+                                                              double* __restrict__ partials) {
+  __shared__ double sh[ICP_BLOCK / 64][27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  const size_t P = (size_t)W * H;
+  const int npx = (row1 - row0) * W;
+  if (!st->lost) {
+    const float* R = st->R;
+    const float* Rp = st->Rp;
+    const float t0 = st->t[0], t1 = st->t[1], t2 = st->t[2];
+    const float p0 = st->tp[0], p1 = st->tp[1], p2 = st->tp[2];
+    const int base = blockIdx.x * (ICP_BLOCK * ICP_PX) + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < ICP_PX; ++q) {
+      const int li = base + q * ICP_BLOCK;
+      if (li >= npx) break;
+      const size_t i = (size_t)row0 * W + li;
+      const float ncx = ncur[i];
+      if (hsk_isnan(ncx)) continue;
+      const float ncy = ncur[P + i], ncz = ncur[2 * P + i];
+      const float vcx = vcur[i], vcy = vcur[P + i], vcz = vcur[2 * P + i];
+      const float gx = ((R[0] * vcx + R[1] * vcy) + R[2] * vcz) + t0;
+      const float gy = ((R[3] * vcx + R[4] * vcy) + R[5] * vcz) + t1;
+      const float gz = ((R[6] * vcx + R[7] * vcy) + R[8] * vcz) + t2;
+      const float dx = gx - p0, dy = gy - p1, dz = gz - p2;
+      // Rprev^T * d
+      const float cpx = (Rp[0] * dx + Rp[3] * dy) + Rp[6] * dz;
+      const float cpy = (Rp[1] * dx + Rp[4] * dy) + Rp[7] * dz;
+      const float cpz = (Rp[2] * dx + Rp[5] * dy) + Rp[8] * dz;
+      if (!(cpz > 0.0f)) continue;
+      const float fu = (cpx * in.fx) / cpz + in.cx;
+      const float fv = (cpy * in.fy) / cpz + in.cy;
+      int u, v;
+      if (!hsk_rint_guard(fu, u) || !hsk_rint_guard(fv, v)) continue;
+      if (u < 0 || v < 0 || u >= W || v >= H) continue;
+      const size_t j = (size_t)v * W + u;
+      const float npx_ = nprev[j];
+      if (hsk_isnan(npx_)) continue;
+      const float npy = nprev[P + j], npz = nprev[2 * P + j];
+      const float vpx = vprev[j], vpy = vprev[P + j], vpz = vprev[2 * P + j];
+      const float ex = vpx - gx, ey = vpy - gy, ez = vpz - gz;
+      const float dist = sqrtf(hsk_dot3(ex, ey, ez, ex, ey, ez));
+      if (!(dist <= dist_thresh)) continue;
+      const float ngx = (R[0] * ncx + R[1] * ncy) + R[2] * ncz;
+      const float ngy = (R[3] * ncx + R[4] * ncy) + R[5] * ncz;
+      const float ngz = (R[6] * ncx + R[7] * ncy) + R[8] * ncz;
+      const float c0 = ngy * npz - ngz * npy;
+      const float c1 = ngz * npx_ - ngx * npz;
+      const float c2 = ngx * npy - ngy * npx_;
+      const float sine = sqrtf(hsk_dot3(c0, c1, c2, c0, c1, c2));
+      if (!(sine < angle_thresh)) continue;
+      float row[7];
+      row[0] = gy * npz - gz * npy;  // s x n
+      row[1] = gz * npx_ - gx * npz;
+      row[2] = gx * npy - gy * npx_;
+      row[3] = npx_;
+      row[4] = npy;
+      row[5] = npz;
+      row[6] = hsk_dot3(npx_, npy, npz, ex, ey, ez);
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 7; ++b) acc[k++] += quant26((double)row[a] * (double)row[b]);
+    }
+  }
+  // wave64 shuffle reduction (exact: order-independent by construction)
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sh[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < ICP_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * 27 + threadIdx.x] = v;
+  }
+}
+
+int icp_num_blocks(int W, int rows) { return (W * rows + ICP_BLOCK * ICP_PX - 1) / (ICP_BLOCK * ICP_PX); }
+
+void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
+                           int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,
+                           int row1, double* partials) {
+  const int nb = icp_num_blocks(W, row1 - row0);
+  hipLaunchKernelGGL(k_icp_accumulate, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
+                     dist_thresh, angle_thresh, row0, row1, partials);
+}
+
+// reduce per-block partials -> 27 sums (one block)
+__global__ __launch_bounds__(256) void k_icp_reduce(const double* __restrict__ partials, int nblocks,
+                                                    double* __restrict__ out27) {
+  __shared__ double sh[4][27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 27; ++k) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * 27 + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sh[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) out27[threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, double* out27) {
+  hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(256), 0, s, partials, nblocks, out27);
+}
+
+// ---- 6x6 solve + pose update, shared by the device kernel and the host mirror (hsk_icp_solve) ----
+__host__ __device__ static inline void hsk_sincos(double x, double* s, double* c) {
+  if (!(fabs(x) < 1.0e5)) {
+    *s = 0.0;
+    *c = 1.0;
+    return;
+  }
+  const double two_over_pi = 0.63661977236758134308;
+  const double pio2_hi = 1.57079632673412561417e+00;
+  const double pio2_lo = 6.07710050650619224932e-11;
+  const double kf = rint(x * two_over_pi);
+  const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+  const double r2 = r * r;
+  double S = -1.0 / 1307674368000.0;
+  S = S * r2 + 1.0 / 6227020800.0;
+  S = S * r2 - 1.0 / 39916800.0;
+  S = S * r2 + 1.0 / 362880.0;
+  S = S * r2 - 1.0 / 5040.0;
+  S = S * r2 + 1.0 / 120.0;
+  S = S * r2 - 1.0 / 6.0;
+  const double sr = r + (r * r2) * S;
+  double C = 1.0 / 20922789888000.0;
+  C = C * r2 - 1.0 / 87178291200.0;
+  C = C * r2 + 1.0 / 479001600.0;
+  C = C * r2 - 1.0 / 3628800.0;
+  C = C * r2 + 1.0 / 40320.0;
+  C = C * r2 - 1.0 / 720.0;
+  C = C * r2 + 1.0 / 24.0;
+  const double cr = (1.0 - 0.5 * r2) + (r2 * r2) * C;
+  const int q = ((int)kf) & 3;
+  if (q == 0) {
+    *s = sr;
+    *c = cr;
+  } else if (q == 1) {
+    *s = cr;
+    *c = -sr;
+  } else if (q == 2) {
+    *s = -sr;
+    *c = -cr;
+  } else {
+    *s = -cr;
+    *c = sr;
+  }
+}
+
+__host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6) {
+  double A[6][6], b[6], L[6][6];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const double v = in27[k++];
+      if (j == 6)
+        b[i] = v;
+      else {
+        A[i][j] = v;
+        A[j][i] = v;
+      }
+    }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+  double det = 1.0;
+  for (int j = 0; j < 6; ++j) {
+    double s = A[j][j];
+    for (int q = 0; q < j; ++q) s = s - L[j][q] * L[j][q];
+    if (!(s > 0.0)) return false;
+    const double d = sqrt(s);
+    L[j][j] = d;
+    det = det * s;
+    for (int i = j + 1; i < 6; ++i) {
+      double r = A[i][j];
+      for (int q = 0; q < j; ++q) r = r - L[i][q] * L[j][q];
+      L[i][j] = r / d;
+    }
+  }
+  if (!(det >= 1e-15)) return false;
+  double yv[6], xv[6];
+  for (int i = 0; i < 6; ++i) {
+    double r = b[i];
+    for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
+    yv[i] = r / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double r = yv[i];
+    for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
+    xv[i] = r / L[i][i];
+  }
+  for (int q = 0; q < 6; ++q) {
+    if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) return false;
+    x6[q] = (float)xv[q];
+  }
+  return true;
+}
+
+__host__ __device__ static inline void hsk_mat3mul(const float* A, const float* B, float* O) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+}
+
+__host__ __device__ static inline void hsk_pose_update(float* R, float* t, const float* x6) {
+  double sd, cd;
+  hsk_sincos((double)x6[0], &sd, &cd);
+  const float sa = (float)sd, ca = (float)cd;
+  hsk_sincos((double)x6[1], &sd, &cd);
+  const float sb = (float)sd, cb = (float)cd;
+  hsk_sincos((double)x6[2], &sd, &cd);
+  const float sg = (float)sd, cg = (float)cd;
+  const float Rx[9] = {1.0f, 0.0f, 0.0f, 0.0f, ca, -sa, 0.0f, sa, ca};
+  const float Ry[9] = {cb, 0.0f, sb, 0.0f, 1.0f, 0.0f, -sb, 0.0f, cb};
+  const float Rz[9] = {cg, -sg, 0.0f, sg, cg, 0.0f, 0.0f, 0.0f, 1.0f};
+  float Rzy[9], Rinc[9], Rn[9];
+  hsk_mat3mul(Rz, Ry, Rzy);
+  hsk_mat3mul(Rzy, Rx, Rinc);
+  const float n0 = ((Rinc[0] * t[0] + Rinc[1] * t[1]) + Rinc[2] * t[2]) + x6[3];
+  const float n1 = ((Rinc[3] * t[0] + Rinc[4] * t[1]) + Rinc[5] * t[2]) + x6[4];
+  const float n2 = ((Rinc[6] * t[0] + Rinc[7] * t[1]) + Rinc[8] * t[2]) + x6[5];
+  t[0] = n0;
+  t[1] = n1;
+  t[2] = n2;
+  hsk_mat3mul(Rinc, R, Rn);
+  for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+}
+
+// single-lane kernel: solve the reduced system and refine the pose held in TrackState
+__global__ void k_icp_update(const double* __restrict__ sums27, TrackState* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->lost) return;
+  double s[27];
+  for (int k = 0; k < 27; ++k) {
+    s[k] = sums27[k];
+    st->sums[k] = s[k];
+  }
+  float x6[6];
+  if (!hsk_solve6(s, x6)) {
+    st->lost = 1;
+    return;
+  }
+  float R[9], t[3];
+  for (int i = 0; i < 9; ++i) R[i] = st->R[i];
+  for (int i = 0; i < 3; ++i) t[i] = st->t[i];
+  hsk_pose_update(R, t, x6);
+  for (int i = 0; i < 9; ++i) st->R[i] = R[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = t[i];
+  st->n_iter += 1;
+}
+void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st) {
+  hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, s, sums27, st);
+}
+
+// fused reduce + solve + update (single-device path): one block
+__global__ __launch_bounds__(256) void k_icp_reduce_update(const double* __restrict__ partials, int nblocks,
+                                                           TrackState* __restrict__ st) {
+  __shared__ double sh[4][27];
+  __shared__ double tot[27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 27; ++k) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * 27 + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sh[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) tot[threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0 && !st->lost) {
+    double s[27];
+    for (int k = 0; k < 27; ++k) {
+      s[k] = tot[k];
+      st->sums[k] = s[k];
+    }
+    float x6[6];
+    if (!hsk_solve6(s, x6)) {
+      st->lost = 1;
+    } else {
+      float R[9], t[3];
+      for (int i = 0; i < 9; ++i) R[i] = st->R[i];
+      for (int i = 0; i < 3; ++i) t[i] = st->t[i];
+      hsk_pose_update(R, t, x6);
+      for (int i = 0; i < 9; ++i) st->R[i] = R[i];
+      for (int i = 0; i < 3; ++i) st->t[i] = t[i];
+      st->n_iter += 1;
+    }
+  }
+}
+void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st) {
+  hipLaunchKernelGGL(k_icp_reduce_update, dim3(1), dim3(256), 0, s, partials, nblocks, st);
+}
+
+// start of a tracked frame: previous pose <- current pose, clear the lost flag
+__global__ void k_begin_frame(TrackState* __restrict__ st) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 9; ++i) st->Rp[i] = st->R[i];
+  for (int i = 0; i < 3; ++i) st->tp[i] = st->t[i];
+  st->lost = 0;
+  st->n_iter = 0;
+}
+void launch_begin_frame(hipStream_t s, TrackState* st) { hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, s, st); }
+
+// host mirrors (used by hsk_icp_solve and by tests through the C ABI)
+bool host_solve6(const double* in27, float* x6) { return hsk_solve6(in27, x6); }
+void host_pose_update(float* R, float* t, const float* x6) { hsk_pose_update(R, t, x6); }

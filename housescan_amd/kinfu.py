@@ -1,0 +1,225 @@
+"""Host-side mirror of the KinFu tracker interface over the C ABI.
+
+Names follow the upstream KinFu application that HouseScan's README points users at
+(/root/reference/README.md:13-14): a tracker object fed one depth frame at a time, returning the camera
+pose; `extract_cloud` yields the packed float32 xyz cloud HouseScan stores in `Cloud.cloudPoints`
+(/root/reference/housescan/Main.hs:117-121).  Depth frames are numpy uint16 arrays of shape (h, w) in the
+row-major layout of HoniHelper.takeDepthSnapshot (/root/reference/housescan/HoniHelper.hs:20-36).
+Errors surface as `KinfuError` carrying `hsk_last_error` (the `Left String` of HoniHelper.hs:39-42).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class KinfuError(RuntimeError):
+    pass
+
+
+def default_config(n=512, **over):
+    lib = _lib.load()
+    cfg = _lib.HskConfig()
+    lib.hsk_default_config(C.byref(cfg), int(n))
+    for k, v in over.items():
+        if k in ("vol_size_m", "icp_iters", "init_pose"):
+            arr = getattr(cfg, k)
+            for i, x in enumerate(np.asarray(v).reshape(-1)):
+                arr[i] = x
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class KinfuTracker:
+    """One TSDF volume + tracker on one MI355X (one `hsk_ctx`)."""
+
+    def __init__(self, cfg=None, **over):
+        self.lib = _lib.load()
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        h = C.c_void_p()
+        rc = self.lib.hsk_create(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise KinfuError(f"hsk_create failed ({rc}): {self.lib.hsk_last_error(None).decode()}")
+        self.h = h
+        self.w, self.hgt = self.cfg.width, self.cfg.height
+        z0, nz = C.c_int(), C.c_int()
+        self.lib.hsk_stored_planes(self.h, C.byref(z0), C.byref(nz))
+        self.stored_z0, self.stored_nz = z0.value, nz.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise KinfuError(f"hskinfu error {rc}: {self.lib.hsk_last_error(self.h).decode()}")
+
+    @staticmethod
+    def _depth(depth):
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        if d.ndim != 2:
+            raise KinfuError("depth must be a (h, w) uint16 array")
+        return d
+
+    # ---- whole tracker step -------------------------------------------------------------------------
+    def process_frame(self, depth):
+        d = self._depth(depth)
+        pose = np.empty(16, np.float32)
+        tracked = C.c_int()
+        self._ck(self.lib.hsk_process_frame(self.h, d.ctypes.data, d.shape[1], d.shape[0], _fp(pose), C.byref(tracked)))
+        return pose.reshape(4, 4), bool(tracked.value)
+
+    def process_frame_dev(self, depth_dev_ptr):
+        pose = np.empty(16, np.float32)
+        tracked = C.c_int()
+        self._ck(self.lib.hsk_process_frame_dev(self.h, C.c_void_p(depth_dev_ptr), self.w, self.hgt, _fp(pose),
+                                                C.byref(tracked)))
+        return pose.reshape(4, 4), bool(tracked.value)
+
+    def reset(self):
+        self._ck(self.lib.hsk_reset(self.h))
+
+    # ---- stages ------------------------------------------------------------------------------------
+    def integrate(self, depth, pose):
+        d = self._depth(depth)
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._ck(self.lib.hsk_integrate(self.h, d.ctypes.data, d.shape[1], d.shape[0], _fp(p)))
+
+    def count_updates(self, depth, pose):
+        d = self._depth(depth)
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        n = C.c_uint64()
+        self._ck(self.lib.hsk_count_updates(self.h, d.ctypes.data, d.shape[1], d.shape[0], _fp(p), C.byref(n)))
+        return n.value
+
+    def raycast(self, pose, want_keys=False):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        v = np.empty((3, self.hgt, self.w), np.float32)
+        n = np.empty((3, self.hgt, self.w), np.float32)
+        keys = np.empty((self.hgt, self.w), np.int32) if want_keys else None
+        self._ck(self.lib.hsk_raycast(self.h, _fp(p), v.ctypes.data, n.ctypes.data, keys.ctypes.data if want_keys else None))
+        return (v, n, keys) if want_keys else (v, n)
+
+    def preprocess(self, depth):
+        d = self._depth(depth)
+        self._ck(self.lib.hsk_preprocess(self.h, d.ctypes.data, d.shape[1], d.shape[0]))
+
+    def icp_accumulate(self, level, pose_est, row0=0, row1=None):
+        p = np.ascontiguousarray(pose_est, np.float32).reshape(16)
+        if row1 is None:
+            row1 = self.hgt >> level
+        out = np.empty(27, np.float64)
+        self._ck(self.lib.hsk_icp_accumulate(self.h, level, _fp(p), row0, row1, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def icp_solve(self, sums27):
+        s = np.ascontiguousarray(sums27, np.float64)
+        x = np.empty(6, np.float32)
+        ok = C.c_int()
+        self._ck(self.lib.hsk_icp_solve(s.ctypes.data_as(C.POINTER(C.c_double)), _fp(x), C.byref(ok)))
+        return x, bool(ok.value)
+
+    def download_tsdf(self):
+        out = np.empty((self.stored_nz, self.cfg.vol_y, self.cfg.vol_x, 2), np.int16)
+        self._ck(self.lib.hsk_download_tsdf(self.h, out.ctypes.data))
+        return out
+
+    def upload_tsdf(self, vol):
+        v = np.ascontiguousarray(vol, np.int16)
+        assert v.size == self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2
+        self._ck(self.lib.hsk_upload_tsdf(self.h, v.ctypes.data))
+
+    def get_pose(self):
+        p = np.empty(16, np.float32)
+        self._ck(self.lib.hsk_get_pose(self.h, _fp(p)))
+        return p.reshape(4, 4)
+
+    def set_pose(self, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        self._ck(self.lib.hsk_set_pose(self.h, _fp(p)))
+
+    def download_map(self, kind, level):
+        out = np.empty((3, self.hgt >> level, self.w >> level), np.float32)
+        self._ck(self.lib.hsk_download_map(self.h, kind, level, out.ctypes.data))
+        return out
+
+    def upload_map(self, kind, level, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        self._ck(self.lib.hsk_upload_map(self.h, kind, level, a.ctypes.data))
+
+    def download_depth_level(self, level):
+        out = np.empty((self.hgt >> level, self.w >> level), np.uint16)
+        self._ck(self.lib.hsk_download_depth_level(self.h, level, out.ctypes.data))
+        return out
+
+    def download_scaled_depth(self):
+        out = np.empty((self.hgt, self.w), np.float32)
+        self._ck(self.lib.hsk_download_scaled_depth(self.h, out.ctypes.data))
+        return out
+
+    def extract_cloud(self, cap=None):
+        n = C.c_size_t()
+        self._ck(self.lib.hsk_extract_cloud(self.h, None, 0, C.byref(n)))
+        total = n.value
+        m = total if cap is None else min(cap, total)
+        out = np.empty((m, 3), np.float32)
+        if m:
+            self._ck(self.lib.hsk_extract_cloud(self.h, out.ctypes.data, m, C.byref(n)))
+        return out, total
+
+    # ---- streams / profiling -----------------------------------------------------------------------
+    def stream(self):
+        return self.lib.hsk_stream(self.h)
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.hsk_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.hsk_synchronize(self.h))
+
+    def set_profiling(self, on):
+        self._ck(self.lib.hsk_set_profiling(self.h, int(on)))
+
+    def stage_ms(self, reset=False):
+        ms = (C.c_double * _lib.HSK_NSTAGES)()
+        n = C.c_uint64()
+        self._ck(self.lib.hsk_stage_ms(self.h, ms, C.byref(n), int(reset)))
+        return list(ms), n.value
+
+
+def synth_pose(frame):
+    lib = _lib.load()
+    p = np.empty(16, np.float32)
+    lib.hsk_synth_pose(int(frame), _fp(p))
+    return p.reshape(4, 4)
+
+
+def synth_depth(pose, w=640, h=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
+    lib = _lib.load()
+    p = np.ascontiguousarray(pose, np.float32).reshape(16)
+    d = np.empty((h, w), np.uint16)
+    rc = lib.hsk_synth_render(_fp(p), w, h, fx, fy, cx, cy, d.ctypes.data)
+    if rc != 0:
+        raise KinfuError(f"hsk_synth_render failed ({rc})")
+    return d
+
+
+def bilateral_tables():
+    lib = _lib.load()
+    ws = np.empty(169, np.float32)
+    wc = np.empty(512, np.float32)
+    lib.hsk_bilateral_tables(_fp(ws), _fp(wc))
+    return ws, wc

@@ -1,0 +1,135 @@
+/*
+ * hskinfu.h -- C ABI of the MI355X-native KinectFusion core for HouseScan.
+ *
+ * The reference program (nh2/housescan) holds no KinectFusion code and no FFI; it exchanges FILES with an
+ * external PCL KinFu fork (/root/reference/README.md:13-14).  This header defines the seam the north_star
+ * asks for: a thin C ABI the Haskell host loop would bind with `foreign import ccall`.  Each entry point
+ * cites the reference interface whose data shape it honours or whose role it replaces:
+ *
+ *   depth frames in   : `takeDepthSnapshot :: IO (Either String (Vector Word16, (Int, Int)))`
+ *                       housescan/HoniHelper.hs:20-36 -- row-major uint16, i = y*w + x (Main.hs:1297-1300),
+ *                       0 = invalid (Main.hs:1297); errors are values, never exceptions (HoniHelper.hs:39-42).
+ *   clouds out        : `Cloud { cloudPoints :: Vector Vec3 }` packed float32 xyz, 12 B/point
+ *                       housescan/Main.hs:117-121, :641, :792; consumed by addPointCloud Main.hs:806.
+ *   poses / transforms: 16 floats row-major, LEFT-multiplicative (p' = M p) -- the form HouseScan exports
+ *                       in roomProjectionToString / roomProjectionToXfFormat, Main.hs:2271-2302.
+ *   products on disk  : cloud_downsampled.pcd, cloud_bin.pcd (Main.hs:1740, :1334-1345, :2437).
+ *
+ * Conventions: every call returns HSK_OK (0) or a negative error code; the message is available from
+ * hsk_last_error (maps to Haskell `Left String`).  Tracking loss is NOT an error: *tracked = 0 and the
+ * volume is reset.  A context is not re-entrant; distinct contexts are independent and
+ * may be driven from different OS threads.  The library never retains caller pointers past the call.
+ * No torch / C++ types cross this boundary.
+ */
+#ifndef HSKINFU_H
+#define HSKINFU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSK_OK 0
+#define HSK_ERR_ARG (-1)
+#define HSK_ERR_HIP (-2)
+#define HSK_ERR_STATE (-3)
+#define HSK_ERR_NOGPU (-4)
+
+#define HSK_LEVELS 3
+#define HSK_KEY_NONE 0x7fffffff
+
+typedef struct hsk_ctx hsk_ctx; /* opaque; one per volume / room */
+
+typedef struct {
+  int vol_x, vol_y, vol_z;      /* voxels, e.g. 256 / 512 / 1024; vol_x must be a multiple of 4         */
+  float vol_size_m[3];          /* metric extent, default 3 x 3 x 3                                    */
+  float trunc_dist_m;           /* default 0.03; clamped to >= 2.1 * max cell                           */
+  int width, height;            /* depth image, default 640 x 480 (the shape HoniHelper.hs:34-36 returns) */
+  float fx, fy, cx, cy;         /* default 525, 525, 319.5, 239.5                                       */
+  int icp_iters[HSK_LEVELS];    /* level 0 (finest) .. 2, default {10, 5, 4}; run coarsest first        */
+  float icp_dist_thresh_m;      /* 0.10                                                                 */
+  float icp_angle_thresh_sin;   /* sin(20 deg)                                                          */
+  float integrate_move_thresh;  /* 0 => integrate every frame                                           */
+  float init_pose[16];          /* row-major cam->world; default R = I, t = (1.5, 1.5, -0.3)            */
+  int device_id;                /* HIP device ordinal                                                   */
+  /* z-slab sharding (multi-GPU): this context stores planes [own_z0 - halo, own_z1 + halo) clipped to the
+   * volume and OWNS raycast steps whose far sample lies in [own_z0, own_z1).  Single device: 0, vol_z, 0. */
+  int own_z0, own_z1, halo;
+  int use_graph;                /* 1 = replay the steady-state frame as one hipGraph (default 1)        */
+} hsk_config;
+
+/* fills *c with the defaults above for an n^3 volume */
+void hsk_default_config(hsk_config* c, int n);
+
+int hsk_create(const hsk_config* c, hsk_ctx** out);
+void hsk_destroy(hsk_ctx* k);
+int hsk_reset(hsk_ctx* k);
+const char* hsk_last_error(const hsk_ctx* k); /* k may be NULL: last create error */
+
+/* Whole tracker step.  `depth` is caller-owned row-major uint16 millimetres (HoniHelper.hs:20; index
+ * convention Main.hs:1298-1300), read-only, may be freed on return.  pose_out: row-major,
+ * left-multiplicative cam->world (Main.hs:2278-2284). */
+int hsk_process_frame(hsk_ctx* k, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked);
+/* Same, the depth frame already resident in device memory (HBM) */
+int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float pose_out[16], int* tracked);
+
+/* Stage-level entry points: exist so parity tests and rocprof can isolate each kernel. */
+int hsk_integrate(hsk_ctx* k, const uint16_t* depth, int w, int h, const float pose[16]);
+int hsk_raycast(hsk_ctx* k, const float pose[16], float* vmap /* 3*h*w SoA */, float* nmap, int32_t* keys /* may be NULL */);
+int hsk_preprocess(hsk_ctx* k, const uint16_t* depth, int w, int h); /* bilateral, pyramid, vertex/normal maps */
+/* 27 sums for pose estimate `pose_est` against the stored model maps and previous pose, rows [row0,row1) */
+int hsk_icp_accumulate(hsk_ctx* k, int level, const float pose_est[16], int row0, int row1, double out27[27]);
+int hsk_icp_solve(const double in27[27], float x6[6], int* ok);       /* host mirror of the device solve */
+int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h, const float pose[16], uint64_t* n_upd);
+
+int hsk_download_tsdf(hsk_ctx* k, int16_t* tsdf_weight_pairs /* 2 * X*Y*stored_planes, x fastest */);
+int hsk_upload_tsdf(hsk_ctx* k, const int16_t* tsdf_weight_pairs);
+int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz);
+int hsk_get_pose(hsk_ctx* k, float pose[16]);
+int hsk_set_pose(hsk_ctx* k, const float pose[16]);
+/* kind: 0 current vertex, 1 current normal, 2 model vertex, 3 model normal; out = 3*(h>>level)*(w>>level) floats */
+int hsk_download_map(hsk_ctx* k, int kind, int level, float* out);
+int hsk_upload_map(hsk_ctx* k, int kind, int level, const float* in);
+int hsk_download_depth_level(hsk_ctx* k, int level, uint16_t* out); /* filtered pyramid */
+int hsk_download_scaled_depth(hsk_ctx* k, float* out);
+
+/* TSDF zero-crossing cloud: packed float32 xyz (the layout of Cloud.cloudPoints, Main.hs:120) in voxel order. */
+int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_points);
+
+/* Multi-GPU (z-slab) building blocks; device pointers so that the host's collective (RCCL through
+ * torch.distributed) can run on them without a host round trip.  All work is enqueued on hsk_stream(). */
+int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, int h); /* preprocess + (frame 0) transform */
+int hsk_mgpu_icp_accumulate(hsk_ctx* k, int level, int row0, int row1, void* sums27_dev /* double[27] */);
+int hsk_mgpu_icp_update(hsk_ctx* k, const void* sums27_dev);                /* solve + pose update on device */
+int hsk_mgpu_integrate(hsk_ctx* k);
+int hsk_mgpu_raycast_local(hsk_ctx* k, void* keys_dev /* int32[h*w] */);    /* slab-local march */
+int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, void* maps_bits_dev /* int32[6*h*w] */);
+int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev, float pose_out[16], int* tracked);
+int hsk_mgpu_frame_index(const hsk_ctx* k);
+
+/* streams / profiling */
+void* hsk_stream(hsk_ctx* k);                 /* hipStream_t the context launches on */
+int hsk_set_stream(hsk_ctx* k, void* stream); /* adopt the caller's hipStream_t (e.g. torch's current stream) */
+int hsk_synchronize(hsk_ctx* k);
+#define HSK_STAGE_PRE 0
+#define HSK_STAGE_ICP 1
+#define HSK_STAGE_INTEGRATE 2
+#define HSK_STAGE_RAYCAST 3
+#define HSK_NSTAGES 4
+int hsk_set_profiling(hsk_ctx* k, int on);    /* record HIP events around each stage of process_frame */
+int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int reset);
+int hsk_bilateral_tables(float ws[169], float wc[512]);
+
+/* Deterministic synthetic depth stream; host-only, no GPU needed. */
+int hsk_synth_pose(int frame, float pose[16]);
+int hsk_synth_render(const float pose[16], int w, int h, float fx, float fy, float cx, float cy, uint16_t* depth);
+
+/* Products on the file seam (Main.hs:1740, :1320-1345): binary PCD with float32 x y z */
+int hsk_write_pcd_xyz(const char* path, const float* xyz, size_t n_points);
+int hsk_voxel_downsample(const float* xyz, size_t n, float leaf_m, float* out, size_t cap, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

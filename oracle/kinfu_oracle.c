@@ -1,0 +1,877 @@
+/*
+ * kinfu_oracle.c -- CPU restatement of the KinectFusion hot path.  TEST INFRASTRUCTURE ONLY; see the
+ * header of kinfu_oracle.h ("PARITY UNPINNED").  Every stage cites the SURVEY.md Appendix A paragraph it
+ * follows (the reference repository itself holds no KinFu source: /root/reference/README.md:13-14).
+ *
+ * Numerical contract (shared with the HIP kernels, which are written independently against it):
+ *   - IEEE-754 binary32/binary64, round-to-nearest-even, one rounding per written operator;
+ *     no fused multiply-add anywhere (build with -ffp-contract=off), no fast-math;
+ *   - sqrtf and '/' are the correctly rounded operations;
+ *   - the only transcendental on data is the bilateral range weight, taken from a host-computed table;
+ *     sin/cos of the ICP increment use ora_sincos (fixed polynomial in binary64) so that the whole
+ *     tracker is bit-reproducible across CPU and GPU;
+ *   - expression trees are evaluated exactly as parenthesised below.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math [-fopenmp]).
+ */
+#include "kinfu_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define NANF (__builtin_nanf(""))
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.1 constants                                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+void ora_default_config(ora_config* c, int vol_n) {
+  memset(c, 0, sizeof(*c));
+  c->vol[0] = c->vol[1] = c->vol[2] = vol_n;
+  c->size[0] = c->size[1] = c->size[2] = 3.0f;
+  c->trunc = 0.03f;
+  c->W = 640;
+  c->H = 480;
+  c->fx = c->fy = 525.0f;
+  c->cx = 319.5f;
+  c->cy = 239.5f;
+  c->icp_iters[0] = 10;
+  c->icp_iters[1] = 5;
+  c->icp_iters[2] = 4;
+  c->dist_thresh = 0.10f;
+  c->angle_thresh = 0.3420201433256687f; /* sin(20 deg) */
+  c->move_thresh = 0.0f;
+  c->init_R[0] = c->init_R[4] = c->init_R[8] = 1.0f;
+  /* t = size/2 - (0,0,1.2*size_z/2)  (A.1) */
+  c->init_t[0] = c->size[0] / 2.0f;
+  c->init_t[1] = c->size[1] / 2.0f;
+  c->init_t[2] = c->size[2] / 2.0f - 1.2f * c->size[2] / 2.0f;
+}
+
+/* truncation distance clamped to >= 2.1 * max cell (A.1) */
+float ora_tau(const ora_config* c) {
+  float cx = c->size[0] / (float)c->vol[0];
+  float cy = c->size[1] / (float)c->vol[1];
+  float cz = c->size[2] / (float)c->vol[2];
+  float m = cx > cy ? cx : cy;
+  m = m > cz ? m : cz;
+  float lo = 2.1f * m;
+  return c->trunc > lo ? c->trunc : lo;
+}
+
+/* round-to-nearest-even to int with a range guard (values outside +-1e6 or NaN are "no pixel") */
+static inline int rint_guard(float f, int* out) {
+  if (!(f > -1.0e6f && f < 1.0e6f)) return 0;
+  *out = (int)lrintf(f);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.4 scaleDepth: z-depth in mm -> ray length in metres                                             */
+/* ------------------------------------------------------------------------------------------------ */
+void ora_scale_depth(const uint16_t* depth, int W, int H, float fx, float fy, float cx, float cy, float* out) {
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      float xl = ((float)u - cx) / fx;
+      float yl = ((float)v - cy) / fy;
+      float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
+      out[v * W + u] = ((float)depth[v * W + u] * lambda) / 1000.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.4 integrate (tsdf23), direct (non-incremental) form                                             */
+/* ------------------------------------------------------------------------------------------------ */
+uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], float tau, int zs0, int nzs,
+                       const float* scaled, int W, int H, float fx, float fy, float cx, float cy,
+                       const float R[9], const float t[3]) {
+  const int X = dims[0], Y = dims[1];
+  const float cellx = size[0] / (float)dims[0];
+  const float celly = size[1] / (float)dims[1];
+  const float cellz = size[2] / (float)dims[2];
+  const float tau_inv = 1.0f / tau;
+  /* Rinv = R^T */
+  const float i00 = R[0], i01 = R[3], i02 = R[6];
+  const float i10 = R[1], i11 = R[4], i12 = R[7];
+  const float i20 = R[2], i21 = R[5], i22 = R[8];
+  uint64_t n_upd = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : n_upd) schedule(static)
+#endif
+  for (int zz = 0; zz < nzs; ++zz) {
+    const int z = zs0 + zz;
+    const float gz = ((float)z + 0.5f) * cellz - t[2];
+    for (int y = 0; y < Y; ++y) {
+      const float gy = ((float)y + 0.5f) * celly - t[1];
+      int16_t* row = vol + 2 * ((size_t)zz * Y + y) * X;
+      for (int x = 0; x < X; ++x) {
+        const float gx = ((float)x + 0.5f) * cellx - t[0];
+        const float camx = (i00 * gx + i01 * gy) + i02 * gz;
+        const float camy = (i10 * gx + i11 * gy) + i12 * gz;
+        const float camz = (i20 * gx + i21 * gy) + i22 * gz;
+        if (!(camz > 0.0f)) continue;
+        const float inv_z = 1.0f / camz;
+        const float fu = (camx * fx) * inv_z + cx;
+        const float fv = (camy * fy) * inv_z + cy;
+        int u, v;
+        if (!rint_guard(fu, &u) || !rint_guard(fv, &v)) continue;
+        if (u < 0 || v < 0 || u >= W || v >= H) continue;
+        const float Ds = scaled[v * W + u];
+        const float dist = sqrtf(gz * gz + (gx * gx + gy * gy));
+        const float sdf = Ds - dist;
+        if (Ds != 0.0f && sdf >= -tau) {
+          float F = sdf * tau_inv;
+          F = F < 1.0f ? F : 1.0f;
+          const int16_t tp = row[2 * x], wp = row[2 * x + 1];
+          const float Fp = (float)tp / 32767.0f;
+          const float Wp = (float)wp;
+          const float Fn = (Fp * Wp + F) / (Wp + 1.0f);
+          int wn = wp + 1;
+          if (wn > ORA_MAX_WEIGHT) wn = ORA_MAX_WEIGHT;
+          int fixed = (int)(Fn * 32767.0f); /* truncation toward zero */
+          if (fixed > ORA_DIVISOR) fixed = ORA_DIVISOR;
+          if (fixed < -ORA_DIVISOR) fixed = -ORA_DIVISOR;
+          row[2 * x] = (int16_t)fixed;
+          row[2 * x + 1] = (int16_t)wn;
+          ++n_upd;
+        }
+      }
+    }
+  }
+  return n_upd;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.3 bilateral filter: 13x13, sigma_space 4.5 px, sigma_color 30 mm                                 */
+/* weight = ws(dx,dy) * wc(|dd|), each factor (float)exp((double)arg); taps summed dy-major, dx-minor */
+/* ------------------------------------------------------------------------------------------------ */
+#define BIL_R 6
+#define BIL_LUT 512
+static float g_ws[13][13];
+static float g_wc[BIL_LUT];
+static int g_bil_init = 0;
+static void bil_init(void) {
+  if (g_bil_init) return;
+  const float sig_s = 4.5f, sig_c = 30.0f;
+  const float s2 = 0.5f / (sig_s * sig_s);
+  const float c2 = 0.5f / (sig_c * sig_c);
+  for (int dy = -BIL_R; dy <= BIL_R; ++dy)
+    for (int dx = -BIL_R; dx <= BIL_R; ++dx) g_ws[dy + BIL_R][dx + BIL_R] = (float)exp(-(double)((float)(dx * dx + dy * dy) * s2));
+  for (int k = 0; k < BIL_LUT; ++k) g_wc[k] = (float)exp(-(double)((float)(k * k) * c2));
+  g_bil_init = 1;
+}
+
+void ora_bilateral(const uint16_t* src, int W, int H, uint16_t* dst) {
+  bil_init();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int value = src[y * W + x];
+      if (value == 0) {
+        dst[y * W + x] = 0;
+        continue;
+      }
+      const int y0 = y - BIL_R < 0 ? 0 : y - BIL_R, y1 = y + BIL_R > H - 1 ? H - 1 : y + BIL_R;
+      const int x0 = x - BIL_R < 0 ? 0 : x - BIL_R, x1 = x + BIL_R > W - 1 ? W - 1 : x + BIL_R;
+      float sum1 = 0.0f, sum2 = 0.0f;
+      for (int cy = y0; cy <= y1; ++cy)
+        for (int cx = x0; cx <= x1; ++cx) {
+          const int tmp = src[cy * W + cx];
+          int dd = value - tmp;
+          if (dd < 0) dd = -dd;
+          const float wc = dd < BIL_LUT ? g_wc[dd] : 0.0f;
+          const float w = g_ws[cy - y + BIL_R][cx - x + BIL_R] * wc;
+          sum1 = sum1 + (float)tmp * w;
+          sum2 = sum2 + w;
+        }
+      int res = (int)lrintf(sum1 / sum2);
+      if (res < 0) res = 0;
+      if (res > 32767) res = 32767;
+      dst[y * W + x] = (uint16_t)res;
+    }
+}
+
+/* A.3 pyrDown: 5x5 window mean of depths within 3*sigma_color of the centre (integer arithmetic) */
+void ora_pyrdown(const uint16_t* src, int W, int H, uint16_t* dst) {
+  const int w2 = W / 2, h2 = H / 2;
+  for (int y = 0; y < h2; ++y)
+    for (int x = 0; x < w2; ++x) {
+      const int center = src[(2 * y) * W + 2 * x];
+      const int y0 = 2 * y - 2 < 0 ? 0 : 2 * y - 2, y1 = 2 * y + 2 > H - 1 ? H - 1 : 2 * y + 2;
+      const int x0 = 2 * x - 2 < 0 ? 0 : 2 * x - 2, x1 = 2 * x + 2 > W - 1 ? W - 1 : 2 * x + 2;
+      int sum = 0, count = 0;
+      for (int cy = y0; cy <= y1; ++cy)
+        for (int cx = x0; cx <= x1; ++cx) {
+          const int val = src[cy * W + cx];
+          int d = val - center;
+          if (d < 0) d = -d;
+          if (d < 90) { /* 3 * sigma_color */
+            sum += val;
+            ++count;
+          }
+        }
+      dst[y * w2 + x] = (uint16_t)(sum / count);
+    }
+}
+
+/* A.3 vertex map: SoA planes x,y,z; NaN = invalid */
+void ora_vmap(const uint16_t* depth, int W, int H, float fx, float fy, float cx, float cy, float* vmap) {
+  const float fx_inv = 1.0f / fx, fy_inv = 1.0f / fy;
+  const size_t P = (size_t)W * H;
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      const size_t i = (size_t)v * W + u;
+      const float z = (float)depth[i] / 1000.0f;
+      if (z != 0.0f) {
+        vmap[i] = (z * ((float)u - cx)) * fx_inv;
+        vmap[P + i] = (z * ((float)v - cy)) * fy_inv;
+        vmap[2 * P + i] = z;
+      } else {
+        vmap[i] = vmap[P + i] = vmap[2 * P + i] = NANF;
+      }
+    }
+}
+
+static inline float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline void cross3(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline void rot3(const float R[9], const float v[3], float o[3]) {
+  o[0] = (R[0] * v[0] + R[1] * v[1]) + R[2] * v[2];
+  o[1] = (R[3] * v[0] + R[4] * v[1]) + R[5] * v[2];
+  o[2] = (R[6] * v[0] + R[7] * v[1]) + R[8] * v[2];
+}
+
+/* A.3 normal map: normalised cross product of forward differences */
+void ora_nmap(const float* vmap, int W, int H, float* nmap) {
+  const size_t P = (size_t)W * H;
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      const size_t i = (size_t)v * W + u;
+      float n[3] = {NANF, NANF, NANF};
+      if (u < W - 1 && v < H - 1) {
+        const size_t i01 = i + 1, i10 = i + W;
+        if (!isnan(vmap[i]) && !isnan(vmap[i01]) && !isnan(vmap[i10])) {
+          const float a[3] = {vmap[i01] - vmap[i], vmap[P + i01] - vmap[P + i], vmap[2 * P + i01] - vmap[2 * P + i]};
+          const float b[3] = {vmap[i10] - vmap[i], vmap[P + i10] - vmap[P + i], vmap[2 * P + i10] - vmap[2 * P + i]};
+          float r[3];
+          cross3(a, b, r);
+          const float inv = 1.0f / sqrtf(dot3(r, r));
+          n[0] = r[0] * inv;
+          n[1] = r[1] * inv;
+          n[2] = r[2] * inv;
+        }
+      }
+      nmap[i] = n[0];
+      nmap[P + i] = n[1];
+      nmap[2 * P + i] = n[2];
+    }
+}
+
+/* A.2 tranformMaps: v_g = R v + t, n_g = R n */
+void ora_transform_maps(const float* vsrc, const float* nsrc, int W, int H, const float R[9], const float t[3],
+                        float* vdst, float* ndst) {
+  const size_t P = (size_t)W * H;
+  for (size_t i = 0; i < P; ++i) {
+    float v[3] = {vsrc[i], vsrc[P + i], vsrc[2 * P + i]};
+    float o[3] = {NANF, NANF, NANF};
+    if (!isnan(v[0])) {
+      rot3(R, v, o);
+      o[0] = o[0] + t[0];
+      o[1] = o[1] + t[1];
+      o[2] = o[2] + t[2];
+    }
+    vdst[i] = o[0];
+    vdst[P + i] = o[1];
+    vdst[2 * P + i] = o[2];
+    float n[3] = {nsrc[i], nsrc[P + i], nsrc[2 * P + i]};
+    float q[3] = {NANF, NANF, NANF};
+    if (!isnan(n[0])) rot3(R, n, q);
+    ndst[i] = q[0];
+    ndst[P + i] = q[1];
+    ndst[2 * P + i] = q[2];
+  }
+}
+
+/* A.3 resizeVMap / resizeNMap: 2x2 mean, NaN if any tap is NaN; normals renormalised */
+static void resize_map(const float* src, int W, int H, float* dst, int normalize) {
+  const int w2 = W / 2, h2 = H / 2;
+  const size_t P = (size_t)W * H, P2 = (size_t)w2 * h2;
+  for (int y = 0; y < h2; ++y)
+    for (int x = 0; x < w2; ++x) {
+      const size_t i00 = (size_t)(2 * y) * W + 2 * x, i01 = i00 + 1, i10 = i00 + W, i11 = i10 + 1;
+      const size_t o = (size_t)y * w2 + x;
+      if (isnan(src[i00]) || isnan(src[i01]) || isnan(src[i10]) || isnan(src[i11])) {
+        dst[o] = dst[P2 + o] = dst[2 * P2 + o] = NANF;
+        continue;
+      }
+      float n[3];
+      for (int k = 0; k < 3; ++k)
+        n[k] = (((src[k * P + i00] + src[k * P + i01]) + src[k * P + i10]) + src[k * P + i11]) / 4.0f;
+      if (normalize) {
+        const float inv = 1.0f / sqrtf(dot3(n, n));
+        n[0] = n[0] * inv;
+        n[1] = n[1] * inv;
+        n[2] = n[2] * inv;
+      }
+      dst[o] = n[0];
+      dst[P2 + o] = n[1];
+      dst[2 * P2 + o] = n[2];
+    }
+}
+void ora_resize_vmap(const float* src, int W, int H, float* dst) { resize_map(src, W, H, dst, 0); }
+void ora_resize_nmap(const float* src, int W, int H, float* dst) { resize_map(src, W, H, dst, 1); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.5 ICP estimateCombined                                                                           */
+/* Products are formed in binary64 (exact for binary32 factors) and snapped to multiples of 2^-26      */
+/* before summation; every partial sum is then exactly representable while |sum| < 2^27, which makes   */
+/* the 27 sums independent of summation order (CPU loop == GPU tree == multi-GPU all-reduce).          */
+/* ------------------------------------------------------------------------------------------------ */
+static inline double quant26(double x) { return rint(x * 67108864.0) * (1.0 / 67108864.0); }
+
+uint64_t ora_icp_accumulate(const float* vcur, const float* ncur, const float* vprev_g, const float* nprev_g,
+                            int W, int H, float fx, float fy, float cx, float cy,
+                            const float R[9], const float t[3], const float Rprev[9], const float tprev[3],
+                            float dist_thresh, float angle_thresh, int row0, int row1, double out27[27]) {
+  const size_t P = (size_t)W * H;
+  /* Rprev_inv = Rprev^T */
+  const float Ri[9] = {Rprev[0], Rprev[3], Rprev[6], Rprev[1], Rprev[4], Rprev[7], Rprev[2], Rprev[5], Rprev[8]};
+  double acc[27];
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  uint64_t n_valid = 0;
+  for (int y = row0; y < row1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const size_t i = (size_t)y * W + x;
+      const float nc[3] = {ncur[i], ncur[P + i], ncur[2 * P + i]};
+      if (isnan(nc[0])) continue;
+      const float vc[3] = {vcur[i], vcur[P + i], vcur[2 * P + i]};
+      float vg[3];
+      rot3(R, vc, vg);
+      vg[0] = vg[0] + t[0];
+      vg[1] = vg[1] + t[1];
+      vg[2] = vg[2] + t[2];
+      const float dv[3] = {vg[0] - tprev[0], vg[1] - tprev[1], vg[2] - tprev[2]};
+      float vcp[3];
+      rot3(Ri, dv, vcp);
+      if (!(vcp[2] > 0.0f)) continue;
+      const float fu = (vcp[0] * fx) / vcp[2] + cx;
+      const float fv = (vcp[1] * fy) / vcp[2] + cy;
+      int u, v;
+      if (!rint_guard(fu, &u) || !rint_guard(fv, &v)) continue;
+      if (u < 0 || v < 0 || u >= W || v >= H) continue;
+      const size_t j = (size_t)v * W + u;
+      const float np[3] = {nprev_g[j], nprev_g[P + j], nprev_g[2 * P + j]};
+      if (isnan(np[0])) continue;
+      const float vp[3] = {vprev_g[j], vprev_g[P + j], vprev_g[2 * P + j]};
+      const float df[3] = {vp[0] - vg[0], vp[1] - vg[1], vp[2] - vg[2]};
+      const float dist = sqrtf(dot3(df, df));
+      if (!(dist <= dist_thresh)) continue;
+      float ng[3];
+      rot3(R, nc, ng);
+      float cr[3];
+      cross3(ng, np, cr);
+      const float sine = sqrtf(dot3(cr, cr));
+      if (!(sine < angle_thresh)) continue;
+      float row[7];
+      cross3(vg, np, row); /* s x n */
+      row[3] = np[0];
+      row[4] = np[1];
+      row[5] = np[2];
+      row[6] = dot3(np, df); /* n . (d - s) */
+      int k = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 7; ++b) acc[k++] += quant26((double)row[a] * (double)row[b]);
+      ++n_valid;
+    }
+  for (int k = 0; k < 27; ++k) out27[k] = acc[k];
+  return n_valid;
+}
+
+/* A.5 host side: symmetric fill, Cholesky (LL^T), |det| < 1e-15 or NaN => lost */
+int ora_icp_solve(const double in27[27], float x6[6]) {
+  double A[6][6], b[6], L[6][6];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const double v = in27[k++];
+      if (j == 6)
+        b[i] = v;
+      else {
+        A[i][j] = v;
+        A[j][i] = v;
+      }
+    }
+  memset(L, 0, sizeof(L));
+  double det = 1.0;
+  for (int j = 0; j < 6; ++j) {
+    double s = A[j][j];
+    for (int q = 0; q < j; ++q) s = s - L[j][q] * L[j][q];
+    if (!(s > 0.0)) {
+      for (int q = 0; q < 6; ++q) x6[q] = 0.0f;
+      return 0;
+    }
+    const double d = sqrt(s);
+    L[j][j] = d;
+    det = det * s;
+    for (int i = j + 1; i < 6; ++i) {
+      double r = A[i][j];
+      for (int q = 0; q < j; ++q) r = r - L[i][q] * L[j][q];
+      L[i][j] = r / d;
+    }
+  }
+  if (!(det >= 1e-15)) { /* also catches NaN */
+    for (int q = 0; q < 6; ++q) x6[q] = 0.0f;
+    return 0;
+  }
+  double yv[6], xv[6];
+  for (int i = 0; i < 6; ++i) {
+    double r = b[i];
+    for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
+    yv[i] = r / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double r = yv[i];
+    for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
+    xv[i] = r / L[i][i];
+  }
+  for (int q = 0; q < 6; ++q) {
+    if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) {
+      for (int w = 0; w < 6; ++w) x6[w] = 0.0f;
+      return 0;
+    }
+    x6[q] = (float)xv[q];
+  }
+  return 1;
+}
+
+/* sin/cos by Cody-Waite reduction + fixed Taylor/Horner polynomials in binary64 (bit-reproducible) */
+void ora_sincos(double x, double* s, double* c) {
+  if (!(fabs(x) < 1.0e5)) {
+    *s = 0.0;
+    *c = 1.0;
+    return;
+  }
+  const double two_over_pi = 0.63661977236758134308;
+  const double pio2_hi = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
+  const double pio2_lo = 6.07710050650619224932e-11;
+  const double kf = rint(x * two_over_pi);
+  const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+  const double r2 = r * r;
+  /* sin r = r + r^3 * S(r2), cos r = 1 - r2/2 + r2^2 * C(r2) */
+  double S = -1.0 / 1307674368000.0; /* -1/15! */
+  S = S * r2 + 1.0 / 6227020800.0;   /* 1/13! */
+  S = S * r2 - 1.0 / 39916800.0;     /* 1/11! */
+  S = S * r2 + 1.0 / 362880.0;       /* 1/9! */
+  S = S * r2 - 1.0 / 5040.0;         /* 1/7! */
+  S = S * r2 + 1.0 / 120.0;          /* 1/5! */
+  S = S * r2 - 1.0 / 6.0;            /* 1/3! */
+  const double sr = r + (r * r2) * S;
+  double C = 1.0 / 20922789888000.0; /* 1/16! */
+  C = C * r2 - 1.0 / 87178291200.0;  /* 1/14! */
+  C = C * r2 + 1.0 / 479001600.0;    /* 1/12! */
+  C = C * r2 - 1.0 / 3628800.0;      /* 1/10! */
+  C = C * r2 + 1.0 / 40320.0;        /* 1/8! */
+  C = C * r2 - 1.0 / 720.0;          /* 1/6! */
+  C = C * r2 + 1.0 / 24.0;           /* 1/4! */
+  const double cr = (1.0 - 0.5 * r2) + (r2 * r2) * C;
+  const int q = ((int)kf) & 3;
+  switch (q) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+  }
+}
+
+static void mat3mul(const float A[9], const float B[9], float O[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+}
+
+/* A.2 step (3): R_inc = Rz(gamma) Ry(beta) Rx(alpha); t <- R_inc t + t_inc; R <- R_inc R */
+void ora_pose_update(float R[9], float t[3], const float x6[6]) {
+  double sd, cd;
+  ora_sincos((double)x6[0], &sd, &cd);
+  const float sa = (float)sd, ca = (float)cd;
+  ora_sincos((double)x6[1], &sd, &cd);
+  const float sb = (float)sd, cb = (float)cd;
+  ora_sincos((double)x6[2], &sd, &cd);
+  const float sg = (float)sd, cg = (float)cd;
+  const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca};
+  const float Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb};
+  const float Rz[9] = {cg, -sg, 0, sg, cg, 0, 0, 0, 1};
+  float Rzy[9], Rinc[9], Rn[9], tn[3];
+  mat3mul(Rz, Ry, Rzy);
+  mat3mul(Rzy, Rx, Rinc);
+  rot3(Rinc, t, tn);
+  t[0] = tn[0] + x6[3];
+  t[1] = tn[1] + x6[4];
+  t[2] = tn[2] + x6[5];
+  mat3mul(Rinc, R, Rn);
+  memcpy(R, Rn, sizeof(Rn));
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.6 raycast                                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const int16_t* vol;
+  int X, Y, Z;
+  int zs0, nzs;
+  float cell[3];
+} rc_vol;
+
+/* voxel index of a coordinate: floor(p / cell), saturated so that the int conversion is defined */
+static inline int vox_of(float p, float cell) {
+  const float q = floorf(p / cell);
+  if (!(q >= 0.0f)) return -1; /* negative or NaN */
+  if (q > 1.0e6f) return 1000000;
+  return (int)q;
+}
+
+static inline int16_t rc_raw(const rc_vol* V, int x, int y, int z) {
+  const int zz = z - V->zs0;
+  if (zz < 0 || zz >= V->nzs) return 0; /* outside the stored slab: never reached when the halo is sized right */
+  return V->vol[2 * (((size_t)zz * V->Y + y) * V->X + x)];
+}
+static inline float rc_tsdf(const rc_vol* V, int x, int y, int z) { return (float)rc_raw(V, x, y, z) / 32767.0f; }
+
+static float rc_trilinear(const rc_vol* V, const float p[3]) {
+  int g[3] = {vox_of(p[0], V->cell[0]), vox_of(p[1], V->cell[1]), vox_of(p[2], V->cell[2])};
+  if (g[0] <= 0 || g[0] >= V->X - 1) return NANF;
+  if (g[1] <= 0 || g[1] >= V->Y - 1) return NANF;
+  if (g[2] <= 0 || g[2] >= V->Z - 1) return NANF;
+  float a[3];
+  for (int k = 0; k < 3; ++k) {
+    const float vc = ((float)g[k] + 0.5f) * V->cell[k];
+    if (p[k] < vc) g[k] -= 1;
+    a[k] = (p[k] - ((float)g[k] + 0.5f) * V->cell[k]) / V->cell[k];
+  }
+  const float A = a[0], B = a[1], C = a[2];
+  const int x = g[0], y = g[1], z = g[2];
+  float res = rc_tsdf(V, x, y, z) * (1.0f - A) * (1.0f - B) * (1.0f - C);
+  res = res + rc_tsdf(V, x, y, z + 1) * (1.0f - A) * (1.0f - B) * C;
+  res = res + rc_tsdf(V, x, y + 1, z) * (1.0f - A) * B * (1.0f - C);
+  res = res + rc_tsdf(V, x, y + 1, z + 1) * (1.0f - A) * B * C;
+  res = res + rc_tsdf(V, x + 1, y, z) * A * (1.0f - B) * (1.0f - C);
+  res = res + rc_tsdf(V, x + 1, y, z + 1) * A * (1.0f - B) * C;
+  res = res + rc_tsdf(V, x + 1, y + 1, z) * A * B * (1.0f - C);
+  res = res + rc_tsdf(V, x + 1, y + 1, z + 1) * A * B * C;
+  return res;
+}
+
+void ora_raycast(const int16_t* vol, const int dims[3], const float size[3], float tau, int zs0, int nzs,
+                 int zo0, int zo1, int W, int H, float fx, float fy, float cx, float cy,
+                 const float R[9], const float t[3], float* vmap, float* nmap, int32_t* keys,
+                 uint64_t* n_steps_out) {
+  rc_vol V;
+  V.vol = vol;
+  V.X = dims[0];
+  V.Y = dims[1];
+  V.Z = dims[2];
+  V.zs0 = zs0;
+  V.nzs = nzs;
+  V.cell[0] = size[0] / (float)dims[0];
+  V.cell[1] = size[1] / (float)dims[1];
+  V.cell[2] = size[2] / (float)dims[2];
+  const size_t P = (size_t)W * H;
+  const float time_step = tau * 0.8f;
+  const float max_time = 3.0f * ((size[0] + size[1]) + size[2]);
+  uint64_t n_steps = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : n_steps) schedule(dynamic, 4)
+#endif
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const size_t i = (size_t)y * W + x;
+      vmap[i] = vmap[P + i] = vmap[2 * P + i] = NANF;
+      nmap[i] = nmap[P + i] = nmap[2 * P + i] = NANF;
+      if (keys) keys[i] = ORA_KEY_NONE;
+      const float rn[3] = {((float)x - cx) / fx, ((float)y - cy) / fy, 1.0f};
+      float nx[3];
+      rot3(R, rn, nx);
+      const float inv = 1.0f / sqrtf(dot3(nx, nx));
+      float dir[3] = {nx[0] * inv, nx[1] * inv, nx[2] * inv};
+      for (int k = 0; k < 3; ++k)
+        if (dir[k] == 0.0f) dir[k] = 1e-15f;
+      float tmin[3], tmax[3];
+      for (int k = 0; k < 3; ++k) {
+        tmin[k] = ((dir[k] > 0.0f ? 0.0f : size[k]) - t[k]) / dir[k];
+        tmax[k] = ((dir[k] > 0.0f ? size[k] : 0.0f) - t[k]) / dir[k];
+      }
+      float t_start = fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]);
+      const float t_exit = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+      t_start = fmaxf(t_start, 0.0f);
+      if (!(t_start < t_exit)) continue;
+      float time_curr = t_start;
+      int step = 0;
+      for (; time_curr < max_time; time_curr = time_curr + time_step, ++step) {
+        const float tn = time_curr + time_step;
+        const float pn[3] = {t[0] + dir[0] * tn, t[1] + dir[1] * tn, t[2] + dir[2] * tn};
+        const int gx = vox_of(pn[0], V.cell[0]), gy = vox_of(pn[1], V.cell[1]), gz = vox_of(pn[2], V.cell[2]);
+        if (gx < 0 || gy < 0 || gz < 0 || gx >= V.X || gy >= V.Y || gz >= V.Z) break;
+        if (gz < zo0 || gz >= zo1) continue; /* step owned by another slab */
+        const float pc[3] = {t[0] + dir[0] * time_curr, t[1] + dir[1] * time_curr, t[2] + dir[2] * time_curr};
+        int px = vox_of(pc[0], V.cell[0]), py = vox_of(pc[1], V.cell[1]), pz = vox_of(pc[2], V.cell[2]);
+        px = px < 0 ? 0 : (px > V.X - 1 ? V.X - 1 : px);
+        py = py < 0 ? 0 : (py > V.Y - 1 ? V.Y - 1 : py);
+        pz = pz < 0 ? 0 : (pz > V.Z - 1 ? V.Z - 1 : pz);
+        const int16_t raw_prev = rc_raw(&V, px, py, pz);
+        const int16_t raw = rc_raw(&V, gx, gy, gz);
+        ++n_steps;
+        if (raw_prev < 0 && raw > 0) { /* back face */
+          if (keys) keys[i] = (step << 1) | 1;
+          break;
+        }
+        if (raw_prev > 0 && raw < 0) { /* zero crossing */
+          int32_t key = (step << 1) | 1;
+          const float Ftdt = rc_trilinear(&V, pn);
+          if (!isnan(Ftdt)) {
+            const float Ft = rc_trilinear(&V, pc);
+            if (!isnan(Ft)) {
+              const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
+              /* deviation from A.6: reject an interpolated time outside
+               * [t - step/2, t + 3 step/2]; bounds the taps to the slab halo. */
+              if (Ts >= time_curr - 0.5f * time_step && Ts <= time_curr + 1.5f * time_step) {
+                const float vtx[3] = {t[0] + dir[0] * Ts, t[1] + dir[1] * Ts, t[2] + dir[2] * Ts};
+                vmap[i] = vtx[0];
+                vmap[P + i] = vtx[1];
+                vmap[2 * P + i] = vtx[2];
+                key = (step << 1);
+                const int qx = vox_of(pc[0], V.cell[0]), qy = vox_of(pc[1], V.cell[1]), qz = vox_of(pc[2], V.cell[2]);
+                if (qx > 1 && qy > 1 && qz > 1 && qx < V.X - 2 && qy < V.Y - 2 && qz < V.Z - 2) {
+                  float n[3];
+                  for (int k = 0; k < 3; ++k) {
+                    float p1[3] = {vtx[0], vtx[1], vtx[2]}, p2[3] = {vtx[0], vtx[1], vtx[2]};
+                    p1[k] = p1[k] + V.cell[k];
+                    p2[k] = p2[k] - V.cell[k];
+                    n[k] = rc_trilinear(&V, p1) - rc_trilinear(&V, p2);
+                  }
+                  const float ninv = 1.0f / sqrtf(dot3(n, n));
+                  nmap[i] = n[0] * ninv;
+                  nmap[P + i] = n[1] * ninv;
+                  nmap[2 * P + i] = n[2] * ninv;
+                }
+              }
+            }
+          }
+          if (keys) keys[i] = key;
+          break;
+        }
+      }
+    }
+  if (n_steps_out) *n_steps_out = n_steps;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.7 extractCloud: zero crossings between +x/+y/+z neighbours, linear interpolation, voxel order    */
+/* ------------------------------------------------------------------------------------------------ */
+size_t ora_extract_cloud(const int16_t* vol, const int dims[3], const float size[3], float* xyz, size_t cap) {
+  const int X = dims[0], Y = dims[1], Z = dims[2];
+  const float cell[3] = {size[0] / (float)X, size[1] / (float)Y, size[2] / (float)Z};
+  size_t n = 0;
+  for (int z = 0; z < Z; ++z)
+    for (int y = 0; y < Y; ++y)
+      for (int x = 0; x < X; ++x) {
+        const size_t i = ((size_t)z * Y + y) * X + x;
+        const int16_t w = vol[2 * i + 1];
+        const int16_t fr = vol[2 * i];
+        if (w == 0 || fr == ORA_DIVISOR) continue;
+        const float F = (float)fr / 32767.0f;
+        const float Vc[3] = {((float)x + 0.5f) * cell[0], ((float)y + 0.5f) * cell[1], ((float)z + 0.5f) * cell[2]};
+        const int g[3] = {x, y, z};
+        const size_t stride[3] = {1, (size_t)X, (size_t)X * Y};
+        for (int k = 0; k < 3; ++k) {
+          if (g[k] + 1 >= dims[k]) continue;
+          const size_t j = i + stride[k];
+          const int16_t wn = vol[2 * j + 1];
+          const int16_t fnr = vol[2 * j];
+          if (wn == 0 || fnr == ORA_DIVISOR) continue;
+          if (!((fr > 0 && fnr < 0) || (fr < 0 && fnr > 0))) continue;
+          const float Fn = (float)fnr / 32767.0f;
+          float p[3] = {Vc[0], Vc[1], Vc[2]};
+          const float Vn = Vc[k] + cell[k];
+          const float d_inv = 1.0f / (fabsf(F) + fabsf(Fn));
+          p[k] = (Vc[k] * fabsf(Fn) + Vn * fabsf(F)) * d_inv;
+          if (n < cap) {
+            xyz[3 * n] = p[0];
+            xyz[3 * n + 1] = p[1];
+            xyz[3 * n + 2] = p[2];
+          }
+          ++n;
+        }
+      }
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.2 tracker state machine                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+struct ora_tracker {
+  ora_config c;
+  float tau;
+  int16_t* vol;
+  int frame;
+  float R[9], t[3];
+  uint16_t* dep[ORA_LEVELS];
+  float *vcur[ORA_LEVELS], *ncur[ORA_LEVELS], *vmod[ORA_LEVELS], *nmod[ORA_LEVELS];
+  float* scaled;
+  double secs[4];
+  uint64_t last_vupd;
+};
+
+ora_tracker* ora_tracker_create(const ora_config* c) {
+  ora_tracker* k = (ora_tracker*)calloc(1, sizeof(*k));
+  k->c = *c;
+  k->tau = ora_tau(c);
+  const size_t nvox = (size_t)c->vol[0] * c->vol[1] * c->vol[2];
+  k->vol = (int16_t*)calloc(nvox * 2, sizeof(int16_t));
+  for (int l = 0; l < ORA_LEVELS; ++l) {
+    const size_t P = (size_t)(c->W >> l) * (c->H >> l);
+    k->dep[l] = (uint16_t*)calloc(P, sizeof(uint16_t));
+    k->vcur[l] = (float*)calloc(3 * P, sizeof(float));
+    k->ncur[l] = (float*)calloc(3 * P, sizeof(float));
+    k->vmod[l] = (float*)calloc(3 * P, sizeof(float));
+    k->nmod[l] = (float*)calloc(3 * P, sizeof(float));
+  }
+  k->scaled = (float*)calloc((size_t)c->W * c->H, sizeof(float));
+  ora_tracker_reset(k);
+  return k;
+}
+
+void ora_tracker_destroy(ora_tracker* k) {
+  if (!k) return;
+  free(k->vol);
+  for (int l = 0; l < ORA_LEVELS; ++l) {
+    free(k->dep[l]);
+    free(k->vcur[l]);
+    free(k->ncur[l]);
+    free(k->vmod[l]);
+    free(k->nmod[l]);
+  }
+  free(k->scaled);
+  free(k);
+}
+
+void ora_tracker_reset(ora_tracker* k) {
+  const size_t nvox = (size_t)k->c.vol[0] * k->c.vol[1] * k->c.vol[2];
+  memset(k->vol, 0, nvox * 2 * sizeof(int16_t));
+  memcpy(k->R, k->c.init_R, sizeof(k->R));
+  memcpy(k->t, k->c.init_t, sizeof(k->t));
+  k->frame = 0;
+}
+
+static void pose_to16(const float R[9], const float t[3], float m[16]) {
+  for (int i = 0; i < 3; ++i) {
+    m[i * 4] = R[i * 3];
+    m[i * 4 + 1] = R[i * 3 + 1];
+    m[i * 4 + 2] = R[i * 3 + 2];
+    m[i * 4 + 3] = t[i];
+  }
+  m[12] = m[13] = m[14] = 0.0f;
+  m[15] = 1.0f;
+}
+
+/* integration gate (A.2 step 5); only evaluated when move_thresh > 0 */
+static int gate_passes(const float R[9], const float t[3], const float Rp[9], const float tp[3], float thr) {
+  if (!(thr > 0.0f)) return 1;
+  /* R^-1 R_prev = R^T R_prev; rotation angle = acos((trace-1)/2) */
+  float tr = 0.0f;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) tr += R[j * 3 + i] * Rp[j * 3 + i];
+  float cs = (tr - 1.0f) / 2.0f;
+  cs = cs > 1.0f ? 1.0f : (cs < -1.0f ? -1.0f : cs);
+  const float rnorm = acosf(cs);
+  const float d[3] = {t[0] - tp[0], t[1] - tp[1], t[2] - tp[2]};
+  const float tnorm = sqrtf(dot3(d, d));
+  return (rnorm + tnorm) / 2.0f >= thr;
+}
+
+int ora_tracker_process(ora_tracker* k, const uint16_t* depth, float pose16[16]) {
+  const ora_config* c = &k->c;
+  const int W = c->W, H = c->H;
+  double t0 = now_s();
+  /* (1) bilateral -> pyramid -> vertex / normal maps */
+  ora_bilateral(depth, W, H, k->dep[0]);
+  for (int l = 1; l < ORA_LEVELS; ++l) ora_pyrdown(k->dep[l - 1], W >> (l - 1), H >> (l - 1), k->dep[l]);
+  for (int l = 0; l < ORA_LEVELS; ++l) {
+    const float s = (float)(1 << l);
+    ora_vmap(k->dep[l], W >> l, H >> l, c->fx / s, c->fy / s, c->cx / s, c->cy / s, k->vcur[l]);
+    ora_nmap(k->vcur[l], W >> l, H >> l, k->ncur[l]);
+  }
+  ora_scale_depth(depth, W, H, c->fx, c->fy, c->cx, c->cy, k->scaled);
+  double t1 = now_s();
+  k->secs[0] += t1 - t0;
+
+  if (k->frame == 0) { /* (2) first frame */
+    k->last_vupd = ora_integrate(k->vol, c->vol, c->size, k->tau, 0, c->vol[2], k->scaled, W, H, c->fx, c->fy, c->cx,
+                                 c->cy, k->R, k->t);
+    for (int l = 0; l < ORA_LEVELS; ++l)
+      ora_transform_maps(k->vcur[l], k->ncur[l], W >> l, H >> l, k->R, k->t, k->vmod[l], k->nmod[l]);
+    k->secs[2] += now_s() - t1;
+    k->frame = 1;
+    pose_to16(k->R, k->t, pose16);
+    return 0;
+  }
+
+  /* (3) ICP, coarse to fine */
+  float R[9], t[3];
+  memcpy(R, k->R, sizeof(R));
+  memcpy(t, k->t, sizeof(t));
+  for (int l = ORA_LEVELS - 1; l >= 0; --l) {
+    const float s = (float)(1 << l);
+    for (int it = 0; it < c->icp_iters[l]; ++it) {
+      double sums[27];
+      float x6[6];
+      ora_icp_accumulate(k->vcur[l], k->ncur[l], k->vmod[l], k->nmod[l], W >> l, H >> l, c->fx / s, c->fy / s,
+                         c->cx / s, c->cy / s, R, t, k->R, k->t, c->dist_thresh, c->angle_thresh, 0, H >> l, sums);
+      if (!ora_icp_solve(sums, x6)) {
+        k->secs[1] += now_s() - t1;
+        ora_tracker_reset(k);
+        pose_to16(k->R, k->t, pose16);
+        return 0;
+      }
+      ora_pose_update(R, t, x6);
+    }
+  }
+  double t2 = now_s();
+  k->secs[1] += t2 - t1;
+  /* (4)-(6) store pose, gate, integrate raw depth */
+  const int do_integrate = gate_passes(R, t, k->R, k->t, c->move_thresh);
+  memcpy(k->R, R, sizeof(R));
+  memcpy(k->t, t, sizeof(t));
+  if (do_integrate)
+    k->last_vupd = ora_integrate(k->vol, c->vol, c->size, k->tau, 0, c->vol[2], k->scaled, W, H, c->fx, c->fy, c->cx,
+                                 c->cy, k->R, k->t);
+  double t3 = now_s();
+  k->secs[2] += t3 - t2;
+  /* (7) raycast -> model level 0, resize -> levels 1, 2 */
+  ora_raycast(k->vol, c->vol, c->size, k->tau, 0, c->vol[2], 0, c->vol[2], W, H, c->fx, c->fy, c->cx, c->cy, k->R,
+              k->t, k->vmod[0], k->nmod[0], NULL, NULL);
+  for (int l = 1; l < ORA_LEVELS; ++l) {
+    ora_resize_vmap(k->vmod[l - 1], W >> (l - 1), H >> (l - 1), k->vmod[l]);
+    ora_resize_nmap(k->nmod[l - 1], W >> (l - 1), H >> (l - 1), k->nmod[l]);
+  }
+  k->secs[3] += now_s() - t3;
+  k->frame += 1;
+  pose_to16(k->R, k->t, pose16);
+  return 1;
+}
+
+const int16_t* ora_tracker_volume(const ora_tracker* k) { return k->vol; }
+const float* ora_tracker_model_vmap(const ora_tracker* k, int level) { return k->vmod[level]; }
+const float* ora_tracker_model_nmap(const ora_tracker* k, int level) { return k->nmod[level]; }
+void ora_tracker_stage_seconds(const ora_tracker* k, double out4[4]) { memcpy(out4, k->secs, sizeof(k->secs)); }
+uint64_t ora_tracker_last_vupd(const ora_tracker* k) { return k->last_vupd; }
