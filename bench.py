@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec fused (640x480 depth into a 512^3 TSDF): integrate + ICP + raycast per frame.
+
+One "step" = one whole tracker step (`hsk_process_frame_dev`: bilateral/pyramid/maps, 19 ICP iterations,
+TSDF integrate, TSDF raycast, model pyramid) on one synthetic 640x480 depth frame that is already resident
+in HBM when the timed region starts.  Prints ONE JSON line (see the task contract) with the extra objects
+`roofline` (integrate kernel vs the HBM roofline, algorithmic bytes = 8 B x V_upd + 2 B x W x H, SURVEY.md
+8(d)) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+
+  python bench.py                       # 1 GPU, 512^3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   # z-slab sharded
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_frames(hsk, first, count):
+    poses = [hsk.synth_pose(k) for k in range(first, first + count)]
+    return poses, [hsk.synth_depth(p) for p in poses]
+
+
+def cpu_baseline(volume, sample_frames, hsk):
+    """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload: frames 0..sample_frames."""
+    from oracle import oracle as O
+    threads = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    cfg = O.default_config(volume, omp=True)
+    trk = O.Tracker(cfg, omp=True)
+    _, frames = make_frames(hsk, 0, sample_frames + 1)
+    trk.process(frames[0])  # frame 0 is the untracked first frame (integrate only)
+    t0 = time.perf_counter()
+    for d in frames[1:]:
+        trk.process(d)
+    dt = time.perf_counter() - t0
+    stages = trk.stage_seconds()
+    trk.close()
+    return {
+        "value": round(sample_frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{sample_frames} tracked frames of the same synthetic stream into a {volume}^3 TSDF "
+                  f"(oracle/kinfu_oracle.c, gcc -O2 -fopenmp, {threads} threads)",
+        "stage_seconds": {"preprocess": round(stages[0], 3), "icp": round(stages[1], 3),
+                          "integrate": round(stages[2], 3), "raycast": round(stages[3], 3)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")
+    ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
+    args = ap.parse_args()
+
+    import torch
+
+    import housescan_amd as hsk
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    K, Wm = args.steps, args.warmup
+    n = args.volume
+    total = 1 + Wm + K  # frame 0 is the untracked first frame
+    prof_frames = min(K, 50)
+    poses_gt, frames = make_frames(hsk, 0, total + prof_frames)
+    dev_frames = [torch.from_numpy(f.view(np.int16)).cuda(local_rank) for f in frames]
+    torch.cuda.synchronize()
+
+    if world > 1:
+        from housescan_amd.sharded import ShardedKinfu
+        eng = ShardedKinfu(n, rank, world, local_rank, mode=args.mode, icp=args.icp)
+        step = eng.process_frame_dev
+        trk = eng.tracker
+    else:
+        trk = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=args.graph)
+        step = lambda t: trk.process_frame_dev(t.data_ptr())  # noqa: E731
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup (includes frame 0 and the hipGraph capture)
+    lost = 0
+    for i in range(1 + Wm):
+        _, ok = step(dev_frames[i])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(1 + Wm, total):
+        pose, ok = step(dev_frames[i])
+        lost += (not ok)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    rooms = world if (world > 1 and args.mode == "rooms") else 1
+    fps = rooms * K / elapsed
+    gt = poses_gt[total - 1]
+    err_mm = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0)
+
+    out = {
+        "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True,
+        "scaling": "weak" if rooms > 1 else ("strong" if world > 1 else "weak"),
+        "vs_baseline": None, "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+        "config": {"workload": "configs[2]-shaped: synthetic 640x480 depth @ scripted trajectory into %d^3 TSDF, "
+                               "3 m cube, integrate + 19-iteration ICP + raycast per frame" % n,
+                   "volume": n, "image": [640, 480], "icp_iters": [10, 5, 4],
+                   "parallelism": ("1 gpu" if world == 1 else f"{args.mode}{world}" + (f"-icp-{args.icp}" if args.mode == "slab" else "")),
+                   "graph": bool(args.graph)},
+        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3)},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel (integrate), HIP events on the library's own stream ----
+        trk.set_profiling(True)
+        trk.stage_ms(reset=True)
+        prof_poses = []
+        for i in range(total, total + prof_frames):
+            p, ok = step(dev_frames[i])
+            prof_poses.append(p.copy())
+        ms, nf = trk.stage_ms(reset=True)
+        trk.set_profiling(False)
+        t_int = ms[2] / nf * 1e-3
+        vupd = [trk.count_updates(frames[total + j], prof_poses[j]) for j in range(0, prof_frames, max(1, prof_frames // 10))]
+        v_mean = float(np.mean(vupd))
+        alg_bytes = 8.0 * v_mean + 2.0 * 640 * 480
+        achieved = alg_bytes / t_int / 1e9
+        sweep = 8.0 * n ** 3 / t_int / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_integrate<false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
+            "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
+            "sweep_GBps_upper_bound_bytes_not_algorithmic": round(sweep, 1),
+            "cache_note": ("%d^3 x 4 B = %d MiB; > 256 MiB Infinity Cache => HBM measurement" % (n, n ** 3 * 4 >> 20))
+            if n ** 3 * 4 > (256 << 20) else "volume fits the 256 MiB Infinity Cache: cache-resident, NOT an HBM measurement",
+        }
+        out["stage_us"] = {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1),
+                           "integrate": round(ms[2] / nf * 1e3, 1), "raycast": round(ms[3] / nf * 1e3, 1),
+                           "note": "eager launches with HIP events between stages (second pass of %d frames)" % nf}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_frames, hsk)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -588,6 +588,9 @@ extern "C" int hsk_icp_accumulate(hsk_ctx* k, int level, const float pose_est[16
   int r = download_state(k);
   if (r != HSK_OK) return r;
   TrackState saved = *k->h_st;
+  // the model maps were raycast from the last stored pose: that is the "previous" camera of A.5
+  memcpy(k->h_st->Rp, saved.R, sizeof(saved.R));
+  memcpy(k->h_st->tp, saved.t, sizeof(saved.t));
   pose16_to_rt(pose_est, k->h_st->R, k->h_st->t);
   k->h_st->lost = 0;
   r = upload_state(k);

@@ -351,6 +351,10 @@ uint64_t ora_icp_accumulate(const float* vcur, const float* ncur, const float* v
   double acc[27];
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   uint64_t n_valid = 0;
+  /* the snapped sums are exact, hence independent of how the rows are split over threads */
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : n_valid) reduction(+ : acc[:27]) schedule(static)
+#endif
   for (int y = row0; y < row1; ++y)
     for (int x = 0; x < W; ++x) {
       const size_t i = (size_t)y * W + x;

@@ -1,0 +1,276 @@
+"""GPU parity tests proper: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for the int16 TSDF, the uint16 depth pyramid, the float maps (compared as bit patterns, NaN
+included), the 27 ICP sums (exact by the 2^-26 snapping) and the float poses.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64) if a.dtype == np.float64 else a
+
+
+def assert_same_bits(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    # NaNs: compare "is NaN" masks, then bit patterns elsewhere (the sign/payload of a NaN is not part of the contract)
+    if a.dtype.kind == "f":
+        na, nb = np.isnan(a), np.isnan(b)
+        assert np.array_equal(na, nb), f"{what}: NaN masks differ at {np.argwhere(na != nb)[:5]}"
+        ok = bits(np.where(na, 0, a).astype(a.dtype)) == bits(np.where(nb, 0, b).astype(b.dtype))
+    else:
+        ok = a == b
+    if not ok.all():
+        idx = np.argwhere(~ok)
+        raise AssertionError(f"{what}: {len(idx)} of {ok.size} elements differ, first at {idx[:5].tolist()}: "
+                             f"{a[tuple(idx[0])]} vs {b[tuple(idx[0])]}")
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_integrate_bit_exact(hsk, oracle, synth_frames, n):
+    cfg_o = oracle.default_config(n)
+    trk = hsk.KinfuTracker(n=n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    for k in (0, 7, 14, 21):
+        pose, depth = synth_frames(k)
+        scaled = oracle.scale_depth(cfg_o, depth)
+        n_upd = oracle.integrate(cfg_o, vol, scaled, pose)
+        assert trk.count_updates(depth, pose) == n_upd
+        trk.integrate(depth, pose)
+        assert_same_bits(trk.download_scaled_depth(), scaled, "scaled depth")
+        assert_same_bits(trk.download_tsdf(), vol, f"tsdf after frame {k}")
+    assert (vol[..., 1] > 0).sum() > 0.1 * n ** 3
+    trk.close()
+
+
+def test_integrate_ragged_and_empty(hsk, oracle, synth_frames):
+    """edge cases: all-zero depth (nothing updated), non-cubic volume, camera inside the volume looking away"""
+    n = 64
+    cfg_o = oracle.default_config(n, vol=(64, 32, 96), size=(3.0, 1.5, 4.5))
+    trk = hsk.KinfuTracker(hsk.default_config(n, vol_y=32, vol_z=96, vol_size_m=(3.0, 1.5, 4.5), own_z1=96))
+    vol = np.zeros((96, 32, 64, 2), np.int16)
+    pose, depth = synth_frames(3)
+    zero = np.zeros_like(depth)
+    assert trk.count_updates(zero, pose) == 0
+    trk.integrate(zero, pose)
+    assert not trk.download_tsdf().any()
+    for p in (pose, np.array([[-1, 0, 0, 1.5], [0, 1, 0, 0.7], [0, 0, -1, 1.0], [0, 0, 0, 1]], np.float32)):
+        n_upd = oracle.integrate(cfg_o, vol, oracle.scale_depth(cfg_o, depth), p)
+        assert trk.count_updates(depth, p) == n_upd
+        trk.integrate(depth, p)
+        assert_same_bits(trk.download_tsdf(), vol, "tsdf (ragged volume)")
+    trk.close()
+
+
+def test_weight_saturates_at_128(hsk, oracle, synth_frames):
+    n = 32
+    cfg_o = oracle.default_config(n)
+    trk = hsk.KinfuTracker(n=n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    pose, depth = synth_frames(0)
+    scaled = oracle.scale_depth(cfg_o, depth)
+    for _ in range(130):
+        oracle.integrate(cfg_o, vol, scaled, pose)
+        trk.integrate(depth, pose)
+    out = trk.download_tsdf()
+    assert out[..., 1].max() == 128
+    assert_same_bits(out, vol, "tsdf after 130 integrations")
+    trk.close()
+
+
+def test_preprocess_bit_exact(hsk, oracle, synth_frames):
+    cfg_o = oracle.default_config(64)
+    trk = hsk.KinfuTracker(n=64)
+    rng = np.random.default_rng(7)
+    for k in (0, 30):
+        pose, depth = synth_frames(k)
+        d = depth.copy()
+        # holes + mm noise so that the bilateral range weights and the pyrDown gate do real work
+        d = (d.astype(np.int32) + rng.integers(-8, 9, d.shape)).clip(0, 65535).astype(np.uint16)
+        d[rng.random(d.shape) < 0.02] = 0
+        d[100:140, 200:260] = 0
+        trk.preprocess(d)
+        lv = [oracle.bilateral(cfg_o, d)]
+        lv.append(oracle.pyrdown(lv[0]))
+        lv.append(oracle.pyrdown(lv[1]))
+        assert_same_bits(trk.download_scaled_depth(), oracle.scale_depth(cfg_o, d), "scaled depth")
+        for l in range(3):
+            assert_same_bits(trk.download_depth_level(l), lv[l], f"depth level {l}")
+            vm = oracle.vmap(cfg_o, lv[l], l)
+            assert_same_bits(trk.download_map(0, l), vm, f"vmap level {l}")
+            assert_same_bits(trk.download_map(1, l), oracle.nmap(vm), f"nmap level {l}")
+    trk.close()
+
+
+def test_bilateral_tables_match_oracle(hsk, oracle):
+    import ctypes as C
+    ws, wc = hsk.bilateral_tables()
+    # the oracle's tables are private; reproduce them through its public filter on an impulse instead:
+    # a flat image must pass through unchanged and the tables must be monotone / normalised at 0
+    assert ws[84] == 1.0 and wc[0] == 1.0 and (np.diff(wc) <= 0).all()
+    flat = np.full((64, 64), 1234, np.uint16)
+    assert (oracle.bilateral(oracle.default_config(64, W=64, H=64), flat) == 1234).all()
+
+
+def _fused_volume(hsk, oracle, synth_frames, n, frames):
+    cfg_o = oracle.default_config(n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    for k in frames:
+        pose, depth = synth_frames(k)
+        oracle.integrate(cfg_o, vol, oracle.scale_depth(cfg_o, depth), pose)
+    return cfg_o, vol
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_raycast_bit_exact(hsk, oracle, synth_frames, n):
+    cfg_o, vol = _fused_volume(hsk, oracle, synth_frames, n, (0, 5, 10))
+    trk = hsk.KinfuTracker(n=n)
+    trk.upload_tsdf(vol)
+    inside = np.array([[0.94, 0, 0.34, 1.2], [0, 1, 0, 1.4], [-0.34, 0, 0.94, 0.6], [0, 0, 0, 1]], np.float32)
+    for pose in (synth_frames(10)[0], synth_frames(40)[0], inside):
+        vm, nm, keys = trk.raycast(pose, want_keys=True)
+        ovm, onm, okeys, _ = oracle.raycast(cfg_o, vol, pose)
+        assert np.array_equal(keys, okeys)
+        assert_same_bits(vm, ovm, "raycast vmap")
+        assert_same_bits(nm, onm, "raycast nmap")
+        assert (~np.isnan(vm[0])).mean() > 0.3
+    trk.close()
+
+
+def test_raycast_empty_volume(hsk, oracle, synth_frames):
+    trk = hsk.KinfuTracker(n=64)
+    vm, nm, keys = trk.raycast(synth_frames(0)[0], want_keys=True)
+    assert np.isnan(vm).all() and np.isnan(nm).all() and (keys == 0x7FFFFFFF).all()
+    trk.close()
+
+
+def test_icp_sums_and_solve_bit_exact(hsk, oracle, synth_frames):
+    n = 128
+    cfg_o = oracle.default_config(n)
+    ot = oracle.Tracker(cfg_o)
+    trk = hsk.KinfuTracker(n=n, use_graph=0)
+    for k in range(3):
+        pose, depth = synth_frames(k)
+        po, _ = ot.process(depth)
+        ph, _ = trk.process_frame(depth)
+        assert_same_bits(ph, po, f"pose frame {k}")
+    # next frame: compare the 27 sums at the coarsest and the finest level for a perturbed estimate
+    pose, depth = synth_frames(3)
+    trk.preprocess(depth)
+    prev = trk.get_pose()
+    est = prev.copy()
+    est[:3, 3] += np.array([0.004, -0.003, 0.002], np.float32)
+    lv = [oracle.bilateral(cfg_o, depth)]
+    lv.append(oracle.pyrdown(lv[0]))
+    lv.append(oracle.pyrdown(lv[1]))
+    for level in (2, 1, 0):
+        vm = oracle.vmap(cfg_o, lv[level], level)
+        nm = oracle.nmap(vm)
+        osum, nvalid = oracle.icp_accumulate(cfg_o, level, vm, nm, ot.model_map(2, level), ot.model_map(3, level), est, prev)
+        assert nvalid > 1000
+        hsum = trk.icp_accumulate(level, est)
+        assert_same_bits(hsum, osum, f"ICP sums level {level}")
+        # row-sharded accumulation (multi-GPU all-reduce mode) adds up to the same bits
+        H = cfg_o.H >> level
+        parts = [trk.icp_accumulate(level, est, r0, r1) for r0, r1 in ((0, H // 3), (H // 3, H // 2), (H // 2, H))]
+        assert_same_bits(parts[0] + parts[1] + parts[2], osum, "row-sharded ICP sums")
+        xo, oko = oracle.icp_solve(osum)
+        xh, okh = trk.icp_solve(hsum)
+        assert oko and okh
+        assert_same_bits(xh, xo, "6x6 solve")
+    # singular system => not ok
+    assert not trk.icp_solve(np.zeros(27))[1] and not oracle.icp_solve(np.zeros(27))[1]
+    trk.close()
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_tracker_bit_exact_and_accurate(hsk, oracle, synth_frames, graph):
+    """whole pipeline, 12 frames: poses and TSDF identical to the oracle; trajectory within 3 mm / 0.1 deg of truth"""
+    n = 128
+    cfg_o = oracle.default_config(n)
+    ot = oracle.Tracker(cfg_o, omp=True)
+    trk = hsk.KinfuTracker(n=n, use_graph=graph)
+    for k in range(12):
+        gt, depth = synth_frames(k)
+        po, oko = ot.process(depth)
+        ph, okh = trk.process_frame(depth)
+        assert oko == okh == (k > 0)
+        assert_same_bits(ph, po, f"pose frame {k}")
+        dt = np.linalg.norm(ph[:3, 3] - gt[:3, 3]) * 1000.0
+        ang = np.degrees(np.arccos(np.clip((np.trace(ph[:3, :3].astype(np.float64).T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+        assert dt < 3.0 and ang < 0.1, (k, dt, ang)
+    assert_same_bits(trk.download_tsdf(), ot.volume(), "tsdf after 12 tracked frames")
+    for level in range(3):
+        assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"model vmap {level}")
+        assert_same_bits(trk.download_map(3, level), ot.model_map(3, level), f"model nmap {level}")
+    trk.close()
+
+
+def test_tracking_lost_resets(hsk, synth_frames):
+    trk = hsk.KinfuTracker(n=64)
+    _, d0 = synth_frames(0)
+    trk.process_frame(d0)
+    pose, tracked = trk.process_frame(np.zeros_like(d0))  # no valid pixel => singular system => lost
+    assert not tracked
+    assert np.allclose(pose[:3, 3], [1.5, 1.5, -0.3])
+    assert not trk.download_tsdf().any()
+    # and it recovers: next frame is a "first" frame again
+    _, t2 = trk.process_frame(d0)
+    assert not t2
+    _, t3 = trk.process_frame(synth_frames(1)[1])
+    assert t3
+    trk.close()
+
+
+def test_errors_are_values(hsk, synth_frames):
+    trk = hsk.KinfuTracker(n=32)
+    with pytest.raises(hsk.KinfuError, match="size"):
+        trk.process_frame(np.zeros((240, 320), np.uint16))
+    with pytest.raises(hsk.KinfuError):
+        hsk.KinfuTracker(hsk.default_config(32, vol_x=30))
+    trk.close()
+
+
+def test_extract_cloud_matches_oracle(hsk, oracle, synth_frames):
+    n = 64
+    cfg_o, vol = _fused_volume(hsk, oracle, synth_frames, n, (0, 5, 10, 15))
+    trk = hsk.KinfuTracker(n=n)
+    trk.upload_tsdf(vol)
+    pts, total = trk.extract_cloud()
+    opts, ototal = oracle.extract_cloud(cfg_o, vol)
+    assert total == ototal and total > 1000
+    assert_same_bits(pts, opts, "extracted cloud")
+    # surface points lie on the synthetic scene: back wall z = 2.8 within one cell
+    back = pts[np.abs(pts[:, 2] - 2.8) < 0.05]
+    assert len(back) > 100
+    trk.close()
+
+
+def test_full_size_properties(hsk, synth_frames):
+    """512^3 (BASELINE.json size): size-independent properties instead of an oracle sweep."""
+    n = 512
+    trk = hsk.KinfuTracker(n=n)
+    pose, depth = synth_frames(0)
+    n_upd = trk.count_updates(depth, pose)
+    trk.integrate(depth, pose)
+    vol = trk.download_tsdf()
+    w = vol[..., 1]
+    assert int((w > 0).sum()) == n_upd                      # exactly the counted voxels were rewritten
+    assert set(np.unique(w).tolist()) <= {0, 1}
+    trk.integrate(depth, pose)                              # idempotence of the running mean on identical input
+    vol2 = trk.download_tsdf()
+    assert np.array_equal(vol2[..., 0], vol[..., 0]) and vol2[..., 1].max() == 2
+    # raycast of the fused frame reproduces the input depth: z of the model vertex in camera frame ~ depth
+    vm, nm = trk.raycast(pose)
+    z_cam = vm[2] - pose[2, 3]
+    valid = ~np.isnan(z_cam) & (depth > 0)
+    assert valid.mean() > 0.5
+    err = np.abs(z_cam[valid] * 1000.0 - depth[valid])
+    assert np.median(err) < 4.0                             # < one 5.86 mm cell
+    nn = np.linalg.norm(nm[:, ~np.isnan(nm[0])], axis=0)
+    assert np.abs(nn - 1).max() < 1e-5
+    trk.close()
