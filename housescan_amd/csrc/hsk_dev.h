@@ -36,7 +36,14 @@ struct VolParams {
   float cell[3];
   float size[3];
   float tau, tau_inv;
+  int bshift;      // log2 of the brick edge of the "has held a negative TSDF" bitfield (3 => 8^3 voxels)
 };
+
+// words of the brick bitfield; the brick edge is chosen so that it fits 32 KiB of LDS
+static inline int hsk_flag_words(const VolParams& vp) {
+  const long bits = (long)(vp.X >> vp.bshift) * (vp.Y >> vp.bshift) * ((vp.nzs + (1 << vp.bshift) - 1) >> vp.bshift);
+  return (int)((bits + 31) / 32);
+}
 
 #define HSK_NANF (__builtin_nanf(""))
 

@@ -4,9 +4,12 @@
 
 // volume
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
-                      int H, Intr in, bool count_only, unsigned long long* counter);
+                      int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
+                      const float* tmax);
+void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
+void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys);
+                    float* vmap, float* nmap, int* keys, const unsigned* flags);
 void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                     int* bits, int P);
 void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vmap, float* nmap, int P);

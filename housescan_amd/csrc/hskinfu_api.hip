@@ -41,6 +41,9 @@ struct hsk_ctx {
   float* d_ws = nullptr;
   float* d_wc = nullptr;
   int* d_keys = nullptr;
+  unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
+  size_t flags_bytes = 0;
+  float* d_tmax = nullptr;           // 16x16-pixel tile maxima of the scaled depth
   uint16_t* h_stage = nullptr;  // pinned staging for the incoming depth frame
   unsigned long long* d_counter = nullptr;
   unsigned* d_rowcnt = nullptr;
@@ -159,6 +162,8 @@ static void free_all(hsk_ctx* k) {
   F(k->d_ws);
   F(k->d_wc);
   F(k->d_keys);
+  F(k->d_flags);
+  F(k->d_tmax);
   F(k->d_counter);
   F(k->d_rowcnt);
   F(k->d_rowoff);
@@ -183,6 +188,7 @@ static int download_state(hsk_ctx* k) {
 static int do_reset(hsk_ctx* k) {
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   HIPCHK(k, hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream));
+  HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
   memset(k->h_st, 0, sizeof(TrackState));
   memcpy(k->h_st->R, k->init_R, sizeof(k->init_R));
   memcpy(k->h_st->t, k->init_t, sizeof(k->init_t));
@@ -198,10 +204,10 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     return HSK_ERR_ARG;
   }
   *out = nullptr;
-  if (c->vol_x <= 0 || c->vol_y <= 0 || c->vol_z <= 0 || (c->vol_x % 4) != 0 || c->width <= 0 || c->height <= 0 ||
+  if (c->vol_x <= 0 || c->vol_y <= 0 || c->vol_z <= 0 || (c->vol_x % 8) != 0 || (c->vol_y % 8) != 0 || c->width <= 0 || c->height <= 0 ||
       (c->width % 4) != 0 || (c->height % 4) != 0 || c->own_z0 < 0 || c->own_z1 > c->vol_z || c->own_z0 >= c->own_z1 ||
       c->halo < 0) {
-    g_create_err = "hsk_create: invalid configuration (vol_x and image dims must be multiples of 4; 0 <= own_z0 < own_z1 <= vol_z)";
+    g_create_err = "hsk_create: invalid configuration (vol_x, vol_y must be multiples of 8, image dims of 4; 0 <= own_z0 < own_z1 <= vol_z)";
     return HSK_ERR_ARG;
   }
   int ndev = 0;
@@ -281,6 +287,13 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipMalloc((void**)&k->d_ws, 169 * 4));
   CK(hipMalloc((void**)&k->d_wc, 512 * 4));
   CK(hipMalloc((void**)&k->d_keys, P0 * 4));
+  vp.bshift = 3;
+  while (hsk_flag_words(vp) > 8192 && vp.bshift < 6 && ((vp.X >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.X &&
+         ((vp.Y >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.Y)
+    ++vp.bshift;
+  k->flags_bytes = (size_t)hsk_flag_words(vp) * 4;
+  CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
+  CK(hipMalloc((void**)&k->d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4));
   CK(hipMalloc((void**)&k->d_counter, 16));
   {
     float ws[169], wc[512];
@@ -332,6 +345,7 @@ extern "C" int hsk_synchronize(hsk_ctx* k) {
 static void enqueue_preprocess(hsk_ctx* k) {
   hipStream_t s = k->stream;
   launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_ws, k->d_wc, k->d_dep[0], k->d_scaled);
+  launch_tile_max(s, k->d_scaled, k->lv[0].W, k->lv[0].H, k->d_tmax);
   for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_dep[l]);
   for (int l = 0; l < HSK_NLEVELS; ++l)
     launch_vmap_nmap(s, k->d_dep[l], k->lv[l].W, k->lv[l].H, k->lv[l].in, k->d_vcur[l], k->d_ncur[l]);
@@ -352,12 +366,12 @@ static void enqueue_icp(hsk_ctx* k) {
 
 static void enqueue_integrate(hsk_ctx* k) {
   launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
-                   k->d_counter);
+                   k->d_counter, k->d_flags, k->d_tmax);
 }
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys) {
   hipStream_t s = k->stream;
-  launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys);
+  launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys, k->d_flags);
   for (int l = 1; l < HSK_NLEVELS; ++l)
     launch_resize_maps(s, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l], k->d_nmod[l],
                        k->d_st);
@@ -523,6 +537,7 @@ extern "C" int hsk_integrate(hsk_ctx* k, const uint16_t* depth, int w, int h, co
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
   launch_scale_depth(k->stream, k->d_raw, w, h, k->lv[0].in, k->d_scaled);
+  launch_tile_max(k->stream, k->d_scaled, w, h, k->d_tmax);
   enqueue_integrate(k);
   HIPCHK(k, hipStreamSynchronize(k->stream));
   HIPCHK(k, hipGetLastError());
@@ -539,8 +554,10 @@ extern "C" int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
   launch_scale_depth(k->stream, k->d_raw, w, h, k->lv[0].in, k->d_scaled);
+  launch_tile_max(k->stream, k->d_scaled, w, h, k->d_tmax);
   HIPCHK(k, hipMemsetAsync(k->d_counter, 0, 8, k->stream));
-  launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter);
+  launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter, k->d_flags,
+                   k->d_tmax);
   unsigned long long c = 0;
   HIPCHK(k, hipMemcpyAsync(&c, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));
@@ -555,7 +572,7 @@ extern "C" int hsk_raycast(hsk_ctx* k, const float pose[16], float* vmap, float*
   if (r != HSK_OK) return r;
   const size_t P = (size_t)k->lv[0].W * k->lv[0].H;
   launch_raycast(k->stream, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0],
-                 k->d_keys);
+                 k->d_keys, k->d_flags);
   for (int l = 1; l < HSK_NLEVELS; ++l)
     launch_resize_maps(k->stream, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l],
                        k->d_nmod[l], k->d_st);
@@ -632,6 +649,8 @@ extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
   if (!k || !in) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   HIPCHK(k, hipMemcpyAsync(k->d_vol, in, k->vol_bytes, hipMemcpyHostToDevice, k->stream));
+  HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
+  launch_rebuild_flags(k->stream, k->d_vol, k->vp, k->d_flags);
   HIPCHK(k, hipStreamSynchronize(k->stream));
   return HSK_OK;
 }
@@ -774,7 +793,7 @@ extern "C" int hsk_mgpu_integrate(hsk_ctx* k) {
 extern "C" int hsk_mgpu_raycast_local(hsk_ctx* k, void* keys_dev) {
   if (!k || !keys_dev) return HSK_ERR_ARG;
   launch_raycast(k->stream, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0],
-                 k->d_keys);
+                 k->d_keys, k->d_flags);
   HIPCHK(k, hipMemcpyAsync(keys_dev, k->d_keys, (size_t)k->lv[0].W * k->lv[0].H * 4, hipMemcpyDeviceToDevice, k->stream));
   return HSK_OK;
 }

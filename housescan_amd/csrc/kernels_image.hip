@@ -239,11 +239,31 @@ void launch_resize_maps(hipStream_t s, const float* vs, const float* ns, int W, 
 // sum exact: the wave64 shuffle tree, the cross-wave LDS step, the cross-block step and (multi-GPU) the
 // RCCL all-reduce all give the same bits as a sequential sum.
 // ------------------------------------------------------------------------------------------------------
-#define ICP_PX 4      // pixels per lane
+// ICP_PX pixels per lane (template): loads batched so that the dependent chain is 2 memory round trips
 #define ICP_BLOCK 256
 
 static __device__ __forceinline__ double quant26(double x) { return rint(x * 67108864.0) * (1.0 / 67108864.0); }
 
+// DPP move of a 64-bit value (two 32-bit halves)
+template <int CTRL>
+static __device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// wave64 sum, result valid in every lane of... lane 0 (and others); any order is fine: the addends are exact.
+static __device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);  // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row total
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int ICP_PX>
 __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __restrict__ vcur,
                                                               const float* __restrict__ ncur,
                                                               const float* __restrict__ vprev,
@@ -264,66 +284,81 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __res
     const float t0 = st->t[0], t1 = st->t[1], t2 = st->t[2];
     const float p0 = st->tp[0], p1 = st->tp[1], p2 = st->tp[2];
     const int base = blockIdx.x * (ICP_BLOCK * ICP_PX) + threadIdx.x;
+    // phase A: all current-map loads in flight together
+    float nc[ICP_PX][3], vc[ICP_PX][3];
+    bool ok[ICP_PX];
 #pragma unroll
     for (int q = 0; q < ICP_PX; ++q) {
       const int li = base + q * ICP_BLOCK;
-      if (li >= npx) break;
-      const size_t i = (size_t)row0 * W + li;
-      const float ncx = ncur[i];
-      if (hsk_isnan(ncx)) continue;
-      const float ncy = ncur[P + i], ncz = ncur[2 * P + i];
-      const float vcx = vcur[i], vcy = vcur[P + i], vcz = vcur[2 * P + i];
-      const float gx = ((R[0] * vcx + R[1] * vcy) + R[2] * vcz) + t0;
-      const float gy = ((R[3] * vcx + R[4] * vcy) + R[5] * vcz) + t1;
-      const float gz = ((R[6] * vcx + R[7] * vcy) + R[8] * vcz) + t2;
-      const float dx = gx - p0, dy = gy - p1, dz = gz - p2;
-      // Rprev^T * d
-      const float cpx = (Rp[0] * dx + Rp[3] * dy) + Rp[6] * dz;
+      ok[q] = li < npx;
+      const size_t i = (size_t)row0 * W + (ok[q] ? li : 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        nc[q][c] = ncur[c * P + i];
+        vc[q][c] = vcur[c * P + i];
+      }
+    }
+    // phase B: transform + project, then all model-map gathers in flight together
+    float g[ICP_PX][3], np_[ICP_PX][3], vp_[ICP_PX][3];
+#pragma unroll
+    for (int q = 0; q < ICP_PX; ++q) {
+      ok[q] = ok[q] && !hsk_isnan(nc[q][0]);
+      g[q][0] = ((R[0] * vc[q][0] + R[1] * vc[q][1]) + R[2] * vc[q][2]) + t0;
+      g[q][1] = ((R[3] * vc[q][0] + R[4] * vc[q][1]) + R[5] * vc[q][2]) + t1;
+      g[q][2] = ((R[6] * vc[q][0] + R[7] * vc[q][1]) + R[8] * vc[q][2]) + t2;
+      const float dx = g[q][0] - p0, dy = g[q][1] - p1, dz = g[q][2] - p2;
+      const float cpx = (Rp[0] * dx + Rp[3] * dy) + Rp[6] * dz;  // Rprev^T * d
       const float cpy = (Rp[1] * dx + Rp[4] * dy) + Rp[7] * dz;
       const float cpz = (Rp[2] * dx + Rp[5] * dy) + Rp[8] * dz;
-      if (!(cpz > 0.0f)) continue;
+      ok[q] = ok[q] && (cpz > 0.0f);
       const float fu = (cpx * in.fx) / cpz + in.cx;
       const float fv = (cpy * in.fy) / cpz + in.cy;
-      int u, v;
-      if (!hsk_rint_guard(fu, u) || !hsk_rint_guard(fv, v)) continue;
-      if (u < 0 || v < 0 || u >= W || v >= H) continue;
-      const size_t j = (size_t)v * W + u;
-      const float npx_ = nprev[j];
-      if (hsk_isnan(npx_)) continue;
-      const float npy = nprev[P + j], npz = nprev[2 * P + j];
-      const float vpx = vprev[j], vpy = vprev[P + j], vpz = vprev[2 * P + j];
-      const float ex = vpx - gx, ey = vpy - gy, ez = vpz - gz;
+      int u = 0, v = 0;
+      ok[q] = ok[q] && hsk_rint_guard(fu, u) && hsk_rint_guard(fv, v);
+      ok[q] = ok[q] && u >= 0 && v >= 0 && u < W && v < H;
+      const size_t j = ok[q] ? (size_t)v * W + u : 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        np_[q][c] = nprev[c * P + j];
+        vp_[q][c] = vprev[c * P + j];
+      }
+    }
+    // phase C: gates, the 7-vector row, 27 snapped products
+#pragma unroll
+    for (int q = 0; q < ICP_PX; ++q) {
+      bool valid = ok[q] && !hsk_isnan(np_[q][0]);
+      const float ex = vp_[q][0] - g[q][0], ey = vp_[q][1] - g[q][1], ez = vp_[q][2] - g[q][2];
       const float dist = sqrtf(hsk_dot3(ex, ey, ez, ex, ey, ez));
-      if (!(dist <= dist_thresh)) continue;
-      const float ngx = (R[0] * ncx + R[1] * ncy) + R[2] * ncz;
-      const float ngy = (R[3] * ncx + R[4] * ncy) + R[5] * ncz;
-      const float ngz = (R[6] * ncx + R[7] * ncy) + R[8] * ncz;
-      const float c0 = ngy * npz - ngz * npy;
-      const float c1 = ngz * npx_ - ngx * npz;
-      const float c2 = ngx * npy - ngy * npx_;
+      valid = valid && (dist <= dist_thresh);
+      const float ngx = (R[0] * nc[q][0] + R[1] * nc[q][1]) + R[2] * nc[q][2];
+      const float ngy = (R[3] * nc[q][0] + R[4] * nc[q][1]) + R[5] * nc[q][2];
+      const float ngz = (R[6] * nc[q][0] + R[7] * nc[q][1]) + R[8] * nc[q][2];
+      const float c0 = ngy * np_[q][2] - ngz * np_[q][1];
+      const float c1 = ngz * np_[q][0] - ngx * np_[q][2];
+      const float c2 = ngx * np_[q][1] - ngy * np_[q][0];
       const float sine = sqrtf(hsk_dot3(c0, c1, c2, c0, c1, c2));
-      if (!(sine < angle_thresh)) continue;
-      float row[7];
-      row[0] = gy * npz - gz * npy;  // s x n
-      row[1] = gz * npx_ - gx * npz;
-      row[2] = gx * npy - gy * npx_;
-      row[3] = npx_;
-      row[4] = npy;
-      row[5] = npz;
-      row[6] = hsk_dot3(npx_, npy, npz, ex, ey, ez);
-      int k = 0;
+      valid = valid && (sine < angle_thresh);
+      if (valid) {
+        float row[7];
+        row[0] = g[q][1] * np_[q][2] - g[q][2] * np_[q][1];  // s x n
+        row[1] = g[q][2] * np_[q][0] - g[q][0] * np_[q][2];
+        row[2] = g[q][0] * np_[q][1] - g[q][1] * np_[q][0];
+        row[3] = np_[q][0];
+        row[4] = np_[q][1];
+        row[5] = np_[q][2];
+        row[6] = hsk_dot3(np_[q][0], np_[q][1], np_[q][2], ex, ey, ez);
+        int k = 0;
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
+        for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = a; b < 7; ++b) acc[k++] += quant26((double)row[a] * (double)row[b]);
+          for (int b = a; b < 7; ++b) acc[k++] += quant26((double)row[a] * (double)row[b]);
+      }
     }
   }
-  // wave64 shuffle reduction (exact: order-independent by construction)
+  // wave64 reduction (exact: order-independent by construction), then across the 4 waves through LDS
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const double v = wave_sum_f64(acc[k]);
     if (lane == 0) sh[wave][k] = v;
   }
   __syncthreads();
@@ -335,30 +370,60 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __res
   }
 }
 
-int icp_num_blocks(int W, int rows) { return (W * rows + ICP_BLOCK * ICP_PX - 1) / (ICP_BLOCK * ICP_PX); }
+// fine level: 4 pixels per lane (300 blocks at 640x480); coarse levels: 1 pixel per lane, shorter serial chain
+static inline int icp_px(int W) { return W >= 512 ? 4 : 1; }
+int icp_num_blocks(int W, int rows) { return (W * rows + ICP_BLOCK * icp_px(W) - 1) / (ICP_BLOCK * icp_px(W)); }
 
 void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
                            int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,
                            int row1, double* partials) {
   const int nb = icp_num_blocks(W, row1 - row0);
-  hipLaunchKernelGGL(k_icp_accumulate, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
-                     dist_thresh, angle_thresh, row0, row1, partials);
+  if (icp_px(W) == 4)
+    hipLaunchKernelGGL(k_icp_accumulate<4>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
+                       dist_thresh, angle_thresh, row0, row1, partials);
+  else
+    hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
+                       dist_thresh, angle_thresh, row0, row1, partials);
 }
 
-// reduce per-block partials -> 27 sums (one block)
-__global__ __launch_bounds__(256) void k_icp_reduce(const double* __restrict__ partials, int nblocks,
-                                                    double* __restrict__ out27) {
-  __shared__ double sh[4][27];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = 0; k < 27; ++k) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * 27 + k];
+// reduce per-block partials -> 27 sums (one block of 256 threads)
+#define ICP_RED_UNROLL 40  // 300 blocks / 8 slices, rounded up: one trip at 640x480
+static __device__ __forceinline__ void block_reduce27(const double* __restrict__ partials, int nblocks,
+                                                      double (*sh)[32], double* tot) {
+  // thread (slice, k): k = tid & 31 is the sum index (27 used), slice = tid >> 5 takes every 8th block row;
+  // consecutive k read consecutive doubles (coalesced) and all of a thread's loads are independent
+  const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  double v = 0.0;
+  if (k < 27) {
+    // partials were written by other XCDs: every load is an L2 miss, so put them ALL in flight before adding
+    for (int b0 = slice; b0 < nblocks; b0 += 8 * ICP_RED_UNROLL) {
+      double w[ICP_RED_UNROLL];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) sh[wave][k] = v;
+      for (int i = 0; i < ICP_RED_UNROLL; ++i) {
+        const int b = b0 + 8 * i;
+        w[i] = b < nblocks ? partials[(size_t)b * 27 + k] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < ICP_RED_UNROLL; ++i) v += w[i];
+    }
+  }
+  sh[slice][k] = v;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double r = sh[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) r += sh[q][threadIdx.x];
+    tot[threadIdx.x] = r;
   }
   __syncthreads();
-  if (threadIdx.x < 27) out27[threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_icp_reduce(const double* __restrict__ partials, int nblocks,
+                                                    double* __restrict__ out27) {
+  __shared__ double sh[8][32];
+  __shared__ double tot[27];
+  block_reduce27(partials, nblocks, sh, tot);
+  if (threadIdx.x < 27) out27[threadIdx.x] = tot[threadIdx.x];
 }
 void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, double* out27) {
   hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(256), 0, s, partials, nblocks, out27);
@@ -425,17 +490,19 @@ __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6)
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
   double det = 1.0;
+  double inv[6];
   for (int j = 0; j < 6; ++j) {
     double s = A[j][j];
     for (int q = 0; q < j; ++q) s = s - L[j][q] * L[j][q];
     if (!(s > 0.0)) return false;
     const double d = sqrt(s);
     L[j][j] = d;
+    inv[j] = 1.0 / d;
     det = det * s;
     for (int i = j + 1; i < 6; ++i) {
       double r = A[i][j];
       for (int q = 0; q < j; ++q) r = r - L[i][q] * L[j][q];
-      L[i][j] = r / d;
+      L[i][j] = r * inv[j];
     }
   }
   if (!(det >= 1e-15)) return false;
@@ -443,12 +510,12 @@ __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6)
   for (int i = 0; i < 6; ++i) {
     double r = b[i];
     for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
-    yv[i] = r / L[i][i];
+    yv[i] = r * inv[i];
   }
   for (int i = 5; i >= 0; --i) {
     double r = yv[i];
     for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
-    xv[i] = r / L[i][i];
+    xv[i] = r * inv[i];
   }
   for (int q = 0; q < 6; ++q) {
     if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) return false;
@@ -515,25 +582,13 @@ void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st) {
 // fused reduce + solve + update (single-device path): one block
 __global__ __launch_bounds__(256) void k_icp_reduce_update(const double* __restrict__ partials, int nblocks,
                                                            TrackState* __restrict__ st) {
-  __shared__ double sh[4][27];
+  __shared__ double sh[8][32];
   __shared__ double tot[27];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = 0; k < 27; ++k) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * 27 + k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) sh[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 27) tot[threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
-  __syncthreads();
+  block_reduce27(partials, nblocks, sh, tot);
   if (threadIdx.x == 0 && !st->lost) {
     double s[27];
-    for (int k = 0; k < 27; ++k) {
-      s[k] = tot[k];
-      st->sums[k] = s[k];
-    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s[k] = tot[k];
     float x6[6];
     if (!hsk_solve6(s, x6)) {
       st->lost = 1;

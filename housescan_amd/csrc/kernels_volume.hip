@@ -6,29 +6,90 @@
 #include "hsk_launch.h"
 
 // ------------------------------------------------------------------------------------------------------
-// integrate: each lane owns 4 x-adjacent voxels (one 16-B vector), a wave covers 256 voxels = 1 KiB of a
-// row, a block covers 4 consecutive rows, and walks a chunk of z planes.  The depth test comes BEFORE the
-// volume access, so only vectors that hold at least one rewritten voxel are ever read or written: HBM
-// traffic tracks the algorithmic 8 B x V_upd rather than the 8 B x N^3 sweep.
+// integrate (A.4).  Layout: each lane owns 4 x-adjacent voxels (one 16-B vector), a wave covers 256 voxels =
+// 1 KiB of a row, a block covers 4 consecutive rows and walks a chunk of z planes.
+//
+// Only vectors that hold at least one rewritten voxel are read or written, so HBM traffic tracks the
+// algorithmic 8 B x V_upd, not the 8 B x N^3 sweep.  Three conservative culls keep the
+// arithmetic off the voxels that cannot be rewritten (each only ever skips voxels the exact test rejects):
+//   1. per-lane z interval of the column inside the (padded) view frustum, computed once per column;
+//   2. occlusion: a 16x16-pixel tile table of max scaled depth, 3x3-dilated and staged in LDS; a 4-voxel
+//      group whose nearest possible point is farther than that maximum + tau cannot pass sdf >= -tau;
+//   3. exact fast paths of the running mean (saturated free space, first observation).
+// Bricks (8^3 voxels) that ever received a negative TSDF are flagged for the raycaster's empty-space test.
 // ------------------------------------------------------------------------------------------------------
-template <bool COUNT_ONLY>
+#define HSK_TILE 16
+#ifndef INTEGRATE_U
+#define INTEGRATE_U 4
+#endif
+
+__global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax, int tw) {
+  __shared__ float sh[4];
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  const int x = tx * HSK_TILE + (threadIdx.x & 15), y = ty * HSK_TILE + (threadIdx.x >> 4);
+  float v = (x < W && y < H) ? scaled[y * W + x] : 0.0f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) tmax[ty * tw + tx] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax) {
+  const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
+  hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tmax, tw);
+}
+
+// clip [lo,hi] (in gz) with c + m*gz >= 0
+static __device__ __forceinline__ void clip_interval(float c, float m, float& lo, float& hi) {
+  if (m > 0.0f) {
+    lo = fmaxf(lo, -c * __builtin_amdgcn_rcpf(m));
+  } else if (m < 0.0f) {
+    hi = fminf(hi, -c * __builtin_amdgcn_rcpf(m));
+  } else if (c < 0.0f) {
+    lo = 1e30f;
+    hi = -1e30f;
+  }
+}
+
+template <bool COUNT_ONLY, int U>
 __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
                                                    const TrackState* __restrict__ st, VolParams vp, int W, int H,
-                                                   Intr in, int zchunk, unsigned long long* __restrict__ counter) {
+                                                   Intr in, int zchunk, unsigned long long* __restrict__ counter,
+                                                   unsigned* __restrict__ flags, const float* __restrict__ tmax,
+                                                   int tw, int th) {
+  extern __shared__ float dmax[];  // 3x3-dilated tile maxima of the scaled depth
   const int lane = threadIdx.x;
-  const int x0 = (blockIdx.x * 64 + lane) * 4;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
   if (!COUNT_ONLY && st->lost) return;
+  for (int i = tid; i < tw * th; i += 256) {
+    const int ty = i / tw, tx = i - ty * tw;
+    float m = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
+        m = fmaxf(m, tmax[yy * tw + xx]);
+      }
+    dmax[i] = m;
+  }
+  __syncthreads();
+  // wave footprint: 64 voxels in x (16 lanes x 16 B = 256 contiguous bytes) by 4 rows in y -- compact, so
+  // that the wave-uniform z range and the group culls reject whole wave trips, not just lanes
+  const int x0 = (blockIdx.x * 16 + (lane & 15)) * 4;
+  const int y = (blockIdx.y * 4 + threadIdx.y) * 4 + (lane >> 4);
   const bool active = (x0 < vp.X) && (y < vp.Y);
   unsigned long long cnt = 0;
+  const int zbeg = blockIdx.z * zchunk;
+  const int zend = min(zbeg + zchunk, vp.nzs);
+  const float tx = st->t[0], ty = st->t[1], tz = st->t[2];
+  // Rinv = R^T
+  const float i00 = st->R[0], i01 = st->R[3], i02 = st->R[6];
+  const float i10 = st->R[1], i11 = st->R[4], i12 = st->R[7];
+  const float i20 = st->R[2], i21 = st->R[5], i22 = st->R[8];
+  float ax[4], ay[4], az[4], pn[4];
+  int zl = 0x7fffffff, zh = -0x7fffffff;  // this lane's stored-plane range inside the padded frustum
   if (active) {
-    const float tx = st->t[0], ty = st->t[1], tz = st->t[2];
-    // Rinv = R^T
-    const float i00 = st->R[0], i01 = st->R[3], i02 = st->R[6];
-    const float i10 = st->R[1], i11 = st->R[4], i12 = st->R[7];
-    const float i20 = st->R[2], i21 = st->R[5], i22 = st->R[8];
     const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
-    float ax[4], ay[4], az[4], pn[4];
+    float glo = 1e30f, ghi = -1e30f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
@@ -36,60 +97,183 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ vol, cons
       ay[j] = i10 * gx + i11 * gy;
       az[j] = i20 * gx + i21 * gy;
       pn[j] = gx * gx + gy * gy;
+      // cam(gz) = (ax,ay,az) + gz * (i02,i12,i22); keep gz where the pixel can fall in [-1.5, W+0.5] x [-1.5, H+0.5]
+      float lo = -1e30f, hi = 1e30f;
+      clip_interval(az[j], i22, lo, hi);
+      const float ul = 1.5f + in.cx, uh = ((float)W + 0.5f) - in.cx;
+      const float vl = 1.5f + in.cy, vh = ((float)H + 0.5f) - in.cy;
+      clip_interval(ax[j] * in.fx + ul * az[j], i02 * in.fx + ul * i22, lo, hi);
+      clip_interval(uh * az[j] - ax[j] * in.fx, uh * i22 - i02 * in.fx, lo, hi);
+      clip_interval(ay[j] * in.fy + vl * az[j], i12 * in.fy + vl * i22, lo, hi);
+      clip_interval(vh * az[j] - ay[j] * in.fy, vh * i22 - i12 * in.fy, lo, hi);
+      if (lo <= hi) {
+        glo = fminf(glo, lo);
+        ghi = fmaxf(ghi, hi);
+      }
     }
-    const int zbeg = blockIdx.z * zchunk;
-    const int zend = min(zbeg + zchunk, vp.nzs);
-    const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
-    size_t idx = (size_t)zbeg * plane_vec + ((size_t)y * vp.X + x0) / 4;
-    for (int zz = zbeg; zz < zend; ++zz, idx += plane_vec) {
-      const float gz = ((float)(vp.zs0 + zz) + 0.5f) * vp.cell[2] - tz;
-      const float bx = i02 * gz, by = i12 * gz, bz = i22 * gz;
-      const float gz2 = gz * gz;
-      float F[4];
-      unsigned mask = 0;
+    if (glo <= ghi) {
+      // gz = (z + 0.5) * cell_z - tz  =>  z = (gz + tz) / cell_z - 0.5; pad by 2 planes for float error
+      const float inv_cz = __builtin_amdgcn_rcpf(vp.cell[2]);
+      const float fl = (glo + tz) * inv_cz - 2.5f, fh = (ghi + tz) * inv_cz + 1.5f;
+      const int a = fl < -1e9f ? -1000000000 : (fl > 1e9f ? 1000000000 : (int)floorf(fl));
+      const int b = fh < -1e9f ? -1000000000 : (fh > 1e9f ? 1000000000 : (int)ceilf(fh));
+      zl = max(a - vp.zs0, zbeg);
+      zh = min(b - vp.zs0, zend - 1);
+    }
+  }
+  // wave-uniform loop bounds
+  int wl = zl, wh = zh;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float camz = az[j] + bz;
-        if (camz > 0.0f) {
-          const float inv_z = 1.0f / camz;
-          const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
-          const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
-          int u, v;
-          if (hsk_rint_guard(fu, u) && hsk_rint_guard(fv, v) && u >= 0 && v >= 0 && u < W && v < H) {
-            const float Ds = scaled[v * W + u];
-            const float dist = sqrtf(gz2 + pn[j]);
-            const float sdf = Ds - dist;
-            if (Ds != 0.0f && sdf >= -vp.tau) {
-              const float f = sdf * vp.tau_inv;
-              F[j] = f < 1.0f ? f : 1.0f;
-              mask |= 1u << j;
+  for (int o = 32; o > 0; o >>= 1) {
+    wl = min(wl, __shfl_xor(wl, o, 64));
+    wh = max(wh, __shfl_xor(wh, o, 64));
+  }
+  const float cull_r_num = 2.75f * fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2])) * fmaxf(in.fx, in.fy);
+  const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
+  if (active && wl <= wh) {
+    const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
+    const int bricks_x = vp.X >> vp.bshift, bricks_y = vp.Y >> vp.bshift;
+    // U planes per trip: phase 1 projects (arithmetic + LDS only), phase 2 puts every depth gather of the trip
+    // in flight, phase 3 puts every needed volume vector in flight, phase 4 updates and stores.  One trip
+    // costs two memory round trips however large U is; U sets the bytes in flight per wave.
+    for (int zb = wl; zb <= wh; zb += U) {
+      int pix[U][4];
+      float gz2[U];
+      bool live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int zz = zb + u;
+        live[u] = (zz >= zl) && (zz <= zh);
+        const float gz = ((float)(vp.zs0 + zz) + 0.5f) * vp.cell[2] - tz;
+        const float bx = i02 * gz, by = i12 * gz, bz = i22 * gz;
+        gz2[u] = gz * gz;
+        // occlusion cull of the whole 4-voxel group against the dilated tile maximum
+        const float czc = 0.5f * ((az[1] + bz) + (az[2] + bz));
+        if (live[u] && czc > 0.1f) {
+          const float rc = __builtin_amdgcn_rcpf(czc);
+          const float r = cull_r_num * __builtin_amdgcn_rcpf(czc - 2.0f * vp.cell[0]) + 2.5f;
+          const float uc = 0.5f * ((ax[1] + bx) + (ax[2] + bx)) * in.fx * rc + in.cx;
+          const float vc = 0.5f * ((ay[1] + by) + (ay[2] + by)) * in.fy * rc + in.cy;
+          if (r <= (float)HSK_TILE && czc > 4.0f * vp.cell[0] && uc >= 0.0f && vc >= 0.0f && uc < (float)W && vc < (float)H) {
+            const float D = dmax[((int)vc / HSK_TILE) * tw + ((int)uc / HSK_TILE)];
+            const float dc = __builtin_amdgcn_sqrtf(gz2[u] + 0.5f * (pn[1] + pn[2]));
+            if (dc * 0.99999f - 2.0f * vp.cell[0] - D > vp.tau * 1.001f + 1e-4f) live[u] = false;
+          }
+        }
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pix[u][j] = -1;
+          const float camz = az[j] + bz;
+          if (live[u] && camz > 0.0f) {
+            // v_rcp_f32 (1 ulp) moves the pixel coordinate by < 1.6e-4 px; only a coordinate within 3e-4 px
+            // of a rounding boundary (x.5) needs the correctly rounded division of the spec
+            const float px_ = (ax[j] + bx) * in.fx, py_ = (ay[j] + by) * in.fy;
+            const float inv_a = __builtin_amdgcn_rcpf(camz);
+            float fu = px_ * inv_a + in.cx;
+            float fv = py_ * inv_a + in.cy;
+            if (fu > -2.0f && fv > -2.0f && fu < (float)W + 1.0f && fv < (float)H + 1.0f) {
+              float ru = rintf(fu), rv = rintf(fv);
+              if (0.5f - fabsf(fu - ru) < 3.0e-4f || 0.5f - fabsf(fv - rv) < 3.0e-4f) {
+                const float inv_z = 1.0f / camz;
+                fu = px_ * inv_z + in.cx;
+                fv = py_ * inv_z + in.cy;
+                ru = rintf(fu);
+                rv = rintf(fv);
+              }
+              const int uu = (int)ru, vv = (int)rv;
+              if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H) {
+                pix[u][j] = vv * W + uu;
+                any = true;
+              }
             }
           }
         }
+        live[u] = live[u] && any;
       }
-      if (mask) {
-        if (COUNT_ONLY) {
-          cnt += __popc(mask);
-        } else {
-          uint4 q = vol[idx];
-          unsigned w4[4] = {q.x, q.y, q.z, q.w};
+      // phase 2: depth gathers (pixel 0 stands in for "no pixel": harmless read, result ignored)
+      float F[U][4];
+      unsigned mask[U];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (mask & (1u << j)) {
-              const int tp = (int)(short)(w4[j] & 0xffffu);
-              const int wp = (int)(short)(w4[j] >> 16);
-              const float Fp = (float)tp / 32767.0f;
-              const float Wp = (float)wp;
-              const float Fn = (Fp * Wp + F[j]) / (Wp + 1.0f);
-              int wn = wp + 1;
-              wn = wn > HSK_MAX_WEIGHT ? HSK_MAX_WEIGHT : wn;
-              int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
-              fixed = fixed > HSK_DIVISOR ? HSK_DIVISOR : fixed;
-              fixed = fixed < -HSK_DIVISOR ? -HSK_DIVISOR : fixed;
-              w4[j] = ((unsigned)fixed & 0xffffu) | ((unsigned)wn << 16);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) F[u][j] = scaled[pix[u][j] < 0 ? 0 : pix[u][j]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        mask[u] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float Ds = F[u][j];
+          if (pix[u][j] >= 0 && Ds != 0.0f) {
+            // v_sqrt_f32 (1 ulp) moves sdf by < 1e-6 m: decide with it unless sdf is within 2e-6 m of -tau
+            // or sdf/tau is not clearly >= 1 (the truncation band, where the exact value is stored)
+            const float arg = gz2[u] + pn[j];
+            const float sdf_a = Ds - __builtin_amdgcn_sqrtf(arg);
+            if (sdf_a * vp.tau_inv > 1.0001f) {
+              F[u][j] = 1.0f;
+              mask[u] |= 1u << j;
+            } else if (sdf_a >= -vp.tau - 2.0e-6f) {
+              const float sdf = Ds - sqrtf(arg);
+              if (sdf >= -vp.tau) {
+                const float f = sdf * vp.tau_inv;
+                F[u][j] = f < 1.0f ? f : 1.0f;
+                mask[u] |= 1u << j;
+              }
             }
           }
-          vol[idx] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        if (!live[u]) mask[u] = 0;
+      }
+      if (COUNT_ONLY) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt += __popc(mask[u]);
+        continue;
+      }
+      // phase 3: volume vectors that hold at least one rewritten voxel
+      uint4 q[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (mask[u]) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+      // phase 4: running mean, repack, store
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!mask[u]) continue;
+        unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+        bool neg = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (mask[u] & (1u << j)) {
+            const int tp = (int)(short)(w4[j] & 0xffffu);
+            const int wp = (int)(short)(w4[j] >> 16);
+            int wn = wp + 1;
+            wn = wn > HSK_MAX_WEIGHT ? HSK_MAX_WEIGHT : wn;
+            int fixed;
+            if (F[u][j] == 1.0f && tp == HSK_DIVISOR) {
+              fixed = HSK_DIVISOR;  // (1*W + 1) / (W + 1) == 1 exactly
+            } else {
+              float Fn;
+              if (wp == 0) {
+                Fn = F[u][j];  // (Fp*0 + F) / (0 + 1) == F exactly
+              } else {
+                const float Fp = (float)tp / 32767.0f;
+                const float Wp = (float)wp;
+                Fn = (Fp * Wp + F[u][j]) / (Wp + 1.0f);
+              }
+              fixed = (int)(Fn * 32767.0f);  // truncation toward zero
+              fixed = fixed > HSK_DIVISOR ? HSK_DIVISOR : fixed;
+              fixed = fixed < -HSK_DIVISOR ? -HSK_DIVISOR : fixed;
+            }
+            neg = neg || (fixed < 0);
+            w4[j] = ((unsigned)fixed & 0xffffu) | ((unsigned)wn << 16);
+          }
+        }
+        vol[idx0 + (size_t)(zb + u) * plane_vec] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        if (neg) {
+          const int bit = ((((zb + u) >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
+          // test first: after the first frames the bit is already set and no atomic is issued (a stale read
+          // only costs a redundant OR)
+          if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
+            __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -102,15 +286,36 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ vol, cons
 }
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
-                      int H, Intr in, bool count_only, unsigned long long* counter) {
+                      int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
+                      const float* tmax) {
   const int zchunks = vp.nzs >= 64 ? 8 : 1;
   const int zchunk = (vp.nzs + zchunks - 1) / zchunks;
+  const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   dim3 block(64, 4, 1);
-  dim3 grid((vp.X / 4 + 63) / 64, (vp.Y + 3) / 4, zchunks);
+  dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
+  const size_t lds = (size_t)tw * th * sizeof(float);
   if (count_only)
-    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in, zchunk, counter);
+    hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, lds, s, (uint4*)vol, scaled, st, vp, W, H, in, zchunk, counter,
+                       flags, tmax, tw, th);
   else
-    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in, zchunk, counter);
+    hipLaunchKernelGGL((k_integrate<false, INTEGRATE_U>), grid, block, lds, s, (uint4*)vol, scaled, st, vp, W, H, in, zchunk, counter,
+                       flags, tmax, tw, th);
+}
+
+// rebuild the brick bitfield from a volume that was uploaded rather than integrated
+__global__ void k_rebuild_flags(const short2* __restrict__ vol, VolParams vp, unsigned* __restrict__ flags) {
+  const size_t n = (size_t)vp.X * vp.Y * vp.nzs;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (vol[i].x < 0) {
+    const int x = (int)(i % vp.X), y = (int)((i / vp.X) % vp.Y), zz = (int)(i / ((size_t)vp.X * vp.Y));
+    const int bit = ((zz >> vp.bshift) * (vp.Y >> vp.bshift) + (y >> vp.bshift)) * (vp.X >> vp.bshift) + (x >> vp.bshift);
+    __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags) {
+  const size_t n = (size_t)vp.X * vp.Y * vp.nzs;
+  hipLaunchKernelGGL(k_rebuild_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const short2*)vol, vp, flags);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -134,21 +339,34 @@ static __device__ __forceinline__ float tsdf_at(const short2* __restrict__ vol, 
   return (float)raw_at(vol, vp, x, y, z) / 32767.0f;
 }
 
-static __device__ float trilinear(const short2* __restrict__ vol, const VolParams& vp, float px, float py, float pz) {
+// trilinear TSDF sample (A.6).  Branch-free: indices are clamped for the loads and the NaN of the spec
+// (sample on the outer shell of the grid) is selected at the end, so that the 8 taps of several calls can be
+// in flight together.
+static __device__ __forceinline__ float trilinear(const short2* __restrict__ vol, const VolParams& vp, float px, float py,
+                                                  float pz) {
   int gx = vox_of(px, vp.cell[0]), gy = vox_of(py, vp.cell[1]), gz = vox_of(pz, vp.cell[2]);
-  if (gx <= 0 || gx >= vp.X - 1) return HSK_NANF;
-  if (gy <= 0 || gy >= vp.Y - 1) return HSK_NANF;
-  if (gz <= 0 || gz >= vp.Z - 1) return HSK_NANF;
+  const bool ok = gx > 0 && gx < vp.X - 1 && gy > 0 && gy < vp.Y - 1 && gz > 0 && gz < vp.Z - 1;
+  gx = min(max(gx, 1), vp.X - 2);
+  gy = min(max(gy, 1), vp.Y - 2);
+  gz = min(max(gz, 1), vp.Z - 2);
   if (px < ((float)gx + 0.5f) * vp.cell[0]) gx -= 1;
   if (py < ((float)gy + 0.5f) * vp.cell[1]) gy -= 1;
   if (pz < ((float)gz + 0.5f) * vp.cell[2]) gz -= 1;
   const float a = (px - ((float)gx + 0.5f) * vp.cell[0]) / vp.cell[0];
   const float b = (py - ((float)gy + 0.5f) * vp.cell[1]) / vp.cell[1];
   const float c = (pz - ((float)gz + 0.5f) * vp.cell[2]) / vp.cell[2];
-  const float f000 = tsdf_at(vol, vp, gx, gy, gz), f001 = tsdf_at(vol, vp, gx, gy, gz + 1);
-  const float f010 = tsdf_at(vol, vp, gx, gy + 1, gz), f011 = tsdf_at(vol, vp, gx, gy + 1, gz + 1);
-  const float f100 = tsdf_at(vol, vp, gx + 1, gy, gz), f101 = tsdf_at(vol, vp, gx + 1, gy, gz + 1);
-  const float f110 = tsdf_at(vol, vp, gx + 1, gy + 1, gz), f111 = tsdf_at(vol, vp, gx + 1, gy + 1, gz + 1);
+  // stored planes: a tap outside the slab reads plane 0 of the slab and is discarded (cannot happen when the
+  // halo is sized as DESIGN.md prescribes)
+  const int z0 = gz - vp.zs0, z1 = z0 + 1;
+  const bool in0 = z0 >= 0 && z0 < vp.nzs, in1 = z1 >= 0 && z1 < vp.nzs;
+  const size_t row0 = ((size_t)(in0 ? z0 : 0) * vp.Y + gy) * vp.X + gx;
+  const size_t row1 = ((size_t)(in1 ? z1 : 0) * vp.Y + gy) * vp.X + gx;
+  const int r000 = vol[row0].x, r100 = vol[row0 + 1].x, r010 = vol[row0 + vp.X].x, r110 = vol[row0 + vp.X + 1].x;
+  const int r001 = vol[row1].x, r101 = vol[row1 + 1].x, r011 = vol[row1 + vp.X].x, r111 = vol[row1 + vp.X + 1].x;
+  const float f000 = (float)(in0 ? r000 : 0) / 32767.0f, f100 = (float)(in0 ? r100 : 0) / 32767.0f;
+  const float f010 = (float)(in0 ? r010 : 0) / 32767.0f, f110 = (float)(in0 ? r110 : 0) / 32767.0f;
+  const float f001 = (float)(in1 ? r001 : 0) / 32767.0f, f101 = (float)(in1 ? r101 : 0) / 32767.0f;
+  const float f011 = (float)(in1 ? r011 : 0) / 32767.0f, f111 = (float)(in1 ? r111 : 0) / 32767.0f;
   float res = f000 * (1.0f - a) * (1.0f - b) * (1.0f - c);
   res = res + f001 * (1.0f - a) * (1.0f - b) * c;
   res = res + f010 * (1.0f - a) * b * (1.0f - c);
@@ -157,12 +375,31 @@ static __device__ float trilinear(const short2* __restrict__ vol, const VolParam
   res = res + f101 * a * (1.0f - b) * c;
   res = res + f110 * a * b * (1.0f - c);
   res = res + f111 * a * b * c;
-  return res;
+  return ok ? res : HSK_NANF;
+}
+
+// floor(p / cell) of the spec without the IEEE division in the common case: q = p * (1/cell) differs from the
+// correctly rounded quotient by < 3 * 2^-24 * |q|, so unless q sits within 2.5e-4 of an integer (|q| < 1100)
+// both have the same floor; the rare lanes that do sit there take the exact division.
+static __device__ __forceinline__ int vox_fast(float p, float cell, float inv_cell) {
+  const float q = p * inv_cell;
+  float f = floorf(q);
+  const float fr = q - f;
+  if (!(fr > 2.5e-4f && fr < 0.99975f && q > -1100.0f && q < 1100.0f)) f = floorf(p / cell);
+  if (!(f >= 0.0f)) return -1;
+  if (f > 1.0e6f) return 1000000;
+  return (int)f;
 }
 
 __global__ __launch_bounds__(256) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
                                                  VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
-                                                 float* __restrict__ nmap, int* __restrict__ keys) {
+                                                 float* __restrict__ nmap, int* __restrict__ keys,
+                                                 const unsigned* __restrict__ flags, int flag_words) {
+  // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
+  // global memory only next to surfaces
+  extern __shared__ unsigned lflags[];
+  for (int w = threadIdx.x; w < flag_words; w += blockDim.x) lflags[w] = flags[w];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int tiles_x = (W + 7) >> 3;
@@ -194,52 +431,98 @@ __global__ __launch_bounds__(256) void k_raycast(const short2* __restrict__ vol,
   const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
   t_start = fmaxf(t_start, 0.0f);
   if (t_start < t_exit) {
+    const float ic0 = 1.0f / vp.cell[0], ic1 = 1.0f / vp.cell[1], ic2 = 1.0f / vp.cell[2];
+    const int bs = vp.bshift;
+    const int bxn = vp.X >> bs, byn = vp.Y >> bs;
     const float time_step = vp.tau * 0.8f;
     const float max_time = 3.0f * ((vp.size[0] + vp.size[1]) + vp.size[2]);
     float time_curr = t_start;
     int step = 0;
+    // near sample of step 0: the entry voxel, clamped into the grid (A.6)
+    int qx = vox_fast(t0 + d0 * time_curr, vp.cell[0], ic0);
+    int qy = vox_fast(t1 + d1 * time_curr, vp.cell[1], ic1);
+    int qz = vox_fast(t2 + d2 * time_curr, vp.cell[2], ic2);
+    int px = qx < 0 ? 0 : (qx > vp.X - 1 ? vp.X - 1 : qx);
+    int py = qy < 0 ? 0 : (qy > vp.Y - 1 ? vp.Y - 1 : qy);
+    int pz = qz < 0 ? 0 : (qz > vp.Z - 1 ? vp.Z - 1 : qz);
+    bool have_prev = false;  // fl_prev is the brick flag of the current near sample
+    bool crossing = false;
+    int nux = 0, nuy = 0, nuz = 0;  // unclamped voxel of the near sample at the crossing
+    unsigned fl_prev = 0;
     for (; time_curr < max_time; time_curr = time_curr + time_step, ++step) {
       const float tn = time_curr + time_step;
       const float pnx = t0 + d0 * tn, pny = t1 + d1 * tn, pnz = t2 + d2 * tn;
-      const int gx = vox_of(pnx, vp.cell[0]), gy = vox_of(pny, vp.cell[1]), gz = vox_of(pnz, vp.cell[2]);
-      if (gx < 0 || gy < 0 || gz < 0 || gx >= vp.X || gy >= vp.Y || gz >= vp.Z) break;
-      if (gz < vp.zo0 || gz >= vp.zo1) continue;
-      const float pcx = t0 + d0 * time_curr, pcy = t1 + d1 * time_curr, pcz = t2 + d2 * time_curr;
-      const int qx = vox_of(pcx, vp.cell[0]), qy = vox_of(pcy, vp.cell[1]), qz = vox_of(pcz, vp.cell[2]);
-      const int cxv = qx < 0 ? 0 : (qx > vp.X - 1 ? vp.X - 1 : qx);
-      const int cyv = qy < 0 ? 0 : (qy > vp.Y - 1 ? vp.Y - 1 : qy);
-      const int czv = qz < 0 ? 0 : (qz > vp.Z - 1 ? vp.Z - 1 : qz);
+      // voxel of the far sample: floor(p / cell) of the spec; the products q = p * (1/cell) give the same floor
+      // unless one of them sits within 2.5e-4 of an integer (see vox_fast), checked for the three axes at once
+      const float q0 = pnx * ic0, q1 = pny * ic1, q2 = pnz * ic2;
+      float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+      const float e = fminf(fminf(fabsf(q0 - rintf(q0)), fabsf(q1 - rintf(q1))), fabsf(q2 - rintf(q2)));
+      const float m = fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fabsf(q2));
+      if (!(e > 2.5e-4f && m < 1100.0f)) {
+        f0 = floorf(pnx / vp.cell[0]);
+        f1 = floorf(pny / vp.cell[1]);
+        f2 = floorf(pnz / vp.cell[2]);
+      }
+      // v_cvt_i32_f32 saturates; a negative or huge index fails the unsigned bound test below
+      const int gx = (int)f0, gy = (int)f1, gz = (int)f2;
+      if ((unsigned)gx >= (unsigned)vp.X || (unsigned)gy >= (unsigned)vp.Y || (unsigned)gz >= (unsigned)vp.Z) break;
+      const int cxv = px, cyv = py, czv = pz;  // near sample of this step (already inside the grid)
+      const int ux = qx, uy = qy, uz = qz;     // ... and its unclamped voxel (differs only at step 0)
+      px = gx; py = gy; pz = gz;               // the far sample is the next step's near sample
+      qx = gx; qy = gy; qz = gz;
+      if (gz < vp.zo0 || gz >= vp.zo1) {       // step owned by another slab
+        have_prev = false;
+        continue;
+      }
+      // an event needs a negative sample: skip the voxel gathers when neither brick ever held one
+      const int bf = (((gz - vp.zs0) >> bs) * byn + (gy >> bs)) * bxn + (gx >> bs);
+      const unsigned fl_far = (lflags[bf >> 5] >> (bf & 31)) & 1u;
+      unsigned fl_near = fl_prev;
+      if (!have_prev) {
+        const int zzn = czv - vp.zs0;
+        const int bn = ((zzn >> bs) * byn + (cyv >> bs)) * bxn + (cxv >> bs);
+        fl_near = (zzn >= 0 && zzn < vp.nzs) ? ((lflags[bn >> 5] >> (bn & 31)) & 1u) : 0;
+      }
+      fl_prev = fl_far;
+      have_prev = true;
+      if (!(fl_far | fl_near)) continue;
       const int raw_prev = raw_at(vol, vp, cxv, cyv, czv);
       const int raw = raw_at(vol, vp, gx, gy, gz);
-      if (raw_prev < 0 && raw > 0) {
+      if (raw_prev < 0 && raw > 0) {  // back face
         key = (step << 1) | 1;
         break;
       }
-      if (raw_prev > 0 && raw < 0) {
-        key = (step << 1) | 1;
-        const float Ftdt = trilinear(vol, vp, pnx, pny, pnz);
-        if (!hsk_isnan(Ftdt)) {
-          const float Ft = trilinear(vol, vp, pcx, pcy, pcz);
-          if (!hsk_isnan(Ft)) {
-            const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
-            if (Ts >= time_curr - 0.5f * time_step && Ts <= time_curr + 1.5f * time_step) {
-              vx = t0 + d0 * Ts;
-              vy = t1 + d1 * Ts;
-              vz = t2 + d2 * Ts;
-              key = (step << 1);
-              if (qx > 1 && qy > 1 && qz > 1 && qx < vp.X - 2 && qy < vp.Y - 2 && qz < vp.Z - 2) {
-                const float gxn = trilinear(vol, vp, vx + vp.cell[0], vy, vz) - trilinear(vol, vp, vx - vp.cell[0], vy, vz);
-                const float gyn = trilinear(vol, vp, vx, vy + vp.cell[1], vz) - trilinear(vol, vp, vx, vy - vp.cell[1], vz);
-                const float gzn = trilinear(vol, vp, vx, vy, vz + vp.cell[2]) - trilinear(vol, vp, vx, vy, vz - vp.cell[2]);
-                const float ninv = 1.0f / sqrtf(hsk_dot3(gxn, gyn, gzn, gxn, gyn, gzn));
-                nx = gxn * ninv;
-                ny = gyn * ninv;
-                nz = gzn * ninv;
-              }
-            }
+      if (raw_prev > 0 && raw < 0) {  // zero crossing: leave the loop, refine below with every lane of the wave
+        crossing = true;
+        nux = ux; nuy = uy; nuz = uz;
+        break;
+      }
+    }
+    // Deferred hit processing: lanes hit at different steps, and refining inside the loop would run these
+    // (memory-latency-bound) taps once per distinct step.  Here the wave runs them once, loads batched.
+    if (crossing) {
+      key = (step << 1) | 1;
+      const float tn = time_curr + time_step;
+      const float Ftdt = trilinear(vol, vp, t0 + d0 * tn, t1 + d1 * tn, t2 + d2 * tn);
+      const float Ft = trilinear(vol, vp, t0 + d0 * time_curr, t1 + d1 * time_curr, t2 + d2 * time_curr);
+      if (!hsk_isnan(Ftdt) && !hsk_isnan(Ft)) {
+        const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
+        if (Ts >= time_curr - 0.5f * time_step && Ts <= time_curr + 1.5f * time_step) {
+          vx = t0 + d0 * Ts;
+          vy = t1 + d1 * Ts;
+          vz = t2 + d2 * Ts;
+          key = (step << 1);
+          if (nux > 1 && nuy > 1 && nuz > 1 && nux < vp.X - 2 && nuy < vp.Y - 2 && nuz < vp.Z - 2) {
+            const float xp = trilinear(vol, vp, vx + vp.cell[0], vy, vz), xm = trilinear(vol, vp, vx - vp.cell[0], vy, vz);
+            const float yp = trilinear(vol, vp, vx, vy + vp.cell[1], vz), ym = trilinear(vol, vp, vx, vy - vp.cell[1], vz);
+            const float zp = trilinear(vol, vp, vx, vy, vz + vp.cell[2]), zm = trilinear(vol, vp, vx, vy, vz - vp.cell[2]);
+            const float gxn = xp - xm, gyn = yp - ym, gzn = zp - zm;
+            const float ninv = 1.0f / sqrtf(hsk_dot3(gxn, gyn, gzn, gxn, gyn, gzn));
+            nx = gxn * ninv;
+            ny = gyn * ninv;
+            nz = gzn * ninv;
           }
         }
-        break;
       }
     }
   }
@@ -253,11 +536,13 @@ __global__ __launch_bounds__(256) void k_raycast(const short2* __restrict__ vol,
 }
 
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys) {
+                    float* vmap, float* nmap, int* keys, const unsigned* flags) {
   const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
   dim3 block(256);
   dim3 grid((tiles + 3) / 4);
-  hipLaunchKernelGGL(k_raycast, grid, block, 0, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap, keys);
+  const int words = hsk_flag_words(vp);
+  hipLaunchKernelGGL(k_raycast, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
+                     keys, flags, words);
 }
 
 // ------------------------------------------------------------------------------------------------------

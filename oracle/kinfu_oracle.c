@@ -419,6 +419,7 @@ int ora_icp_solve(const double in27[27], float x6[6]) {
     }
   memset(L, 0, sizeof(L));
   double det = 1.0;
+  double inv[6]; /* one reciprocal per pivot; every later "divide by L[j][j]" is a multiply by it */
   for (int j = 0; j < 6; ++j) {
     double s = A[j][j];
     for (int q = 0; q < j; ++q) s = s - L[j][q] * L[j][q];
@@ -428,11 +429,12 @@ int ora_icp_solve(const double in27[27], float x6[6]) {
     }
     const double d = sqrt(s);
     L[j][j] = d;
+    inv[j] = 1.0 / d;
     det = det * s;
     for (int i = j + 1; i < 6; ++i) {
       double r = A[i][j];
       for (int q = 0; q < j; ++q) r = r - L[i][q] * L[j][q];
-      L[i][j] = r / d;
+      L[i][j] = r * inv[j];
     }
   }
   if (!(det >= 1e-15)) { /* also catches NaN */
@@ -443,12 +445,12 @@ int ora_icp_solve(const double in27[27], float x6[6]) {
   for (int i = 0; i < 6; ++i) {
     double r = b[i];
     for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
-    yv[i] = r / L[i][i];
+    yv[i] = r * inv[i];
   }
   for (int i = 5; i >= 0; --i) {
     double r = yv[i];
     for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
-    xv[i] = r / L[i][i];
+    xv[i] = r * inv[i];
   }
   for (int q = 0; q < 6; ++q) {
     if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) {
