@@ -20,23 +20,58 @@
 // ------------------------------------------------------------------------------------------------------
 #define HSK_TILE 16
 #ifndef INTEGRATE_U
-#define INTEGRATE_U 4
+#define INTEGRATE_U 1  // software-pipeline depth of k_integrate (1 measured fastest: profiles/r01/integrate_analysis.md)
+#endif
+#ifndef INTEGRATE_ZCHUNK
+#define INTEGRATE_ZCHUNK 8
 #endif
 
-__global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax, int tw) {
-  __shared__ float sh[4];
+__global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax,
+                           float* __restrict__ tmin, int tw) {
+  __shared__ float shx[4], shn[4];
   const int tx = blockIdx.x, ty = blockIdx.y;
   const int x = tx * HSK_TILE + (threadIdx.x & 15), y = ty * HSK_TILE + (threadIdx.x >> 4);
-  float v = (x < W && y < H) ? scaled[y * W + x] : 0.0f;
+  const bool in = x < W && y < H;
+  const float v = in ? scaled[y * W + x] : 0.0f;
+  float mx = v, mn = v;  // a pixel outside the image or without depth makes the tile minimum 0 ("not all valid")
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    shx[threadIdx.x >> 6] = mx;
+    shn[threadIdx.x >> 6] = mn;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) tmax[ty * tw + tx] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  if (threadIdx.x == 0) {
+    tmax[ty * tw + tx] = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
+    tmin[ty * tw + tx] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
+  }
 }
-void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax) {
+// 3x3 dilation of the tile tables into one interleaved (max, min) table, once per frame (the integrate blocks
+// only copy the result into LDS)
+__global__ void k_tile_dilate(const float* __restrict__ tmax, const float* __restrict__ tmin, float2* __restrict__ dtab,
+                              int tw, int th) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tw * th) return;
+  const int ty = i / tw, tx = i - ty * tw;
+  float mx = 0.0f, mn = 1e30f;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
+      mx = fmaxf(mx, tmax[yy * tw + xx]);
+      mn = fminf(mn, tmin[yy * tw + xx]);
+    }
+  dtab[i] = make_float2(mx, mn);
+}
+// tiles holds 4 * tw * th floats: raw max, raw min, then the interleaved dilated (max, min) table
+void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tiles) {
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
-  hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tmax, tw);
+  const int n = tw * th;
+  hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tiles, tiles + n, tw);
+  hipLaunchKernelGGL(k_tile_dilate, dim3((n + 255) / 256), dim3(256), 0, s, tiles, tiles + n, (float2*)(tiles + 2 * n), tw,
+                     th);
 }
 
 // clip [lo,hi] (in gz) with c + m*gz >= 0
@@ -51,230 +86,320 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
   }
 }
 
-template <bool COUNT_ONLY, int U>
+// Per-frame pre-pass: for every lane column (4 x-adjacent voxels at one y) the range of stored planes that can
+// project into the padded image [-1.5, W+0.5] x [-1.5, H+0.5] in front of the camera.  The view frustum is
+// convex, so each column meets it in one interval; clipping the line cam(gz) = a + gz * c against the five
+// half-spaces gives it.  Conservative by 2 planes (float error).  Empty columns get (INT_MAX, INT_MIN).
+__global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
+                                int2* __restrict__ zint) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncol = vp.X / 4;
+  if (c >= ncol * vp.Y) return;
+  const int y = c / ncol, x0 = (c - y * ncol) * 4;
+  const float tx = st->t[0], ty = st->t[1], tz = st->t[2];
+  const float i00 = st->R[0], i01 = st->R[3], i02 = st->R[6];
+  const float i10 = st->R[1], i11 = st->R[4], i12 = st->R[7];
+  const float i20 = st->R[2], i21 = st->R[5], i22 = st->R[8];
+  const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
+  float glo = 1e30f, ghi = -1e30f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
+    const float ax = i00 * gx + i01 * gy, ay = i10 * gx + i11 * gy, az = i20 * gx + i21 * gy;
+    float lo = -1e30f, hi = 1e30f;
+    clip_interval(az, i22, lo, hi);
+    const float ul = 1.5f + in.cx, uh = ((float)W + 0.5f) - in.cx;
+    const float vl = 1.5f + in.cy, vh = ((float)H + 0.5f) - in.cy;
+    clip_interval(ax * in.fx + ul * az, i02 * in.fx + ul * i22, lo, hi);
+    clip_interval(uh * az - ax * in.fx, uh * i22 - i02 * in.fx, lo, hi);
+    clip_interval(ay * in.fy + vl * az, i12 * in.fy + vl * i22, lo, hi);
+    clip_interval(vh * az - ay * in.fy, vh * i22 - i12 * in.fy, lo, hi);
+    if (lo <= hi) {
+      glo = fminf(glo, lo);
+      ghi = fmaxf(ghi, hi);
+    }
+  }
+  int zl = 0x7fffffff, zh = -0x7fffffff;
+  if (glo <= ghi) {
+    // gz = (z + 0.5) * cell_z - tz  =>  z = (gz + tz) / cell_z - 0.5; pad by 2 planes for float error
+    const float inv_cz = __builtin_amdgcn_rcpf(vp.cell[2]);
+    const float fl = (glo + tz) * inv_cz - 2.5f, fh = (ghi + tz) * inv_cz + 1.5f;
+    const int a = fl < -1e9f ? -1000000000 : (fl > 1e9f ? 1000000000 : (int)floorf(fl));
+    const int b = fh < -1e9f ? -1000000000 : (fh > 1e9f ? 1000000000 : (int)ceilf(fh));
+    zl = a - vp.zs0;
+    zh = b - vp.zs0;
+  }
+  zint[c] = make_int2(zl, zh);
+}
+
+// per-lane, z-invariant terms of one column group (4 x-adjacent voxels)
+struct ColumnTerms {
+  float ax[4], ay[4], az[4], pn[4];  // (R^T (gx, gy, 0)) per voxel and gx^2 + gy^2
+  float axfc, ayfc, azc, pnc;        // group centre: x/y terms pre-multiplied by fx/fy
+};
+// wave-uniform constants of the launch
+struct IntegrateConst {
+  float i02, i12, i22, tz;
+  float rk, zmin, cull_thr, free_thr, hw, hh;
+};
+
+// Phases 0-2b for ONE plane: which of the lane's 4 voxels are rewritten (mask), which of those with F == 1
+// (one), and F for the others.  Branch-free inside, guarded by wave-uniform ballots; the correctly rounded
+// division / square root of the spec run only for voxels flagged as sitting on a decision boundary.
+static __device__ __forceinline__ void classify_plane(int zz, bool in_range, const ColumnTerms& c,
+                                                      const IntegrateConst& k, const VolParams& vp, int W, int H,
+                                                      const Intr& in, const float2* __restrict__ dtab, int tw, int th,
+                                                      const float* __restrict__ scaled, unsigned& mask, unsigned& one,
+                                                      float F[4]) {
+  mask = 0;
+  one = 0;
+  const float gz = ((float)(vp.zs0 + zz) + 0.5f) * vp.cell[2] - k.tz;
+  const float gz2 = gz * gz;
+  // ---- phase 0: classify the 4-voxel group against the tile table (conservative):
+  //      dead  -- nearest possible point farther than the largest depth around its pixels + tau,
+  //      free4 -- farthest possible point closer than the smallest (all-valid) depth around - tau,
+  //      detail otherwise.
+  const float czc = c.azc + k.i22 * gz;
+  const float rc = __builtin_amdgcn_rcpf(czc);
+  const float uc = (c.axfc + (k.i02 * gz) * in.fx) * rc + in.cx;
+  const float vc = (c.ayfc + (k.i12 * gz) * in.fy) * rc + in.cy;
+  const float r = k.rk * rc + 2.5f;
+  const bool ok = czc > k.zmin && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
+  const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
+  const float2 D = dtab[tv * tw + tu];
+  const float dc = __builtin_amdgcn_sqrtf(gz2 + c.pnc);
+  const bool dead = !in_range || (ok && (dc * 0.99999f - D.x > k.cull_thr));
+  const bool fr = in_range && ok && (dc * 1.00001f + k.free_thr <= D.y);
+  const bool detail = !dead && !fr;
+  if (fr) mask = one = 0xFu;
+  if (__ballot(detail) == 0ull) return;  // no lane of the wave needs voxel detail in this plane
+  // ---- phase 1: project (v_rcp_f32 instead of the division: moves the coordinate by < 1.6e-4 px)
+  const float bx = k.i02 * gz, by = k.i12 * gz, bz = k.i22 * gz;
+  int pix[4];
+  unsigned nearb = 0;  // bit j: pixel coordinate within 3e-4 px of a rounding boundary
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float camz = c.az[j] + bz;
+    const float inv_a = __builtin_amdgcn_rcpf(camz);
+    const float fu = ((c.ax[j] + bx) * in.fx) * inv_a + in.cx;
+    const float fv = ((c.ay[j] + by) * in.fy) * inv_a + in.cy;
+    const float ru = rintf(fu), rv = rintf(fv);
+    const int uu = (int)ru, vv = (int)rv;  // saturating conversion
+    const bool front = detail && camz > 0.0f && fabsf(fu) < 1.0e5f && fabsf(fv) < 1.0e5f;
+    const bool inb = front && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
+    const bool nb = front && fmaxf(fabsf(fu - ru), fabsf(fv - rv)) > 0.5f - 3.0e-4f;
+    pix[j] = inb ? vv * W + uu : -1;
+    nearb |= (nb ? 1u : 0u) << j;
+  }
+  if (nearb) {  // the correctly rounded division of the spec, only where it can change the pixel
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (nearb & (1u << j)) {
+        const float inv_z = 1.0f / (c.az[j] + bz);
+        const float fu = ((c.ax[j] + bx) * in.fx) * inv_z + in.cx;
+        const float fv = ((c.ay[j] + by) * in.fy) * inv_z + in.cy;
+        int uu, vv;
+        pix[j] = (hsk_rint_guard(fu, uu) && hsk_rint_guard(fv, vv) && uu >= 0 && vv >= 0 && uu < W && vv < H) ? vv * W + uu
+                                                                                                            : -1;
+      }
+  }
+  // ---- phase 2: depth gathers, all in flight together (pixel 0 stands in for "no pixel")
+#pragma unroll
+  for (int j = 0; j < 4; ++j) F[j] = scaled[max(pix[j], 0)];
+  // ---- phase 2b: classify with v_sqrt_f32 (moves sdf by < 1e-6 m); undecided voxels get the exact sdf
+  unsigned unsure = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float Ds = F[j];
+    const float sdf_a = Ds - __builtin_amdgcn_sqrtf(gz2 + c.pn[j]);
+    const bool val = pix[j] >= 0 && Ds != 0.0f;
+    const bool sure = val && sdf_a * vp.tau_inv > 1.0001f;
+    const bool maybe = val && !sure && sdf_a >= -vp.tau - 2.0e-6f;
+    mask |= (sure ? 1u : 0u) << j;
+    one |= (sure ? 1u : 0u) << j;
+    unsure |= (maybe ? 1u : 0u) << j;
+  }
+  if (unsure) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (unsure & (1u << j)) {
+        const float sdf = F[j] - sqrtf(gz2 + c.pn[j]);
+        if (sdf >= -vp.tau) {
+          const float f = sdf * vp.tau_inv;
+          mask |= 1u << j;
+          if (f < 1.0f)
+            F[j] = f;
+          else
+            one |= 1u << j;
+        }
+      }
+  }
+}
+
+// Phase 4 for one plane: running mean (A.4), repack.  Returns true when a negative TSDF was written.
+static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]) {
+  unsigned w4[4] = {q.x, q.y, q.z, q.w};
+  // saturated free space: F == 1 onto a stored +1 gives (1*W + 1) / (W + 1) == 1 exactly: only W moves
+  bool simple = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool upd = (mask >> j) & 1u;
+    const bool sj = ((one >> j) & 1u) && (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
+    simple = simple && (!upd || sj);
+  }
+  bool neg = false;
+  if (simple) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool upd = (mask >> j) & 1u;
+      w4[j] += (upd && (w4[j] >> 16) < (unsigned)HSK_MAX_WEIGHT) ? 0x10000u : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!((mask >> j) & 1u)) continue;
+      const int tp = (int)(short)(w4[j] & 0xffffu);
+      const int wp = (int)(short)(w4[j] >> 16);
+      const float Fj = ((one >> j) & 1u) ? 1.0f : F[j];
+      float Fn;
+      if (wp == 0) {
+        Fn = Fj;  // (Fp*0 + F) / (0 + 1) == F exactly
+      } else if (Fj == 1.0f && tp == HSK_DIVISOR) {
+        Fn = 1.0f;
+      } else {
+        const float Fp = (float)tp / 32767.0f;
+        const float Wp = (float)wp;
+        Fn = (Fp * Wp + Fj) / (Wp + 1.0f);
+      }
+      int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
+      fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
+      const int wn = min(wp + 1, HSK_MAX_WEIGHT);
+      neg = neg || (fixed < 0);
+      w4[j] = ((unsigned)fixed & 0xffffu) | ((unsigned)wn << 16);
+    }
+  }
+  q = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+  return neg;
+}
+
+// The integrate kernel.  D = software-pipeline depth: plane z+D is classified and its volume vector requested
+// before plane z is updated and stored, so every wave keeps D 1-KiB requests in flight (the kernel is bound by
+// HBM latency x occupancy otherwise -- profiles/r01/integrate_wave_timing.txt).
+template <bool COUNT_ONLY, int D>
 __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
                                                    const TrackState* __restrict__ st, VolParams vp, int W, int H,
                                                    Intr in, int zchunk, unsigned long long* __restrict__ counter,
-                                                   unsigned* __restrict__ flags, const float* __restrict__ tmax,
-                                                   int tw, int th) {
-  extern __shared__ float dmax[];  // 3x3-dilated tile maxima of the scaled depth
+                                                   unsigned* __restrict__ flags, const float2* __restrict__ dtab,
+                                                   int tw, int th, const int2* __restrict__ zint) {
+  // dtab: per 16x16-pixel tile (max, min-if-all-valid) of the scaled depth, 3x3-dilated.  It is 9.6 KB and stays
+  // hot in every CU's vector L1; staging it in LDS per workgroup cost ~2.5 us of each short-lived block's life.
   const int lane = threadIdx.x;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
   if (!COUNT_ONLY && st->lost) return;
-  for (int i = tid; i < tw * th; i += 256) {
-    const int ty = i / tw, tx = i - ty * tw;
-    float m = 0.0f;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
-        m = fmaxf(m, tmax[yy * tw + xx]);
-      }
-    dmax[i] = m;
-  }
-  __syncthreads();
   // wave footprint: 64 voxels in x (16 lanes x 16 B = 256 contiguous bytes) by 4 rows in y -- compact, so
-  // that the wave-uniform z range and the group culls reject whole wave trips, not just lanes
+  // that the wave-uniform z range and the group classification reject whole planes, not just lanes
   const int x0 = (blockIdx.x * 16 + (lane & 15)) * 4;
   const int y = (blockIdx.y * 4 + threadIdx.y) * 4 + (lane >> 4);
   const bool active = (x0 < vp.X) && (y < vp.Y);
   unsigned long long cnt = 0;
   const int zbeg = blockIdx.z * zchunk;
   const int zend = min(zbeg + zchunk, vp.nzs);
-  const float tx = st->t[0], ty = st->t[1], tz = st->t[2];
-  // Rinv = R^T
-  const float i00 = st->R[0], i01 = st->R[3], i02 = st->R[6];
-  const float i10 = st->R[1], i11 = st->R[4], i12 = st->R[7];
-  const float i20 = st->R[2], i21 = st->R[5], i22 = st->R[8];
-  float ax[4], ay[4], az[4], pn[4];
   int zl = 0x7fffffff, zh = -0x7fffffff;  // this lane's stored-plane range inside the padded frustum
   if (active) {
-    const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
-    float glo = 1e30f, ghi = -1e30f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
-      ax[j] = i00 * gx + i01 * gy;
-      ay[j] = i10 * gx + i11 * gy;
-      az[j] = i20 * gx + i21 * gy;
-      pn[j] = gx * gx + gy * gy;
-      // cam(gz) = (ax,ay,az) + gz * (i02,i12,i22); keep gz where the pixel can fall in [-1.5, W+0.5] x [-1.5, H+0.5]
-      float lo = -1e30f, hi = 1e30f;
-      clip_interval(az[j], i22, lo, hi);
-      const float ul = 1.5f + in.cx, uh = ((float)W + 0.5f) - in.cx;
-      const float vl = 1.5f + in.cy, vh = ((float)H + 0.5f) - in.cy;
-      clip_interval(ax[j] * in.fx + ul * az[j], i02 * in.fx + ul * i22, lo, hi);
-      clip_interval(uh * az[j] - ax[j] * in.fx, uh * i22 - i02 * in.fx, lo, hi);
-      clip_interval(ay[j] * in.fy + vl * az[j], i12 * in.fy + vl * i22, lo, hi);
-      clip_interval(vh * az[j] - ay[j] * in.fy, vh * i22 - i12 * in.fy, lo, hi);
-      if (lo <= hi) {
-        glo = fminf(glo, lo);
-        ghi = fmaxf(ghi, hi);
-      }
-    }
-    if (glo <= ghi) {
-      // gz = (z + 0.5) * cell_z - tz  =>  z = (gz + tz) / cell_z - 0.5; pad by 2 planes for float error
-      const float inv_cz = __builtin_amdgcn_rcpf(vp.cell[2]);
-      const float fl = (glo + tz) * inv_cz - 2.5f, fh = (ghi + tz) * inv_cz + 1.5f;
-      const int a = fl < -1e9f ? -1000000000 : (fl > 1e9f ? 1000000000 : (int)floorf(fl));
-      const int b = fh < -1e9f ? -1000000000 : (fh > 1e9f ? 1000000000 : (int)ceilf(fh));
-      zl = max(a - vp.zs0, zbeg);
-      zh = min(b - vp.zs0, zend - 1);
-    }
+    const int2 zr = zint[(size_t)y * (vp.X / 4) + (x0 >> 2)];  // computed once per frame by k_column_zrange
+    zl = max(zr.x, zbeg);
+    zh = min(zr.y, zend - 1);
   }
-  // wave-uniform loop bounds
-  int wl = zl, wh = zh;
+  int wl = zl, wh = zh;  // wave-uniform loop bounds
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     wl = min(wl, __shfl_xor(wl, o, 64));
     wh = max(wh, __shfl_xor(wh, o, 64));
   }
-  const float cull_r_num = 2.75f * fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2])) * fmaxf(in.fx, in.fy);
-  const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
-  if (active && wl <= wh) {
+  if (wl <= wh) {
+    const float tx = st->t[0], ty = st->t[1];
+    // Rinv = R^T
+    const float i00 = st->R[0], i01 = st->R[3], i10 = st->R[1], i11 = st->R[4], i20 = st->R[2], i21 = st->R[5];
+    IntegrateConst k;
+    k.i02 = st->R[6];
+    k.i12 = st->R[7];
+    k.i22 = st->R[8];
+    k.tz = st->t[2];
+    // The 4 voxels of a lane lie within 1.5 cells of the group centre; their pixels lie within
+    // r = rk / z + 2.5 px of the centre's pixel when z > zmin (z - 2 cells >= z / 1.06).
+    const float cellm = fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2]));
+    k.rk = 1.06f * 2.75f * cellm * fmaxf(in.fx, in.fy);
+    k.zmin = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk / ((float)HSK_TILE - 2.5f));
+    k.cull_thr = vp.tau * 1.001f + 1e-4f + 2.0f * vp.cell[0];
+    k.free_thr = vp.tau * 1.0002f + 1e-4f + 2.0f * vp.cell[0];
+    k.hw = 0.5f * (float)(W - 1);
+    k.hh = 0.5f * (float)(H - 1);
+    ColumnTerms c;
+    {
+      const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
+        c.ax[j] = i00 * gx + i01 * gy;
+        c.ay[j] = i10 * gx + i11 * gy;
+        c.az[j] = i20 * gx + i21 * gy;
+        c.pn[j] = gx * gx + gy * gy;
+      }
+      c.axfc = 0.5f * (c.ax[1] + c.ax[2]) * in.fx;
+      c.ayfc = 0.5f * (c.ay[1] + c.ay[2]) * in.fy;
+      c.azc = 0.5f * (c.az[1] + c.az[2]);
+      c.pnc = 0.5f * (c.pn[1] + c.pn[2]);
+    }
+    const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
     const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
     const int bricks_x = vp.X >> vp.bshift, bricks_y = vp.Y >> vp.bshift;
-    // U planes per trip: phase 1 projects (arithmetic + LDS only), phase 2 puts every depth gather of the trip
-    // in flight, phase 3 puts every needed volume vector in flight, phase 4 updates and stores.  One trip
-    // costs two memory round trips however large U is; U sets the bytes in flight per wave.
-    for (int zb = wl; zb <= wh; zb += U) {
-      int pix[U][4];
-      float gz2[U];
-      bool live[U];
+    uint4 q[D];
+    float F[D][4];
+    unsigned mask[D], one[D];
+    // pipeline prologue: planes wl .. wl+D-1
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int zz = zb + u;
-        live[u] = (zz >= zl) && (zz <= zh);
-        const float gz = ((float)(vp.zs0 + zz) + 0.5f) * vp.cell[2] - tz;
-        const float bx = i02 * gz, by = i12 * gz, bz = i22 * gz;
-        gz2[u] = gz * gz;
-        // occlusion cull of the whole 4-voxel group against the dilated tile maximum
-        const float czc = 0.5f * ((az[1] + bz) + (az[2] + bz));
-        if (live[u] && czc > 0.1f) {
-          const float rc = __builtin_amdgcn_rcpf(czc);
-          const float r = cull_r_num * __builtin_amdgcn_rcpf(czc - 2.0f * vp.cell[0]) + 2.5f;
-          const float uc = 0.5f * ((ax[1] + bx) + (ax[2] + bx)) * in.fx * rc + in.cx;
-          const float vc = 0.5f * ((ay[1] + by) + (ay[2] + by)) * in.fy * rc + in.cy;
-          if (r <= (float)HSK_TILE && czc > 4.0f * vp.cell[0] && uc >= 0.0f && vc >= 0.0f && uc < (float)W && vc < (float)H) {
-            const float D = dmax[((int)vc / HSK_TILE) * tw + ((int)uc / HSK_TILE)];
-            const float dc = __builtin_amdgcn_sqrtf(gz2[u] + 0.5f * (pn[1] + pn[2]));
-            if (dc * 0.99999f - 2.0f * vp.cell[0] - D > vp.tau * 1.001f + 1e-4f) live[u] = false;
-          }
-        }
-        bool any = false;
+    for (int d = 0; d < D; ++d) {
+      const int zz = wl + d;
+      mask[d] = 0;
+      if (zz <= wh) {
+        classify_plane(zz, active && zz >= zl && zz <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, mask[d], one[d], F[d]);
+        if (COUNT_ONLY)
+          cnt += __popc(mask[d]);
+        else if (mask[d])
+          q[d] = vol[idx0 + (size_t)zz * plane_vec];
+      }
+    }
+    if (!COUNT_ONLY) {
+      for (int zb = wl; zb <= wh; zb += D) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pix[u][j] = -1;
-          const float camz = az[j] + bz;
-          if (live[u] && camz > 0.0f) {
-            // v_rcp_f32 (1 ulp) moves the pixel coordinate by < 1.6e-4 px; only a coordinate within 3e-4 px
-            // of a rounding boundary (x.5) needs the correctly rounded division of the spec
-            const float px_ = (ax[j] + bx) * in.fx, py_ = (ay[j] + by) * in.fy;
-            const float inv_a = __builtin_amdgcn_rcpf(camz);
-            float fu = px_ * inv_a + in.cx;
-            float fv = py_ * inv_a + in.cy;
-            if (fu > -2.0f && fv > -2.0f && fu < (float)W + 1.0f && fv < (float)H + 1.0f) {
-              float ru = rintf(fu), rv = rintf(fv);
-              if (0.5f - fabsf(fu - ru) < 3.0e-4f || 0.5f - fabsf(fv - rv) < 3.0e-4f) {
-                const float inv_z = 1.0f / camz;
-                fu = px_ * inv_z + in.cx;
-                fv = py_ * inv_z + in.cy;
-                ru = rintf(fu);
-                rv = rintf(fv);
-              }
-              const int uu = (int)ru, vv = (int)rv;
-              if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H) {
-                pix[u][j] = vv * W + uu;
-                any = true;
-              }
+        for (int d = 0; d < D; ++d) {
+          const int zz = zb + d;  // the plane whose vector sits in slot d
+          if (mask[d]) {
+            const bool neg = update_vector(q[d], mask[d], one[d], F[d]);
+            vol[idx0 + (size_t)zz * plane_vec] = q[d];
+            if (neg) {
+              const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
+              // test first: after the first frames the bit is already set and no atomic is issued (a stale
+              // read only costs a redundant OR)
+              if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
+                __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
-        }
-        live[u] = live[u] && any;
-      }
-      // phase 2: depth gathers (pixel 0 stands in for "no pixel": harmless read, result ignored)
-      float F[U][4];
-      unsigned mask[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) F[u][j] = scaled[pix[u][j] < 0 ? 0 : pix[u][j]];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        mask[u] = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float Ds = F[u][j];
-          if (pix[u][j] >= 0 && Ds != 0.0f) {
-            // v_sqrt_f32 (1 ulp) moves sdf by < 1e-6 m: decide with it unless sdf is within 2e-6 m of -tau
-            // or sdf/tau is not clearly >= 1 (the truncation band, where the exact value is stored)
-            const float arg = gz2[u] + pn[j];
-            const float sdf_a = Ds - __builtin_amdgcn_sqrtf(arg);
-            if (sdf_a * vp.tau_inv > 1.0001f) {
-              F[u][j] = 1.0f;
-              mask[u] |= 1u << j;
-            } else if (sdf_a >= -vp.tau - 2.0e-6f) {
-              const float sdf = Ds - sqrtf(arg);
-              if (sdf >= -vp.tau) {
-                const float f = sdf * vp.tau_inv;
-                F[u][j] = f < 1.0f ? f : 1.0f;
-                mask[u] |= 1u << j;
-              }
-            }
+          // refill the slot with plane zz + D
+          const int zn = zz + D;
+          mask[d] = 0;
+          if (zn <= wh) {
+            classify_plane(zn, active && zn >= zl && zn <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, mask[d], one[d],
+                           F[d]);
+            if (mask[d]) q[d] = vol[idx0 + (size_t)zn * plane_vec];
           }
         }
-        if (!live[u]) mask[u] = 0;
       }
-      if (COUNT_ONLY) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) cnt += __popc(mask[u]);
-        continue;
-      }
-      // phase 3: volume vectors that hold at least one rewritten voxel
-      uint4 q[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (mask[u]) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
-      // phase 4: running mean, repack, store
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!mask[u]) continue;
-        unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-        bool neg = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (mask[u] & (1u << j)) {
-            const int tp = (int)(short)(w4[j] & 0xffffu);
-            const int wp = (int)(short)(w4[j] >> 16);
-            int wn = wp + 1;
-            wn = wn > HSK_MAX_WEIGHT ? HSK_MAX_WEIGHT : wn;
-            int fixed;
-            if (F[u][j] == 1.0f && tp == HSK_DIVISOR) {
-              fixed = HSK_DIVISOR;  // (1*W + 1) / (W + 1) == 1 exactly
-            } else {
-              float Fn;
-              if (wp == 0) {
-                Fn = F[u][j];  // (Fp*0 + F) / (0 + 1) == F exactly
-              } else {
-                const float Fp = (float)tp / 32767.0f;
-                const float Wp = (float)wp;
-                Fn = (Fp * Wp + F[u][j]) / (Wp + 1.0f);
-              }
-              fixed = (int)(Fn * 32767.0f);  // truncation toward zero
-              fixed = fixed > HSK_DIVISOR ? HSK_DIVISOR : fixed;
-              fixed = fixed < -HSK_DIVISOR ? -HSK_DIVISOR : fixed;
-            }
-            neg = neg || (fixed < 0);
-            w4[j] = ((unsigned)fixed & 0xffffu) | ((unsigned)wn << 16);
-          }
-        }
-        vol[idx0 + (size_t)(zb + u) * plane_vec] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-        if (neg) {
-          const int bit = ((((zb + u) >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
-          // test first: after the first frames the bit is already set and no atomic is issued (a stale read
-          // only costs a redundant OR)
-          if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
-            __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    } else {
+      for (int zz = wl + D; zz <= wh; ++zz) {
+        unsigned m, o;
+        float f[4];
+        classify_plane(zz, active && zz >= zl && zz <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, m, o, f);
+        cnt += __popc(m);
       }
     }
   }
@@ -287,19 +412,21 @@ __global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ vol, cons
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax) {
-  const int zchunks = vp.nzs >= 64 ? 8 : 1;
-  const int zchunk = (vp.nzs + zchunks - 1) / zchunks;
+                      const float* tmax, int2* zint) {
+  const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
+  const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
+  const int ncols = (vp.X / 4) * vp.Y;
+  hipLaunchKernelGGL(k_column_zrange, dim3((ncols + 255) / 256), dim3(256), 0, s, st, vp, W, H, in, zint);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
-  const size_t lds = (size_t)tw * th * sizeof(float);
+  const float2* dil = (const float2*)(tmax + 2 * tw * th);
   if (count_only)
-    hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, lds, s, (uint4*)vol, scaled, st, vp, W, H, in, zchunk, counter,
-                       flags, tmax, tw, th);
+    hipLaunchKernelGGL((k_integrate<true, INTEGRATE_U>), grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
+                       zchunk, counter, flags, dil, tw, th, zint);
   else
-    hipLaunchKernelGGL((k_integrate<false, INTEGRATE_U>), grid, block, lds, s, (uint4*)vol, scaled, st, vp, W, H, in, zchunk, counter,
-                       flags, tmax, tw, th);
+    hipLaunchKernelGGL((k_integrate<false, INTEGRATE_U>), grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
+                       zchunk, counter, flags, dil, tw, th, zint);
 }
 
 // rebuild the brick bitfield from a volume that was uploaded rather than integrated
