@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
+    ap.add_argument("--force-sharded", action="store_true", help="use the z-slab host + collectives even at 1 GPU (plumbing check)")
     args = ap.parse_args()
 
     import torch
@@ -80,9 +81,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     K, Wm = args.steps, args.warmup
     n = args.volume
@@ -92,9 +96,9 @@ def main():
     dev_frames = [torch.from_numpy(f.view(np.int16)).cuda(local_rank) for f in frames]
     torch.cuda.synchronize()
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from housescan_amd.sharded import ShardedKinfu
-        eng = ShardedKinfu(n, rank, world, local_rank, mode=args.mode, icp=args.icp)
+        eng = ShardedKinfu(n, rank, world, local_rank, mode=args.mode, icp=args.icp, force_collectives=args.force_sharded)
         step = eng.process_frame_dev
         trk = eng.tracker
     else:
@@ -140,7 +144,7 @@ def main():
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3)},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.force_sharded:
         # ---- roofline of the dominant kernel (integrate), HIP events on the library's own stream ----
         trk.set_profiling(True)
         trk.stage_ms(reset=True)

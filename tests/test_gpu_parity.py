@@ -274,3 +274,77 @@ def test_full_size_properties(hsk, synth_frames):
     nn = np.linalg.norm(nm[:, ~np.isnan(nm[0])], axis=0)
     assert np.abs(nn - 1).max() < 1e-5
     trk.close()
+
+
+def test_golden_vectors_gpu(hsk):
+    """HIP path vs the committed golden vectors (tests/golden/make_golden.py), no oracle involved"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kinfu_golden.npz"))
+    W, H, FX, CX, CY = 160, 120, 131.25, 79.75, 59.75
+    n = int(g["n"])
+    trk = hsk.KinfuTracker(hsk.default_config(n, width=W, height=H, fx=FX, fy=FX, cx=CX, cy=CY))
+    poses = []
+    for k in g["frames"]:
+        poses.append(trk.process_frame(hsk.synth_depth(hsk.synth_pose(int(k)), W, H, FX, FX, CX, CY))[0])
+    assert_same_bits(np.stack(poses), g["poses"], "golden poses")
+    assert_same_bits(trk.download_tsdf()[8:24, 8:24, 8:24], g["tsdf_crop"], "golden tsdf crop")
+    assert_same_bits(trk.download_map(2, 0)[:, 40:70, 60:100], g["vmap_crop"], "golden vmap crop")
+    assert_same_bits(trk.download_map(3, 0)[:, 40:70, 60:100], g["nmap_crop"], "golden nmap crop")
+    trk.preprocess(hsk.synth_depth(hsk.synth_pose(4), W, H, FX, FX, CX, CY))
+    assert_same_bits(trk.icp_accumulate(0, poses[-1]), g["icp27"], "golden ICP sums")
+    trk.close()
+
+
+def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
+    """two z-slab contexts on one GPU driven through the hsk_mgpu_* building blocks, composited on the host the
+    way the collectives do (MIN of keys, SUM of bit patterns): bit-identical to the single-volume context"""
+    import ctypes as C
+    import torch
+    from housescan_amd.sharded import HipSlabEngine, slab_halo, slab_range
+    n, world = 64, 2
+    dev = torch.device("cuda", 0)
+    ref = hsk.KinfuTracker(n=n, use_graph=0)
+    engines = []
+    for r in range(world):
+        cfg = hsk.default_config(n, use_graph=0)
+        cfg.own_z0, cfg.own_z1 = slab_range(r, world, n)
+        cfg.halo = slab_halo(max(0.03, 2.1 * 3.0 / n), 3.0 / n)
+        engines.append(HipSlabEngine(hsk.KinfuTracker(cfg), torch, dev))
+    for k in range(4):
+        _, depth = synth_frames(k)
+        pref, okref = ref.process_frame(depth)
+        d_dev = torch.from_numpy(depth.view(np.int16)).to(dev)
+        first = engines[0].frame_index() == 0
+        for e in engines:
+            e.frame_begin(d_dev)
+        if first:
+            outs = [e.frame_end(None, None) for e in engines]
+        else:
+            for level in (2, 1, 0):
+                for _ in range([10, 5, 4][level]):
+                    # "allreduce" mode: each engine sums half of the rows, the sums are added exactly
+                    h = 480 >> level
+                    parts = [e.icp_accumulate(level, r * h // 2, (r + 1) * h // 2).clone() for r, e in enumerate(engines)]
+                    tot = parts[0] + parts[1]
+                    for e in engines:
+                        e.icp_update(tot)
+            for e in engines:
+                e.integrate()
+            keys = [e.raycast_local().clone() for e in engines]
+            kmin = torch.minimum(keys[0], keys[1])
+            bits = [e.raycast_resolve(kmin).clone() for e in engines]
+            bsum = bits[0] + bits[1]
+            outs = [e.frame_end(kmin, bsum) for e in engines]
+        for p, ok in outs:
+            assert ok == okref
+            assert_same_bits(p, pref, f"slab pose frame {k}")
+    full = ref.download_tsdf()
+    for r, e in enumerate(engines):
+        z0, z1 = slab_range(r, world, n)
+        got = e.t.download_tsdf()
+        assert_same_bits(got[z0 - e.t.stored_z0:z1 - e.t.stored_z0], full[z0:z1], f"slab {r} owned planes")
+        for level in range(3):
+            assert_same_bits(e.t.download_map(2, level), ref.download_map(2, level), f"slab {r} model vmap {level}")
+            assert_same_bits(e.t.download_map(3, level), ref.download_map(3, level), f"slab {r} model nmap {level}")
+        e.t.close()
+    ref.close()

@@ -1,0 +1,57 @@
+"""Host-side pieces that need no GPU: synthetic stream, product writers on the file seam HouseScan reads."""
+import os
+
+import numpy as np
+
+
+def test_synth_stream_is_deterministic_and_physical(hsk):
+    p0 = hsk.synth_pose(0)
+    assert np.allclose(p0, [[1, 0, 0, 1.5], [0, 1, 0, 1.5], [0, 0, 1, -0.3], [0, 0, 0, 1]], atol=1e-7)
+    d = hsk.synth_depth(p0)
+    assert d.shape == (480, 640) and d.dtype == np.uint16
+    assert np.array_equal(d, hsk.synth_depth(p0))
+    assert d[239, 319] == 3100 and d.min() == 1500 and (d > 0).all()
+    # side wall x = 2.8 seen at the right image edge: z = (2.8 - 1.5) / ((639 - 319.5) / 525)
+    assert abs(int(d[239, 639]) - round(1000 * 1.3 / ((639 - 319.5) / 525))) <= 1
+    # trajectory: <= 7 mm and <= 0.6 deg per frame, rotation orthonormal
+    for k in (1, 37, 150, 299):
+        a, b = hsk.synth_pose(k), hsk.synth_pose(k + 1)
+        assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 0.007
+        assert np.allclose(a[:3, :3] @ a[:3, :3].T, np.eye(3), atol=1e-6)
+        ang = np.degrees(np.arccos(np.clip((np.trace(a[:3, :3].T @ b[:3, :3]) - 1) / 2, -1, 1)))
+        assert ang < 0.6
+    assert np.allclose(hsk.synth_pose(300), hsk.synth_pose(0), atol=1e-6)   # period 300
+
+
+def test_pcd_writer_and_downsample(tmp_path, hsk):
+    """cloud_downsampled.pcd / cloud_bin.pcd in the layout HouseScan's loader (PCD.loadXyz) expects"""
+    import ctypes as C
+    lib = hsk._lib.load()
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(0, 1, size=(5000, 3)).astype(np.float32)
+    path = str(tmp_path / "cloud_bin.pcd")
+    assert lib.hsk_write_pcd_xyz(path.encode(), pts.ctypes.data, len(pts)) == 0
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"DATA binary\n", 1)
+    h = head.decode()
+    assert "FIELDS x y z" in h and "SIZE 4 4 4" in h and "TYPE F F F" in h and f"POINTS {len(pts)}" in h
+    assert np.array_equal(np.frombuffer(body, np.float32).reshape(-1, 3), pts)
+    out = np.empty((5000, 3), np.float32)
+    n = C.c_size_t()
+    assert lib.hsk_voxel_downsample(pts.ctypes.data, len(pts), C.c_float(0.25), out.ctypes.data, 5000, C.byref(n)) == 0
+    assert n.value == 64     # 4^3 occupied leaves
+    cells = np.floor(out[:n.value] / 0.25).astype(int)
+    assert len({tuple(c) for c in cells}) == 64
+    ref = pts[(np.floor(pts / 0.25).astype(int) == cells[0]).all(axis=1)].astype(np.float64).mean(axis=0)
+    assert np.allclose(out[0], ref, atol=1e-6)
+
+
+def test_oracle_is_not_reachable_from_the_product(hsk):
+    """the product package must never import or link the oracle (it is test infrastructure)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "housescan_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert "kinfu_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, (dp, f)
