@@ -53,6 +53,18 @@ def cpu_baseline(volume, sample_frames, hsk):
     }
 
 
+def pmc_traffic(volume):
+    """HBM bytes per integrate launch from the committed PMC passes (tools/pmc.sh: separate --pmc runs of this
+    same command; FETCH_SIZE in KiB doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE in KiB)."""
+    path = os.path.join(ROOT, "profiles", "latest_integrate_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t["bytes_per_launch"] if int(t.get("volume", 0)) == int(volume) else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +76,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
+    ap.add_argument("--host-frames", action="store_true", help="also time hsk_process_frame with HOST depth buffers (PCIe-inclusive)")
     ap.add_argument("--force-sharded", action="store_true", help="use the z-slab host + collectives even at 1 GPU (plumbing check)")
     args = ap.parse_args()
 
@@ -161,8 +174,9 @@ def main():
         achieved = alg_bytes / t_int / 1e9
         sweep = 8.0 * n ** 3 / t_int / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_integrate<false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bound": "hbm", "kernel": "k_integrate<false> (+ k_column_zrange pre-pass, same event pair)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n),
             "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
             "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
             "sweep_GBps_upper_bound_bytes_not_algorithmic": round(sweep, 1),
@@ -172,6 +186,13 @@ def main():
         out["stage_us"] = {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1),
                            "integrate": round(ms[2] / nf * 1e3, 1), "raycast": round(ms[3] / nf * 1e3, 1),
                            "note": "eager launches with HIP events between stages (second pass of %d frames)" % nf}
+        if args.host_frames:
+            _, hf = make_frames(hsk, total + prof_frames, 60)
+            trk.synchronize()
+            t1 = time.perf_counter()
+            for f in hf:
+                trk.process_frame(f)
+            out["pcie_inclusive_fps"] = round(len(hf) / (time.perf_counter() - t1), 2)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_frames, hsk)
     if rank == 0:

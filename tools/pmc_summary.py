@@ -19,3 +19,16 @@ for k, d in sorted(acc.items()):
     print(f"== {k}  (dispatches per pass ~{n})")
     for c, v in sorted(d.items()):
         print(f"   {c:28s} mean={sum(v)/len(v):16.1f}  n={len(v)}")
+
+# traffic file for bench.py's roofline.traffic (integrate kernel)
+import json, os
+for k, d in acc.items():
+    if k.startswith("void k_integrate<false") and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 1024 * 2   # gfx950: FETCH_SIZE reads 1/2 of wide streams
+        write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024
+        out = {"kernel": k, "volume": int(os.environ.get("HSK_PMC_VOLUME", "512")), "bytes_per_launch": int(fetch + write),
+               "fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/pmc.sh"}
+        with open(os.path.join(root, "integrate_traffic.json"), "w") as f:
+            json.dump(out, f)
+        print("traffic:", out)
