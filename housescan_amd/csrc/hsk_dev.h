@@ -42,7 +42,7 @@ struct VolParams {
 // words of the brick bitfield; the brick edge is chosen so that it fits 32 KiB of LDS
 static inline int hsk_flag_words(const VolParams& vp) {
   const long bits = (long)(vp.X >> vp.bshift) * (vp.Y >> vp.bshift) * ((vp.nzs + (1 << vp.bshift) - 1) >> vp.bshift);
-  return (int)((bits + 31) / 32);
+  return (int)(((bits + 31) / 32 + 3) / 4 * 4);  // multiple of 4 words: staged into LDS with 16-B loads
 }
 
 #define HSK_NANF (__builtin_nanf(""))

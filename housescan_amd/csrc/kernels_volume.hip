@@ -518,14 +518,33 @@ static __device__ __forceinline__ int vox_fast(float p, float cell, float inv_ce
   return (int)f;
 }
 
-__global__ __launch_bounds__(256) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
+#define RC_BLOCK 512    // 8 waves share one staged copy of the 32 KiB bitfield: all 4800 waves of a 640x480 frame are
+                        // resident at once (with 256-thread blocks only 4096 fit and a second round formed the tail)
+#define RC_STAGE_MAX 4  // 16-B loads per thread: 32 KiB / (512 x 16 B)
+__global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
                                                  VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
                                                  float* __restrict__ nmap, int* __restrict__ keys,
                                                  const unsigned* __restrict__ flags, int flag_words) {
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];
-  for (int w = threadIdx.x; w < flag_words; w += blockDim.x) lflags[w] = flags[w];
+  {
+    // 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging loop cost 9 us per
+    // block: profiles/r01/raycast_analysis.md)
+    const int nq = flag_words >> 2;  // flag_words is a multiple of 4 (hsk_flag_words)
+    uint4 tmp[RC_STAGE_MAX];
+#pragma unroll
+    for (int i = 0; i < RC_STAGE_MAX; ++i) {
+      const int q = threadIdx.x + i * RC_BLOCK;
+      if (q < nq) tmp[i] = ((const uint4*)flags)[q];
+    }
+#pragma unroll
+    for (int i = 0; i < RC_STAGE_MAX; ++i) {
+      const int q = threadIdx.x + i * RC_BLOCK;
+      if (q < nq) ((uint4*)lflags)[q] = tmp[i];
+    }
+    for (int q = threadIdx.x + RC_STAGE_MAX * RC_BLOCK; q < nq; q += RC_BLOCK) ((uint4*)lflags)[q] = ((const uint4*)flags)[q];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -665,8 +684,8 @@ __global__ __launch_bounds__(256) void k_raycast(const short2* __restrict__ vol,
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
                     float* vmap, float* nmap, int* keys, const unsigned* flags) {
   const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
-  dim3 block(256);
-  dim3 grid((tiles + 3) / 4);
+  dim3 block(RC_BLOCK);
+  dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
   const int words = hsk_flag_words(vp);
   hipLaunchKernelGGL(k_raycast, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
                      keys, flags, words);
