@@ -35,5 +35,9 @@ void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, doubl
 void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st);
 void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st);
 void launch_begin_frame(hipStream_t s, TrackState* st);
+size_t icp_pose_bytes();
+void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
+                      const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
+                      void* pose_buf, double* part_a, double* part_b);
 bool host_solve6(const double* in27, float* x6);
 void host_pose_update(float* R, float* t, const float* x6);

@@ -37,6 +37,8 @@ struct hsk_ctx {
   TrackState* d_st = nullptr;
   TrackState* h_st = nullptr;  // pinned
   double* d_partials = nullptr;
+  double* d_partials2 = nullptr;  // ping-pong partner of d_partials (fused ICP iterations)
+  void* d_icp_pose = nullptr;     // two IcpPose slots
   double* d_sums = nullptr;
   float* d_ws = nullptr;
   float* d_wc = nullptr;
@@ -159,6 +161,8 @@ static void free_all(hsk_ctx* k) {
   }
   F(k->d_st);
   F(k->d_partials);
+  F(k->d_partials2);
+  F(k->d_icp_pose);
   F(k->d_sums);
   F(k->d_ws);
   F(k->d_wc);
@@ -285,6 +289,8 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipHostMalloc((void**)&k->h_stage, P0 * 2, hipHostMallocDefault));
   const int nb0 = icp_num_blocks(c->width, c->height);
   CK(hipMalloc((void**)&k->d_partials, (size_t)nb0 * 27 * sizeof(double)));
+  CK(hipMalloc((void**)&k->d_partials2, (size_t)nb0 * 27 * sizeof(double)));
+  CK(hipMalloc(&k->d_icp_pose, icp_pose_bytes()));
   CK(hipMalloc((void**)&k->d_sums, 27 * sizeof(double)));
   CK(hipMalloc((void**)&k->d_ws, 169 * 4));
   CK(hipMalloc((void**)&k->d_wc, 512 * 4));
@@ -355,16 +361,8 @@ static void enqueue_preprocess(hsk_ctx* k) {
 }
 
 static void enqueue_icp(hsk_ctx* k) {
-  hipStream_t s = k->stream;
-  for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
-    const int nb = icp_num_blocks(k->lv[l].W, k->lv[l].H);
-    for (int it = 0; it < k->cfg.icp_iters[l]; ++it) {
-      launch_icp_accumulate(s, k->d_vcur[l], k->d_ncur[l], k->d_vmod[l], k->d_nmod[l], k->lv[l].W, k->lv[l].H,
-                            k->lv[l].in, k->d_st, k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, 0, k->lv[l].H,
-                            k->d_partials);
-      launch_icp_reduce_update(s, k->d_partials, nb, k->d_st);
-    }
-  }
+  launch_icp_fused(k->stream, k->d_vcur, k->d_ncur, k->d_vmod, k->d_nmod, k->lv, k->cfg.icp_iters, k->d_st,
+                   k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2);
 }
 
 static void enqueue_integrate(hsk_ctx* k) {

@@ -241,8 +241,16 @@ void launch_resize_maps(hipStream_t s, const float* vs, const float* ns, int W, 
 // ------------------------------------------------------------------------------------------------------
 // ICP_PX pixels per lane (template): loads batched so that the dependent chain is 2 memory round trips
 #define ICP_BLOCK 256
+#ifndef ICP_PX_FINE
+#define ICP_PX_FINE 4  // pixels per lane at the finest level (1 at the coarse levels)
+#endif
 
-static __device__ __forceinline__ double quant26(double x) { return rint(x * 67108864.0) * (1.0 / 67108864.0); }
+// Exact accumulation.  The spec sums quant26(p) = rint(p * 2^26) * 2^-26 over pixels, p the binary64 product of
+// two binary32 row entries.  Scaling one factor by 2^26 first is exact (power of two), so the kernel adds the
+// integer-valued rint(a' * b) and leaves the common 2^-26 to the very end: every partial sum is an integer below
+// 2^53, hence exact, hence independent of the order of the additions (wave tree, LDS, blocks, GPUs).
+#define ICP_SCALE 67108864.0          // 2^26
+#define ICP_UNSCALE (1.0 / 67108864.0)
 
 // DPP move of a 64-bit value (two 32-bit halves)
 template <int CTRL>
@@ -252,7 +260,7 @@ static __device__ __forceinline__ double dpp_mov_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-// wave64 sum, result valid in every lane of... lane 0 (and others); any order is fine: the addends are exact.
+// wave64 sum of one value (any order is fine: the addends are exact integers)
 static __device__ __forceinline__ double wave_sum_f64(double v) {
   v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -263,6 +271,176 @@ static __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// wave64 sums of 27 values at once by a halving butterfly: at every step the two partner lanes split the
+// remaining values between them, so 16 + 8 + 4 + 2 + 1 + 1 exchanges replace 27 x 6.  On return lane l holds the
+// wave total of value (l >> 1) & 31 for l < 64 (values 27..31 are padding); lanes 2k and 2k+1 both hold value k.
+static __device__ __forceinline__ double wave_sum27(const double* acc, int lane) {
+  double v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = i < 27 ? acc[i] : 0.0;
+  // step with partner lane ^ 32: lanes < 32 keep values 0..15, lanes >= 32 keep 16..31
+  {
+    const bool up = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double keep = up ? v[i + 16] : v[i], send = up ? v[i] : v[i + 16];
+      v[i] = keep + __shfl_xor(send, 32, 64);
+    }
+  }
+  {
+    const bool up = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+      v[i] = keep + __shfl_xor(send, 16, 64);
+    }
+  }
+  {
+    const bool up = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+      v[i] = keep + __shfl_xor(send, 8, 64);
+    }
+  }
+  {
+    const bool up = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+      v[i] = keep + __shfl_xor(send, 4, 64);
+    }
+  }
+  {
+    const bool up = lane & 2;
+    const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + __shfl_xor(send, 2, 64);
+  }
+  v[0] += __shfl_xor(v[0], 1, 64);
+  return v[0];
+}
+// value index held by `lane` after wave_sum27: bit 5 -> +16, bit 4 -> +8, bit 3 -> +4, bit 2 -> +2, bit 1 -> +1
+static __device__ __forceinline__ int wave_sum27_index(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
+// Current-level inputs of one lane (ICP_PX pixels): loaded first, so that the loads overlap whatever comes before
+// the pose is known (the solve of the previous iteration in the fused kernel).
+template <int ICP_PX>
+struct IcpLaneIn {
+  float nc[ICP_PX][3], vc[ICP_PX][3];
+  bool ok[ICP_PX];
+};
+
+template <int ICP_PX>
+static __device__ __forceinline__ void icp_load_current(const float* __restrict__ vcur, const float* __restrict__ ncur,
+                                                        int W, int H, int row0, int row1, IcpLaneIn<ICP_PX>& L) {
+  const size_t P = (size_t)W * H;
+  const int npx = (row1 - row0) * W;
+  const int base = blockIdx.x * (ICP_BLOCK * ICP_PX) + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < ICP_PX; ++q) {
+    const int li = base + q * ICP_BLOCK;
+    L.ok[q] = li < npx;
+    const size_t i = (size_t)row0 * W + (L.ok[q] ? li : 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      L.nc[q][c] = ncur[c * P + i];
+      L.vc[q][c] = vcur[c * P + i];
+    }
+  }
+}
+
+// Per pixel: transform, project into the previous camera, gate, build the 7-vector row, add the 27 scaled products.
+template <int ICP_PX>
+static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& L, const float* __restrict__ vprev,
+                                                             const float* __restrict__ nprev, int W, int H, const Intr& in,
+                                                             const float* R, const float* tt, const float* Rp,
+                                                             const float* tp, float dist_thresh, float angle_thresh,
+                                                             double* acc) {
+  const size_t P = (size_t)W * H;
+  const float t0 = tt[0], t1 = tt[1], t2 = tt[2];
+  const float p0 = tp[0], p1 = tp[1], p2 = tp[2];
+  auto& nc = L.nc;
+  auto& vc = L.vc;
+  auto& ok = L.ok;
+  // phase B: transform + project, then all model-map gathers in flight together
+  float g[ICP_PX][3], np_[ICP_PX][3], vp_[ICP_PX][3];
+#pragma unroll
+  for (int q = 0; q < ICP_PX; ++q) {
+    ok[q] = ok[q] && !hsk_isnan(nc[q][0]);
+    g[q][0] = ((R[0] * vc[q][0] + R[1] * vc[q][1]) + R[2] * vc[q][2]) + t0;
+    g[q][1] = ((R[3] * vc[q][0] + R[4] * vc[q][1]) + R[5] * vc[q][2]) + t1;
+    g[q][2] = ((R[6] * vc[q][0] + R[7] * vc[q][1]) + R[8] * vc[q][2]) + t2;
+    const float dx = g[q][0] - p0, dy = g[q][1] - p1, dz = g[q][2] - p2;
+    const float cpx = (Rp[0] * dx + Rp[3] * dy) + Rp[6] * dz;  // Rprev^T * d
+    const float cpy = (Rp[1] * dx + Rp[4] * dy) + Rp[7] * dz;
+    const float cpz = (Rp[2] * dx + Rp[5] * dy) + Rp[8] * dz;
+    ok[q] = ok[q] && (cpz > 0.0f);
+    const float fu = (cpx * in.fx) / cpz + in.cx;
+    const float fv = (cpy * in.fy) / cpz + in.cy;
+    int u = 0, v = 0;
+    ok[q] = ok[q] && hsk_rint_guard(fu, u) && hsk_rint_guard(fv, v);
+    ok[q] = ok[q] && u >= 0 && v >= 0 && u < W && v < H;
+    const size_t j = ok[q] ? (size_t)v * W + u : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      np_[q][c] = nprev[c * P + j];
+      vp_[q][c] = vprev[c * P + j];
+    }
+  }
+  // phase C: gates, the 7-vector row, 27 scaled products
+#pragma unroll
+  for (int q = 0; q < ICP_PX; ++q) {
+    bool valid = ok[q] && !hsk_isnan(np_[q][0]);
+    const float ex = vp_[q][0] - g[q][0], ey = vp_[q][1] - g[q][1], ez = vp_[q][2] - g[q][2];
+    const float dist = sqrtf(hsk_dot3(ex, ey, ez, ex, ey, ez));
+    valid = valid && (dist <= dist_thresh);
+    const float ngx = (R[0] * nc[q][0] + R[1] * nc[q][1]) + R[2] * nc[q][2];
+    const float ngy = (R[3] * nc[q][0] + R[4] * nc[q][1]) + R[5] * nc[q][2];
+    const float ngz = (R[6] * nc[q][0] + R[7] * nc[q][1]) + R[8] * nc[q][2];
+    const float c0 = ngy * np_[q][2] - ngz * np_[q][1];
+    const float c1 = ngz * np_[q][0] - ngx * np_[q][2];
+    const float c2 = ngx * np_[q][1] - ngy * np_[q][0];
+    const float sine = sqrtf(hsk_dot3(c0, c1, c2, c0, c1, c2));
+    valid = valid && (sine < angle_thresh);
+    if (valid) {
+      float row[7];
+      row[0] = g[q][1] * np_[q][2] - g[q][2] * np_[q][1];  // s x n
+      row[1] = g[q][2] * np_[q][0] - g[q][0] * np_[q][2];
+      row[2] = g[q][0] * np_[q][1] - g[q][1] * np_[q][0];
+      row[3] = np_[q][0];
+      row[4] = np_[q][1];
+      row[5] = np_[q][2];
+      row[6] = hsk_dot3(np_[q][0], np_[q][1], np_[q][2], ex, ey, ez);
+      double rs[6], rd[7];
+#pragma unroll
+      for (int a = 0; a < 7; ++a) rd[a] = (double)row[a];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) rs[a] = rd[a] * ICP_SCALE;
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 7; ++b) acc[k++] += rint(rs[a] * rd[b]);
+    }
+  }
+}
+
+// block reduction of the per-lane accumulators -> 27 (unscaled) sums in out[0..26], valid after the barrier
+static __device__ __forceinline__ void icp_block_sums(const double* acc, double (*sh)[32], double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double v = wave_sum27(acc, lane);
+  if ((lane & 1) == 0) sh[wave][wave_sum27_index(lane)] = v;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < ICP_BLOCK / 64; ++w) r += sh[w][threadIdx.x];
+    out[threadIdx.x] = r * ICP_UNSCALE;
+  }
+}
+
 template <int ICP_PX>
 __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __restrict__ vcur,
                                                               const float* __restrict__ ncur,
@@ -271,115 +449,28 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __res
                                                               const TrackState* __restrict__ st, float dist_thresh,
                                                               float angle_thresh, int row0, int row1,
                                                               double* __restrict__ partials) {
-  __shared__ double sh[ICP_BLOCK / 64][27];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ double sh[ICP_BLOCK / 64][32];
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  const size_t P = (size_t)W * H;
-  const int npx = (row1 - row0) * W;
   if (!st->lost) {
-    const float* R = st->R;
-    const float* Rp = st->Rp;
-    const float t0 = st->t[0], t1 = st->t[1], t2 = st->t[2];
-    const float p0 = st->tp[0], p1 = st->tp[1], p2 = st->tp[2];
-    const int base = blockIdx.x * (ICP_BLOCK * ICP_PX) + threadIdx.x;
-    // phase A: all current-map loads in flight together
-    float nc[ICP_PX][3], vc[ICP_PX][3];
-    bool ok[ICP_PX];
-#pragma unroll
-    for (int q = 0; q < ICP_PX; ++q) {
-      const int li = base + q * ICP_BLOCK;
-      ok[q] = li < npx;
-      const size_t i = (size_t)row0 * W + (ok[q] ? li : 0);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        nc[q][c] = ncur[c * P + i];
-        vc[q][c] = vcur[c * P + i];
-      }
-    }
-    // phase B: transform + project, then all model-map gathers in flight together
-    float g[ICP_PX][3], np_[ICP_PX][3], vp_[ICP_PX][3];
-#pragma unroll
-    for (int q = 0; q < ICP_PX; ++q) {
-      ok[q] = ok[q] && !hsk_isnan(nc[q][0]);
-      g[q][0] = ((R[0] * vc[q][0] + R[1] * vc[q][1]) + R[2] * vc[q][2]) + t0;
-      g[q][1] = ((R[3] * vc[q][0] + R[4] * vc[q][1]) + R[5] * vc[q][2]) + t1;
-      g[q][2] = ((R[6] * vc[q][0] + R[7] * vc[q][1]) + R[8] * vc[q][2]) + t2;
-      const float dx = g[q][0] - p0, dy = g[q][1] - p1, dz = g[q][2] - p2;
-      const float cpx = (Rp[0] * dx + Rp[3] * dy) + Rp[6] * dz;  // Rprev^T * d
-      const float cpy = (Rp[1] * dx + Rp[4] * dy) + Rp[7] * dz;
-      const float cpz = (Rp[2] * dx + Rp[5] * dy) + Rp[8] * dz;
-      ok[q] = ok[q] && (cpz > 0.0f);
-      const float fu = (cpx * in.fx) / cpz + in.cx;
-      const float fv = (cpy * in.fy) / cpz + in.cy;
-      int u = 0, v = 0;
-      ok[q] = ok[q] && hsk_rint_guard(fu, u) && hsk_rint_guard(fv, v);
-      ok[q] = ok[q] && u >= 0 && v >= 0 && u < W && v < H;
-      const size_t j = ok[q] ? (size_t)v * W + u : 0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        np_[q][c] = nprev[c * P + j];
-        vp_[q][c] = vprev[c * P + j];
-      }
-    }
-    // phase C: gates, the 7-vector row, 27 snapped products
-#pragma unroll
-    for (int q = 0; q < ICP_PX; ++q) {
-      bool valid = ok[q] && !hsk_isnan(np_[q][0]);
-      const float ex = vp_[q][0] - g[q][0], ey = vp_[q][1] - g[q][1], ez = vp_[q][2] - g[q][2];
-      const float dist = sqrtf(hsk_dot3(ex, ey, ez, ex, ey, ez));
-      valid = valid && (dist <= dist_thresh);
-      const float ngx = (R[0] * nc[q][0] + R[1] * nc[q][1]) + R[2] * nc[q][2];
-      const float ngy = (R[3] * nc[q][0] + R[4] * nc[q][1]) + R[5] * nc[q][2];
-      const float ngz = (R[6] * nc[q][0] + R[7] * nc[q][1]) + R[8] * nc[q][2];
-      const float c0 = ngy * np_[q][2] - ngz * np_[q][1];
-      const float c1 = ngz * np_[q][0] - ngx * np_[q][2];
-      const float c2 = ngx * np_[q][1] - ngy * np_[q][0];
-      const float sine = sqrtf(hsk_dot3(c0, c1, c2, c0, c1, c2));
-      valid = valid && (sine < angle_thresh);
-      if (valid) {
-        float row[7];
-        row[0] = g[q][1] * np_[q][2] - g[q][2] * np_[q][1];  // s x n
-        row[1] = g[q][2] * np_[q][0] - g[q][0] * np_[q][2];
-        row[2] = g[q][0] * np_[q][1] - g[q][1] * np_[q][0];
-        row[3] = np_[q][0];
-        row[4] = np_[q][1];
-        row[5] = np_[q][2];
-        row[6] = hsk_dot3(np_[q][0], np_[q][1], np_[q][2], ex, ey, ez);
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = a; b < 7; ++b) acc[k++] += quant26((double)row[a] * (double)row[b]);
-      }
-    }
+    IcpLaneIn<ICP_PX> L;
+    icp_load_current<ICP_PX>(vcur, ncur, W, H, row0, row1, L);
+    icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, st->R, st->t, st->Rp, st->tp, dist_thresh, angle_thresh, acc);
   }
-  // wave64 reduction (exact: order-independent by construction), then across the 4 waves through LDS
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const double v = wave_sum_f64(acc[k]);
-    if (lane == 0) sh[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 27) {
-    double v = 0.0;
-#pragma unroll
-    for (int w = 0; w < ICP_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * 27 + threadIdx.x] = v;
-  }
+  icp_block_sums(acc, sh, partials + (size_t)blockIdx.x * 27);
 }
 
-// fine level: 4 pixels per lane (300 blocks at 640x480); coarse levels: 1 pixel per lane, shorter serial chain
-static inline int icp_px(int W) { return W >= 512 ? 4 : 1; }
+// fine level: ICP_PX_FINE pixels per lane; coarse levels: 1 pixel per lane, shorter serial chain
+static inline int icp_px(int W) { return W >= 512 ? ICP_PX_FINE : 1; }
 int icp_num_blocks(int W, int rows) { return (W * rows + ICP_BLOCK * icp_px(W) - 1) / (ICP_BLOCK * icp_px(W)); }
 
 void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
                            int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,
                            int row1, double* partials) {
   const int nb = icp_num_blocks(W, row1 - row0);
-  if (icp_px(W) == 4)
-    hipLaunchKernelGGL(k_icp_accumulate<4>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
+  if (icp_px(W) == ICP_PX_FINE)
+    hipLaunchKernelGGL(k_icp_accumulate<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
                        dist_thresh, angle_thresh, row0, row1, partials);
   else
     hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
@@ -387,7 +478,7 @@ void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, 
 }
 
 // reduce per-block partials -> 27 sums (one block of 256 threads)
-#define ICP_RED_UNROLL 40  // 300 blocks / 8 slices, rounded up: one trip at 640x480
+#define ICP_RED_UNROLL 40  // partial rows / 8 slices per trip (600 rows at 640x480 with 2 px per lane: 2 trips)
 static __device__ __forceinline__ void block_reduce27(const double* __restrict__ partials, int nblocks,
                                                       double (*sh)[32], double* tot) {
   // thread (slice, k): k = tid & 31 is the sum index (27 used), slice = tid >> 5 takes every 8th block row;
@@ -605,6 +696,121 @@ __global__ __launch_bounds__(256) void k_icp_reduce_update(const double* __restr
 }
 void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st) {
   hipLaunchKernelGGL(k_icp_reduce_update, dim3(1), dim3(256), 0, s, partials, nblocks, st);
+}
+
+// ---- fused ICP iteration (single-device path) -------------------------------------------------------------
+// Iteration i: every block first reduces the partials of iteration i-1 and solves for the pose increment -- the
+// same deterministic arithmetic in every block, so all blocks agree -- then accumulates its pixels with the new
+// pose.  One launch per iteration instead of two; the current-map loads are issued before the prologue so their
+// latency overlaps the solve.  Poses ping-pong through two IcpPose slots (block 0 publishes the new one).
+struct IcpPose {
+  float R[9], t[3];
+  int lost, n_iter, pad[2];
+};
+
+static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p) {
+  if (p.lost) return;
+  double s[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) s[k] = tot[k];
+  float x6[6];
+  if (!hsk_solve6(s, x6)) {
+    p.lost = 1;
+    return;
+  }
+  hsk_pose_update(p.R, p.t, x6);
+  p.n_iter += 1;
+}
+
+template <int ICP_PX>
+__global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict__ vcur, const float* __restrict__ ncur,
+                                                        const float* __restrict__ vprev, const float* __restrict__ nprev,
+                                                        int W, int H, Intr in, const TrackState* __restrict__ st,
+                                                        float dist_thresh, float angle_thresh,
+                                                        const IcpPose* __restrict__ pose_in, IcpPose* __restrict__ pose_out,
+                                                        const double* __restrict__ part_prev, int nb_prev,
+                                                        double* __restrict__ part_out) {
+  __shared__ double sh[8][32];
+  __shared__ double tot[27];
+  __shared__ IcpPose sp;
+  IcpLaneIn<ICP_PX> L;
+  icp_load_current<ICP_PX>(vcur, ncur, W, H, 0, H, L);  // independent of the pose: in flight during the prologue
+  if (nb_prev > 0) block_reduce27(part_prev, nb_prev, sh, tot);
+  if (threadIdx.x == 0) {
+    IcpPose p = *pose_in;
+    if (nb_prev > 0) icp_solve_step(tot, p);
+    sp = p;
+    if (blockIdx.x == 0) *pose_out = p;
+  }
+  __syncthreads();
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  if (!sp.lost)
+    icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, sp.R, sp.t, st->Rp, st->tp, dist_thresh, angle_thresh, acc);
+  __syncthreads();  // sh is reused by the block reduction below
+  icp_block_sums(acc, (double (*)[32])sh, part_out + (size_t)blockIdx.x * 27);
+}
+
+// after the last iteration: final solve, pose and lost flag into the tracker state
+__global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ pose_in, const double* __restrict__ part_prev,
+                                                   int nb_prev, TrackState* __restrict__ st) {
+  __shared__ double sh[8][32];
+  __shared__ double tot[27];
+  block_reduce27(part_prev, nb_prev, sh, tot);
+  if (threadIdx.x == 0) {
+    IcpPose p = *pose_in;
+    icp_solve_step(tot, p);
+    for (int k = 0; k < 27; ++k) st->sums[k] = tot[k];
+    if (p.lost) {
+      st->lost = 1;
+    } else {
+      for (int i = 0; i < 9; ++i) st->R[i] = p.R[i];
+      for (int i = 0; i < 3; ++i) st->t[i] = p.t[i];
+    }
+    st->n_iter = p.n_iter;
+  }
+}
+
+// seeds the pose ping-pong from the tracker state (after k_begin_frame)
+__global__ void k_icp_seed(const TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
+  if (threadIdx.x != 0) return;
+  IcpPose p;
+  for (int i = 0; i < 9; ++i) p.R[i] = st->R[i];
+  for (int i = 0; i < 3; ++i) p.t[i] = st->t[i];
+  p.lost = st->lost;
+  p.n_iter = 0;
+  p.pad[0] = p.pad[1] = 0;
+  *pose0 = p;
+}
+
+size_t icp_pose_bytes() { return 2 * sizeof(IcpPose); }
+
+// enqueue the whole ICP of one frame: levels coarse -> fine, iters[l] iterations each
+void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
+                      const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
+                      void* pose_buf, double* part_a, double* part_b) {
+  IcpPose* pb = (IcpPose*)pose_buf;
+  double* part[2] = {part_a, part_b};
+  hipLaunchKernelGGL(k_icp_seed, dim3(1), dim3(64), 0, s, st, pb);
+  int i = 0, nb_prev = 0;
+  for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
+    const int W = lv[l].W, H = lv[l].H;
+    const int nb = icp_num_blocks(W, H);
+    for (int it = 0; it < iters[l]; ++it, ++i) {
+      const double* pp = part[(i + 1) & 1];
+      if (icp_px(W) == ICP_PX_FINE)
+        hipLaunchKernelGGL(k_icp_iter<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
+                           H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), pp, nb_prev,
+                           part[i & 1]);
+      else
+        hipLaunchKernelGGL(k_icp_iter<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W, H,
+                           lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), pp, nb_prev,
+                           part[i & 1]);
+      nb_prev = nb;
+    }
+  }
+  if (i > 0) hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(256), 0, s, pb + (i & 1), part[(i + 1) & 1], nb_prev, st);
 }
 
 // start of a tracked frame: previous pose <- current pose, clear the lost flag
