@@ -19,14 +19,15 @@ void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigne
 
 // image
 void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
-                            uint16_t* dst, float* scaled);
+                            uint16_t* dst, float* scaled, float* tiles);
 void launch_scale_depth(hipStream_t s, const uint16_t* src, int W, int H, Intr in, float* scaled);
 void launch_pyrdown(hipStream_t s, const uint16_t* src, int W, int H, uint16_t* dst);
-void launch_vmap_nmap(hipStream_t s, const uint16_t* depth, int W, int H, Intr in, float* vmap, float* nmap);
+void launch_vmap_nmap_pyramid(hipStream_t s, uint16_t* const* depth, const ImgLevel* lv, float* const* vmap,
+                              float* const* nmap);
 void launch_transform_maps(hipStream_t s, const float* vs, const float* ns, int P, const TrackState* st, float* vd,
                            float* nd);
-void launch_resize_maps(hipStream_t s, const float* vs, const float* ns, int W, int H, float* vd, float* nd,
-                        const TrackState* st);
+void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W, int H, float* v1, float* n1, float* v2,
+                         float* n2, const TrackState* st);
 int icp_num_blocks(int W, int rows);
 void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
                            int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,
@@ -34,7 +35,7 @@ void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, 
 void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, double* out27);
 void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st);
 void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st);
-void launch_begin_frame(hipStream_t s, TrackState* st);
+void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf);
 size_t icp_pose_bytes();
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,

@@ -353,11 +353,10 @@ extern "C" int hsk_synchronize(hsk_ctx* k) {
 // ------------------------------------------------------------------------------------------------------
 static void enqueue_preprocess(hsk_ctx* k) {
   hipStream_t s = k->stream;
-  launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_ws, k->d_wc, k->d_dep[0], k->d_scaled);
-  launch_tile_max(s, k->d_scaled, k->lv[0].W, k->lv[0].H, k->d_tmax);
+  launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_ws, k->d_wc, k->d_dep[0], k->d_scaled,
+                         k->d_tmax);
   for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_dep[l]);
-  for (int l = 0; l < HSK_NLEVELS; ++l)
-    launch_vmap_nmap(s, k->d_dep[l], k->lv[l].W, k->lv[l].H, k->lv[l].in, k->d_vcur[l], k->d_ncur[l]);
+  launch_vmap_nmap_pyramid(s, k->d_dep, k->lv, k->d_vcur, k->d_ncur);
 }
 
 static void enqueue_icp(hsk_ctx* k) {
@@ -373,9 +372,8 @@ static void enqueue_integrate(hsk_ctx* k) {
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys) {
   hipStream_t s = k->stream;
   launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys, k->d_flags);
-  for (int l = 1; l < HSK_NLEVELS; ++l)
-    launch_resize_maps(s, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l], k->d_nmod[l],
-                       k->d_st);
+  launch_resize_maps2(s, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
+                      k->d_nmod[2], k->d_st);
 }
 
 // integration gate (A.2 step 5); evaluated on the host, only when the threshold is positive
@@ -397,7 +395,7 @@ static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
   hipStream_t s = k->stream;
   if (with_events) (void)hipEventRecord(k->ev[0], s);
   enqueue_preprocess(k);
-  launch_begin_frame(s, k->d_st);
+  launch_begin_frame(s, k->d_st, k->d_icp_pose);
   if (with_events) (void)hipEventRecord(k->ev[1], s);
   enqueue_icp(k);
   if (with_events) (void)hipEventRecord(k->ev[2], s);
@@ -427,7 +425,7 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
   if (gated) {
     // host decides whether to integrate: one extra synchronisation, only in this non-default mode
     enqueue_preprocess(k);
-    launch_begin_frame(s, k->d_st);
+    launch_begin_frame(s, k->d_st, k->d_icp_pose);
     enqueue_icp(k);
     int r = download_state(k);
     if (r != HSK_OK) return r;
@@ -574,9 +572,8 @@ extern "C" int hsk_raycast(hsk_ctx* k, const float pose[16], float* vmap, float*
   const size_t P = (size_t)k->lv[0].W * k->lv[0].H;
   launch_raycast(k->stream, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0],
                  k->d_keys, k->d_flags);
-  for (int l = 1; l < HSK_NLEVELS; ++l)
-    launch_resize_maps(k->stream, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l],
-                       k->d_nmod[l], k->d_st);
+  launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
+                      k->d_nmod[2], k->d_st);
   HIPCHK(k, hipMemcpyAsync(vmap, k->d_vmod[0], P * 12, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipMemcpyAsync(nmap, k->d_nmod[0], P * 12, hipMemcpyDeviceToHost, k->stream));
   if (keys) HIPCHK(k, hipMemcpyAsync(keys, k->d_keys, P * 4, hipMemcpyDeviceToHost, k->stream));
@@ -759,7 +756,7 @@ extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, in
       launch_transform_maps(k->stream, k->d_vcur[l], k->d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l],
                             k->d_nmod[l]);
   } else {
-    launch_begin_frame(k->stream, k->d_st);
+    launch_begin_frame(k->stream, k->d_st, nullptr);
   }
   return HSK_OK;
 }
@@ -815,9 +812,8 @@ extern "C" int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const vo
     if (!keys_min_dev || !maps_bits_dev) return fail(k, HSK_ERR_ARG, "composite buffers are null");
     launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0],
                  k->lv[0].W * k->lv[0].H);
-    for (int l = 1; l < HSK_NLEVELS; ++l)
-      launch_resize_maps(k->stream, k->d_vmod[l - 1], k->d_nmod[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_vmod[l],
-                         k->d_nmod[l], k->d_st);
+    launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1],
+                        k->d_vmod[2], k->d_nmod[2], k->d_st);
   }
   int r = download_state(k);
   if (r != HSK_OK) return r;

@@ -16,8 +16,10 @@
 __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* __restrict__ src, int W, int H, Intr in,
                                                          const float* __restrict__ ws_tab,
                                                          const float* __restrict__ wc_tab,
-                                                         unsigned short* __restrict__ dst, float* __restrict__ scaled) {
+                                                         unsigned short* __restrict__ dst, float* __restrict__ scaled,
+                                                         float* __restrict__ tmax, float* __restrict__ tmin) {
   __shared__ int tile[BIL_S][BIL_S + 1];  // -1 marks "outside the image"
+  __shared__ float shx[4], shn[4];
   __shared__ float ws[13 * 13];
   __shared__ float wc[512];
   const int tid = threadIdx.y * BIL_T + threadIdx.x;
@@ -31,15 +33,37 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
   for (int i = tid; i < 512; i += 256) wc[i] = wc_tab[i];
   __syncthreads();
   const int x = bx + threadIdx.x, y = by + threadIdx.y;
-  if (x >= W || y >= H) return;
-  const int value = tile[threadIdx.y + BIL_R][threadIdx.x + BIL_R];
-  // scaleDepth (A.4)
-  {
+  const bool inside = x < W && y < H;
+  const int value = inside ? tile[threadIdx.y + BIL_R][threadIdx.x + BIL_R] : 0;
+  // scaleDepth (A.4), and this 16x16 tile's (max, min) of it for the integrate kernel's group classification:
+  // a pixel outside the image or without depth makes the tile minimum 0 ("not all valid")
+  float sc = 0.0f;
+  if (inside) {
     const float xl = ((float)x - in.cx) / in.fx;
     const float yl = ((float)y - in.cy) / in.fy;
     const float lambda = sqrtf((xl * xl + yl * yl) + 1.0f);
-    scaled[y * W + x] = ((float)value * lambda) / 1000.0f;
+    sc = ((float)value * lambda) / 1000.0f;
+    scaled[y * W + x] = sc;
   }
+  {
+    float mx = sc, mn = sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    if ((tid & 63) == 0) {
+      shx[tid >> 6] = mx;
+      shn[tid >> 6] = mn;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int tw = gridDim.x;
+      tmax[blockIdx.y * tw + blockIdx.x] = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
+      tmin[blockIdx.y * tw + blockIdx.x] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
+    }
+  }
+  if (!inside) return;
   if (value == 0) {
     dst[y * W + x] = 0;
     return;
@@ -64,10 +88,12 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
   dst[y * W + x] = (unsigned short)res;
 }
 
+// tiles: raw tile maxima then minima (tw*th floats each), as launch_tile_max lays them out
 void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
-                            uint16_t* dst, float* scaled) {
+                            uint16_t* dst, float* scaled, float* tiles) {
   dim3 block(BIL_T, BIL_T), grid((W + BIL_T - 1) / BIL_T, (H + BIL_T - 1) / BIL_T);
-  hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, ws, wc, dst, scaled);
+  hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, ws, wc, dst, scaled, tiles,
+                     tiles + grid.x * grid.y);
 }
 
 // scaleDepth alone (stage-level integrate entry point)
@@ -127,9 +153,25 @@ static __device__ __forceinline__ bool vertex_of(const unsigned short* __restric
   return false;
 }
 
-__global__ void k_vmap_nmap(const unsigned short* __restrict__ depth, int W, int H, Intr in, float* __restrict__ vmap,
-                            float* __restrict__ nmap) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+struct PyramidArgs {
+  const unsigned short* depth[HSK_NLEVELS];
+  float* vmap[HSK_NLEVELS];
+  float* nmap[HSK_NLEVELS];
+  int W[HSK_NLEVELS], H[HSK_NLEVELS], first_block[HSK_NLEVELS + 1];
+  Intr in[HSK_NLEVELS];
+};
+// one launch for the three levels: a block belongs to the level whose block range contains it
+__global__ void k_vmap_nmap(PyramidArgs a) {
+  int l = 0;
+  if ((int)blockIdx.x >= a.first_block[1]) l = 1;
+  if ((int)blockIdx.x >= a.first_block[2]) l = 2;
+  const unsigned short* __restrict__ depth = a.depth[l];
+  float* __restrict__ vmap = a.vmap[l];
+  float* __restrict__ nmap = a.nmap[l];
+  const int W = a.W[l], H = a.H[l];
+  const Intr in = a.in[l];
+  const int bw = (W + 63) / 64, b = blockIdx.x - a.first_block[l];
+  const int u = (b % bw) * 64 + threadIdx.x, v = (b / bw) * 4 + threadIdx.y;
   if (u >= W || v >= H) return;
   const size_t P = (size_t)W * H, i = (size_t)v * W + u;
   const float fx_inv = 1.0f / in.fx, fy_inv = 1.0f / in.fy;
@@ -159,9 +201,22 @@ __global__ void k_vmap_nmap(const unsigned short* __restrict__ depth, int W, int
   nmap[P + i] = n1;
   nmap[2 * P + i] = n2;
 }
-void launch_vmap_nmap(hipStream_t s, const uint16_t* depth, int W, int H, Intr in, float* vmap, float* nmap) {
-  dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
-  hipLaunchKernelGGL(k_vmap_nmap, grid, block, 0, s, depth, W, H, in, vmap, nmap);
+void launch_vmap_nmap_pyramid(hipStream_t s, uint16_t* const* depth, const ImgLevel* lv, float* const* vmap,
+                              float* const* nmap) {
+  PyramidArgs a;
+  int nb = 0;
+  for (int l = 0; l < HSK_NLEVELS; ++l) {
+    a.depth[l] = depth[l];
+    a.vmap[l] = vmap[l];
+    a.nmap[l] = nmap[l];
+    a.W[l] = lv[l].W;
+    a.H[l] = lv[l].H;
+    a.in[l] = lv[l].in;
+    a.first_block[l] = nb;
+    nb += ((lv[l].W + 63) / 64) * ((lv[l].H + 3) / 4);
+  }
+  a.first_block[HSK_NLEVELS] = nb;
+  hipLaunchKernelGGL(k_vmap_nmap, dim3(nb), dim3(64, 4), 0, s, a);
 }
 
 // tranformMaps (A.2, first frame): v_g = R v + t, n_g = R n, pose taken from the device state
@@ -196,25 +251,59 @@ void launch_transform_maps(hipStream_t s, const float* vs, const float* ns, int 
   hipLaunchKernelGGL(k_transform_maps, dim3((P + 255) / 256), dim3(256), 0, s, vs, ns, P, st, vd, nd);
 }
 
-// resizeVMap + resizeNMap (A.3) in one launch
-__global__ void k_resize_maps(const float* __restrict__ vs, const float* __restrict__ ns, int W, int H,
-                              float* __restrict__ vd, float* __restrict__ nd, const TrackState* __restrict__ st) {
-  const int w2 = W >> 1, h2 = H >> 1;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w2 || y >= h2) return;
-  if (st->lost) return;
-  const size_t P = (size_t)W * H, P2 = (size_t)w2 * h2;
+// resizeVMap + resizeNMap (A.3): 2x2 mean, NaN if any tap is NaN; normals renormalised
+static __device__ __forceinline__ void resize_tap(const float* __restrict__ src, size_t P, int W, int x, int y, bool normalize,
+                                                  float& a, float& b, float& c) {
   const size_t i00 = (size_t)(2 * y) * W + 2 * x, i01 = i00 + 1, i10 = i00 + W, i11 = i10 + 1;
+  a = b = c = HSK_NANF;
+  if (!(hsk_isnan(src[i00]) || hsk_isnan(src[i01]) || hsk_isnan(src[i10]) || hsk_isnan(src[i11]))) {
+    a = (((src[i00] + src[i01]) + src[i10]) + src[i11]) / 4.0f;
+    b = (((src[P + i00] + src[P + i01]) + src[P + i10]) + src[P + i11]) / 4.0f;
+    c = (((src[2 * P + i00] + src[2 * P + i01]) + src[2 * P + i10]) + src[2 * P + i11]) / 4.0f;
+    if (normalize) {
+      const float inv = 1.0f / sqrtf(hsk_dot3(a, b, c, a, b, c));
+      a = a * inv;
+      b = b * inv;
+      c = c * inv;
+    }
+  }
+}
+// level 0 -> level 1 and level 2 in one launch: blocks [0, nb1) write level 1; the rest write level 2 and
+// recompute the four level-1 values they average (same arithmetic, so the same bits as reading them back)
+__global__ void k_resize_maps2(const float* __restrict__ v0, const float* __restrict__ n0, int W, int H,
+                               float* __restrict__ v1, float* __restrict__ n1, float* __restrict__ v2,
+                               float* __restrict__ n2, const TrackState* __restrict__ st, int nb1) {
+  if (st->lost) return;
+  const int w1 = W >> 1, h1 = H >> 1, w2 = W >> 2, h2 = H >> 2;
+  const size_t P0 = (size_t)W * H, P1 = (size_t)w1 * h1, P2 = (size_t)w2 * h2;
+  if ((int)blockIdx.x < nb1) {
+    const int bw = (w1 + 63) / 64;
+    const int x = (blockIdx.x % bw) * 64 + threadIdx.x, y = (blockIdx.x / bw) * 4 + threadIdx.y;
+    if (x >= w1 || y >= h1) return;
+    const size_t o = (size_t)y * w1 + x;
+    float a, b, c;
+    resize_tap(v0, P0, W, x, y, false, a, b, c);
+    v1[o] = a; v1[P1 + o] = b; v1[2 * P1 + o] = c;
+    resize_tap(n0, P0, W, x, y, true, a, b, c);
+    n1[o] = a; n1[P1 + o] = b; n1[2 * P1 + o] = c;
+    return;
+  }
+  const int bw = (w2 + 63) / 64, bi = blockIdx.x - nb1;
+  const int x = (bi % bw) * 64 + threadIdx.x, y = (bi / bw) * 4 + threadIdx.y;
+  if (x >= w2 || y >= h2) return;
   const size_t o = (size_t)y * w2 + x;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const float* src = m == 0 ? vs : ns;
-    float* dst = m == 0 ? vd : nd;
+    const float* src = m == 0 ? v0 : n0;
+    float* dst = m == 0 ? v2 : n2;
+    float t[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) resize_tap(src, P0, W, 2 * x + (q & 1), 2 * y + (q >> 1), m == 1, t[q][0], t[q][1], t[q][2]);
     float a = HSK_NANF, b = HSK_NANF, c = HSK_NANF;
-    if (!(hsk_isnan(src[i00]) || hsk_isnan(src[i01]) || hsk_isnan(src[i10]) || hsk_isnan(src[i11]))) {
-      a = (((src[i00] + src[i01]) + src[i10]) + src[i11]) / 4.0f;
-      b = (((src[P + i00] + src[P + i01]) + src[P + i10]) + src[P + i11]) / 4.0f;
-      c = (((src[2 * P + i00] + src[2 * P + i01]) + src[2 * P + i10]) + src[2 * P + i11]) / 4.0f;
+    if (!(hsk_isnan(t[0][0]) || hsk_isnan(t[1][0]) || hsk_isnan(t[2][0]) || hsk_isnan(t[3][0]))) {
+      a = (((t[0][0] + t[1][0]) + t[2][0]) + t[3][0]) / 4.0f;
+      b = (((t[0][1] + t[1][1]) + t[2][1]) + t[3][1]) / 4.0f;
+      c = (((t[0][2] + t[1][2]) + t[2][2]) + t[3][2]) / 4.0f;
       if (m == 1) {
         const float inv = 1.0f / sqrtf(hsk_dot3(a, b, c, a, b, c));
         a = a * inv;
@@ -227,10 +316,10 @@ __global__ void k_resize_maps(const float* __restrict__ vs, const float* __restr
     dst[2 * P2 + o] = c;
   }
 }
-void launch_resize_maps(hipStream_t s, const float* vs, const float* ns, int W, int H, float* vd, float* nd,
-                        const TrackState* st) {
-  dim3 block(64, 4), grid((W / 2 + 63) / 64, (H / 2 + 3) / 4);
-  hipLaunchKernelGGL(k_resize_maps, grid, block, 0, s, vs, ns, W, H, vd, nd, st);
+void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W, int H, float* v1, float* n1, float* v2,
+                         float* n2, const TrackState* st) {
+  const int nb1 = ((W / 2 + 63) / 64) * ((H / 2 + 3) / 4), nb2 = ((W / 4 + 63) / 64) * ((H / 4 + 3) / 4);
+  hipLaunchKernelGGL(k_resize_maps2, dim3(nb1 + nb2), dim3(64, 4), 0, s, v0, n0, W, H, v1, n1, v2, n2, st, nb1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -772,18 +861,6 @@ __global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ p
   }
 }
 
-// seeds the pose ping-pong from the tracker state (after k_begin_frame)
-__global__ void k_icp_seed(const TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
-  if (threadIdx.x != 0) return;
-  IcpPose p;
-  for (int i = 0; i < 9; ++i) p.R[i] = st->R[i];
-  for (int i = 0; i < 3; ++i) p.t[i] = st->t[i];
-  p.lost = st->lost;
-  p.n_iter = 0;
-  p.pad[0] = p.pad[1] = 0;
-  *pose0 = p;
-}
-
 size_t icp_pose_bytes() { return 2 * sizeof(IcpPose); }
 
 // enqueue the whole ICP of one frame: levels coarse -> fine, iters[l] iterations each
@@ -792,7 +869,6 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
                       void* pose_buf, double* part_a, double* part_b) {
   IcpPose* pb = (IcpPose*)pose_buf;
   double* part[2] = {part_a, part_b};
-  hipLaunchKernelGGL(k_icp_seed, dim3(1), dim3(64), 0, s, st, pb);
   int i = 0, nb_prev = 0;
   for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
     const int W = lv[l].W, H = lv[l].H;
@@ -814,14 +890,25 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
 }
 
 // start of a tracked frame: previous pose <- current pose, clear the lost flag
-__global__ void k_begin_frame(TrackState* __restrict__ st) {
+__global__ void k_begin_frame(TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
   if (threadIdx.x != 0) return;
   for (int i = 0; i < 9; ++i) st->Rp[i] = st->R[i];
   for (int i = 0; i < 3; ++i) st->tp[i] = st->t[i];
   st->lost = 0;
   st->n_iter = 0;
+  if (pose0) {  // seed of the fused ICP's pose ping-pong
+    IcpPose p;
+    for (int i = 0; i < 9; ++i) p.R[i] = st->R[i];
+    for (int i = 0; i < 3; ++i) p.t[i] = st->t[i];
+    p.lost = 0;
+    p.n_iter = 0;
+    p.pad[0] = p.pad[1] = 0;
+    *pose0 = p;
+  }
 }
-void launch_begin_frame(hipStream_t s, TrackState* st) { hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, s, st); }
+void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf) {
+  hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, s, st, (IcpPose*)icp_pose_buf);
+}
 
 // host mirrors (used by hsk_icp_solve and by tests through the C ABI)
 bool host_solve6(const double* in27, float* x6) { return hsk_solve6(in27, x6); }

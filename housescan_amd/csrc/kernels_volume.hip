@@ -22,6 +22,9 @@
 #ifndef INTEGRATE_U
 #define INTEGRATE_U 1  // software-pipeline depth of k_integrate (1 measured fastest: profiles/r01/integrate_analysis.md)
 #endif
+#ifndef INTEGRATE_WPE
+#define INTEGRATE_WPE 6  // waves per SIMD the register allocator must leave room for (79 VGPRs, no spills)
+#endif
 #ifndef INTEGRATE_ZCHUNK
 #define INTEGRATE_ZCHUNK 8
 #endif
@@ -49,29 +52,12 @@ __global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float
     tmin[ty * tw + tx] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
   }
 }
-// 3x3 dilation of the tile tables into one interleaved (max, min) table, once per frame (the integrate blocks
-// only copy the result into LDS)
-__global__ void k_tile_dilate(const float* __restrict__ tmax, const float* __restrict__ tmin, float2* __restrict__ dtab,
-                              int tw, int th) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= tw * th) return;
-  const int ty = i / tw, tx = i - ty * tw;
-  float mx = 0.0f, mn = 1e30f;
-  for (int dy = -1; dy <= 1; ++dy)
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
-      mx = fmaxf(mx, tmax[yy * tw + xx]);
-      mn = fminf(mn, tmin[yy * tw + xx]);
-    }
-  dtab[i] = make_float2(mx, mn);
-}
-// tiles holds 4 * tw * th floats: raw max, raw min, then the interleaved dilated (max, min) table
+// tiles holds 4 * tw * th floats: raw max, raw min (this kernel, or k_bilateral_scale on the frame path), then the
+// interleaved 3x3-dilated (max, min) table that k_column_zrange's tail blocks fill before every integrate
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tiles) {
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int n = tw * th;
   hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tiles, tiles + n, tw);
-  hipLaunchKernelGGL(k_tile_dilate, dim3((n + 255) / 256), dim3(256), 0, s, tiles, tiles + n, (float2*)(tiles + 2 * n), tw,
-                     th);
 }
 
 // clip [lo,hi] (in gz) with c + m*gz >= 0
@@ -91,7 +77,22 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 // convex, so each column meets it in one interval; clipping the line cam(gz) = a + gz * c against the five
 // half-spaces gives it.  Conservative by 2 planes (float error).  Empty columns get (INT_MAX, INT_MIN).
 __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
-                                int2* __restrict__ zint) {
+                                int2* __restrict__ zint, int col_blocks, const float* __restrict__ tmax,
+                                const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th) {
+  if ((int)blockIdx.x >= col_blocks) {  // the last blocks dilate the tile table instead (saves a launch)
+    const int i = (blockIdx.x - col_blocks) * blockDim.x + threadIdx.x;
+    if (i >= tw * th) return;
+    const int ty = i / tw, tx = i - ty * tw;
+    float mx = 0.0f, mn = 1e30f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
+        mx = fmaxf(mx, tmax[yy * tw + xx]);
+        mn = fminf(mn, tmin[yy * tw + xx]);
+      }
+    dtab[i] = make_float2(mx, mn);
+    return;
+  }
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncol = vp.X / 4;
   if (c >= ncol * vp.Y) return;
@@ -286,7 +287,7 @@ static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, un
 // before plane z is updated and stored, so every wave keeps D 1-KiB requests in flight (the kernel is bound by
 // HBM latency x occupancy otherwise -- profiles/r01/integrate_wave_timing.txt).
 template <bool COUNT_ONLY, int D>
-__global__ __launch_bounds__(256) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
+__global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
                                                    const TrackState* __restrict__ st, VolParams vp, int W, int H,
                                                    Intr in, int zchunk, unsigned long long* __restrict__ counter,
                                                    unsigned* __restrict__ flags, const float2* __restrict__ dtab,
@@ -417,7 +418,9 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int ncols = (vp.X / 4) * vp.Y;
-  hipLaunchKernelGGL(k_column_zrange, dim3((ncols + 255) / 256), dim3(256), 0, s, st, vp, W, H, in, zint);
+  const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
+  hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks + dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, col_blocks,
+                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
