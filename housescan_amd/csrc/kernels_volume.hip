@@ -142,6 +142,7 @@ struct ColumnTerms {
 struct IntegrateConst {
   float i02, i12, i22, tz;
   float rk, zmin, cull_thr, free_thr, hw, hh;
+  float rk4, zmin4, cull_thr4, free_thr4;  // the same for a 4-plane block (voxels within 2.2 cells of its centre)
 };
 
 // Phases 0-2b for ONE plane: which of the lane's 4 voxels are rewritten (mask), which of those with F == 1
@@ -237,6 +238,25 @@ static __device__ __forceinline__ void classify_plane(int zz, bool in_range, con
   }
 }
 
+static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]);
+
+// All four voxels of the vector observed as free space (F == 1).  When all four already store +1 the running
+// mean leaves +1 ((1*W + 1) / (W + 1) == 1 exactly) and only the weights move: W <- min(W + 1, 128), done on the
+// packed words with one add and one min per voxel.  Otherwise the general update runs.
+static __device__ __forceinline__ void update_vector_free4(uint4& q) {
+  const unsigned a = q.x & q.y & q.z & q.w, o = q.x | q.y | q.z | q.w;
+  if ((a & 0x7fffu) == 0x7fffu && (o & 0x8000u) == 0u) {
+    const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
+    q.x = min(q.x + 0x10000u, cap);
+    q.y = min(q.y + 0x10000u, cap);
+    q.z = min(q.z + 0x10000u, cap);
+    q.w = min(q.w + 0x10000u, cap);
+  } else {
+    const float F1[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    (void)update_vector(q, 0xFu, 0xFu, F1);  // F == 1 never writes a negative value
+  }
+}
+
 // Phase 4 for one plane: running mean (A.4), repack.  Returns true when a negative TSDF was written.
 static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]) {
   unsigned w4[4] = {q.x, q.y, q.z, q.w};
@@ -283,9 +303,7 @@ static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, un
   return neg;
 }
 
-// The integrate kernel.  D = software-pipeline depth: plane z+D is classified and its volume vector requested
-// before plane z is updated and stored, so every wave keeps D 1-KiB requests in flight (the kernel is bound by
-// HBM latency x occupancy otherwise -- profiles/r01/integrate_wave_timing.txt).
+// The integrate kernel (the template parameter D is unused since the two-level loop replaced the pipelined one).
 template <bool COUNT_ONLY, int D>
 __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
                                                    const TrackState* __restrict__ st, VolParams vp, int W, int H,
@@ -334,6 +352,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     k.free_thr = vp.tau * 1.0002f + 1e-4f + 2.0f * vp.cell[0];
     k.hw = 0.5f * (float)(W - 1);
     k.hh = 0.5f * (float)(H - 1);
+    k.rk4 = k.rk * 1.47f;  // sqrt(1.5^2 + 1.5^2) / 1.5, rounded up
+    k.zmin4 = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk4 / ((float)HSK_TILE - 2.5f));
+    k.cull_thr4 = vp.tau * 1.001f + 1e-4f + 2.3f * cellm;
+    k.free_thr4 = vp.tau * 1.0002f + 1e-4f + 2.3f * cellm;
     ColumnTerms c;
     {
       const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
@@ -353,54 +375,67 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
     const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
     const int bricks_x = vp.X >> vp.bshift, bricks_y = vp.Y >> vp.bshift;
-    uint4 q[D];
-    float F[D][4];
-    unsigned mask[D], one[D];
-    // pipeline prologue: planes wl .. wl+D-1
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int zz = wl + d;
-      mask[d] = 0;
-      if (zz <= wh) {
-        classify_plane(zz, active && zz >= zl && zz <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, mask[d], one[d], F[d]);
-        if (COUNT_ONLY)
-          cnt += __popc(mask[d]);
-        else if (mask[d])
-          q[d] = vol[idx0 + (size_t)zz * plane_vec];
+    // Two levels.  A lane's 4(x) x 4(z) block is classified ONCE against the tile table; when no lane of the
+    // wave needs a closer look the four planes are dead or deep free space and the wave does four batched
+    // vector updates (loads in flight together) with no per-plane work at all.  Otherwise the four planes go
+    // through the per-plane path.
+    for (int zb = wl & ~3; zb <= wh; zb += 4) {
+      // ---- block classification (conservative, same argument as the per-plane one with a 2.2-cell radius)
+      const bool in_any = (zb + 3 >= zl) && (zb <= zh) && active;
+      const bool in_all = (zb >= zl) && (zb + 3 <= zh) && active;
+      bool free44 = false, other = in_any;
+      {
+        const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - k.tz;  // centre of planes zb .. zb+3
+        const float czc = c.azc + k.i22 * gz;
+        const float rc = __builtin_amdgcn_rcpf(czc);
+        const float uc = (c.axfc + (k.i02 * gz) * in.fx) * rc + in.cx;
+        const float vc = (c.ayfc + (k.i12 * gz) * in.fy) * rc + in.cy;
+        const float r = k.rk4 * rc + 2.5f;
+        const bool ok = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
+        const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
+        const float2 Dt = dtab[tv * tw + tu];
+        const float dc = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
+        const bool dead4 = ok && (dc * 0.99999f - Dt.x > k.cull_thr4);
+        free44 = in_all && ok && (dc * 1.00001f + k.free_thr4 <= Dt.y);
+        other = in_any && !dead4 && !free44;
       }
-    }
-    if (!COUNT_ONLY) {
-      for (int zb = wl; zb <= wh; zb += D) {
+      if (__ballot(other) == 0ull) {
+        if (COUNT_ONLY) {
+          cnt += free44 ? 16 : 0;
+        } else if (free44) {
+          uint4 q4[4];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const int zz = zb + d;  // the plane whose vector sits in slot d
-          if (mask[d]) {
-            const bool neg = update_vector(q[d], mask[d], one[d], F[d]);
-            vol[idx0 + (size_t)zz * plane_vec] = q[d];
-            if (neg) {
-              const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
-              // test first: after the first frames the bit is already set and no atomic is issued (a stale
-              // read only costs a redundant OR)
-              if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
-                __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-          // refill the slot with plane zz + D
-          const int zn = zz + D;
-          mask[d] = 0;
-          if (zn <= wh) {
-            classify_plane(zn, active && zn >= zl && zn <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, mask[d], one[d],
-                           F[d]);
-            if (mask[d]) q[d] = vol[idx0 + (size_t)zn * plane_vec];
+          for (int u = 0; u < 4; ++u) q4[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            update_vector_free4(q4[u]);
+            vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
           }
         }
+        continue;
       }
-    } else {
-      for (int zz = wl + D; zz <= wh; ++zz) {
-        unsigned m, o;
-        float f[4];
-        classify_plane(zz, active && zz >= zl && zz <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, m, o, f);
-        cnt += __popc(m);
+      // ---- per-plane path for these four planes
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u) {
+        const int zz = zb + u;
+        if (zz < wl || zz > wh) continue;
+        unsigned mask, one;
+        float F[4];
+        classify_plane(zz, active && zz >= zl && zz <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, mask, one, F);
+        if (COUNT_ONLY) {
+          cnt += __popc(mask);
+        } else if (mask) {
+          uint4 q = vol[idx0 + (size_t)zz * plane_vec];
+          const bool neg = update_vector(q, mask, one, F);
+          vol[idx0 + (size_t)zz * plane_vec] = q;
+          if (neg) {
+            const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
+            // test first: after the first frames the bit is already set and no atomic is issued (a stale
+            // read only costs a redundant OR)
+            if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
+              __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
   }
