@@ -45,6 +45,7 @@ struct hsk_ctx {
   int* d_keys = nullptr;
   unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
   size_t flags_bytes = 0;
+  unsigned* d_queue = nullptr;       // integrate pass A -> pass B: count (4 words) + uncertain lane-block ids
   int2* d_zint = nullptr;            // per lane column: stored-plane range inside the padded frustum
   float* d_tmax = nullptr;           // 16x16-pixel tile maxima of the scaled depth
   uint16_t* h_stage = nullptr;  // pinned staging for the incoming depth frame
@@ -170,6 +171,7 @@ static void free_all(hsk_ctx* k) {
   F(k->d_flags);
   F(k->d_tmax);
   F(k->d_zint);
+  F(k->d_queue);
   F(k->d_counter);
   F(k->d_rowcnt);
   F(k->d_rowoff);
@@ -301,8 +303,16 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     ++vp.bshift;
   k->flags_bytes = (size_t)hsk_flag_words(vp) * 4;
   CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
+  // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of the pass-A
+  // blocks (64 x 16 voxels x 8 planes per block -> 512 lane-blocks); see launch_integrate
+  {
+    const size_t nblk = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16) * ((vp.nzs + 7) / 8);
+    const size_t qcap = ((nblk + 255) / 256) * 512;
+    CK(hipMalloc((void**)&k->d_queue, (256 * 64 + 256 * qcap) * sizeof(unsigned)));
+  }
   CK(hipMalloc((void**)&k->d_zint, (size_t)(vp.X / 4) * vp.Y * sizeof(int2)));
-  CK(hipMalloc((void**)&k->d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4));
+  CK(hipMalloc((void**)&k->d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4 +
+                                       (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8));
   CK(hipMalloc((void**)&k->d_counter, 16));
   {
     float ws[169], wc[512];
@@ -366,7 +376,7 @@ static void enqueue_icp(hsk_ctx* k) {
 
 static void enqueue_integrate(hsk_ctx* k) {
   launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
-                   k->d_counter, k->d_flags, k->d_tmax, k->d_zint);
+                   k->d_counter, k->d_flags, k->d_tmax, k->d_zint, k->d_queue);
 }
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys) {
@@ -556,7 +566,7 @@ extern "C" int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h
   launch_tile_max(k->stream, k->d_scaled, w, h, k->d_tmax);
   HIPCHK(k, hipMemsetAsync(k->d_counter, 0, 8, k->stream));
   launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter, k->d_flags,
-                   k->d_tmax, k->d_zint);
+                   k->d_tmax, k->d_zint, k->d_queue);
   unsigned long long c = 0;
   HIPCHK(k, hipMemcpyAsync(&c, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));

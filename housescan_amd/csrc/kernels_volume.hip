@@ -22,8 +22,13 @@
 #ifndef INTEGRATE_U
 #define INTEGRATE_U 1  // software-pipeline depth of k_integrate (1 measured fastest: profiles/r01/integrate_analysis.md)
 #endif
+#define HSK_NQUEUES 256       // uncertain lane-blocks are spread over this many queues (pass A -> pass B)
+#define HSK_QCOUNT_STRIDE 64  // words between two queue counters (256 B: one counter per memory-side atomic line)
 #ifndef INTEGRATE_WPE
 #define INTEGRATE_WPE 6  // waves per SIMD the register allocator must leave room for (79 VGPRs, no spills)
+#endif
+#ifndef INTEGRATE_DETAIL_WPE
+#define INTEGRATE_DETAIL_WPE 4  // pass B keeps 4 planes x 4 voxels of state per lane: ~120 VGPRs
 #endif
 #ifndef INTEGRATE_ZCHUNK
 #define INTEGRATE_ZCHUNK 8
@@ -58,6 +63,24 @@ void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* ti
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int n = tw * th;
   hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tiles, tiles + n, tw);
+}
+
+// Fine tile table for the second classification level: per 8x8-pixel tile (max, min-if-all-valid) of the scaled
+// depth, NOT dilated (the lookup covers the exact pixel box of a voxel block).  One thread per tile.
+#define HSK_FTILE 8
+__global__ void k_tile_fine(const float* __restrict__ scaled, int W, int H, float2* __restrict__ ftab, int fw, int fh) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= fw * fh) return;
+  const int ty = t / fw, tx = t - ty * fw;
+  float mx = 0.0f, mn = 1e30f;
+  for (int dy = 0; dy < HSK_FTILE; ++dy)
+    for (int dx = 0; dx < HSK_FTILE; ++dx) {
+      const int x = tx * HSK_FTILE + dx, y = ty * HSK_FTILE + dy;
+      const float v = (x < W && y < H) ? scaled[(size_t)y * W + x] : 0.0f;  // outside the image: never "all valid"
+      mx = fmaxf(mx, v);
+      mn = fminf(mn, v);
+    }
+  ftab[t] = make_float2(mx, mn);
 }
 
 // clip [lo,hi] (in gz) with c + m*gz >= 0
@@ -238,6 +261,117 @@ static __device__ __forceinline__ void classify_plane(int zz, bool in_range, con
   }
 }
 
+// classify_plane for U consecutive planes at once, phase by phase, so that the U tile lookups, then the 4U depth
+// gathers, are in flight together (pass B is bound by the number of dependent memory round trips per entry).
+template <int U>
+static __device__ __forceinline__ void classify_planes(int zz0, const bool* in_range, const ColumnTerms& c,
+                                                       const IntegrateConst& k, const VolParams& vp, int W, int H,
+                                                       const Intr& in, const float2* __restrict__ dtab, int tw, int th,
+                                                       const float* __restrict__ scaled, unsigned* mask, unsigned* one,
+                                                       float (*F)[4]) {
+  float gz2[U], gzv[U];
+  unsigned detail = 0;
+  float2 Dt[U];
+  float ucs[U], vcs[U], czs[U], rcs[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // phase 0a: tile lookups in flight
+    const float gz = ((float)(vp.zs0 + zz0 + u) + 0.5f) * vp.cell[2] - k.tz;
+    gzv[u] = gz;
+    gz2[u] = gz * gz;
+    czs[u] = c.azc + k.i22 * gz;
+    rcs[u] = __builtin_amdgcn_rcpf(czs[u]);
+    ucs[u] = (c.axfc + (k.i02 * gz) * in.fx) * rcs[u] + in.cx;
+    vcs[u] = (c.ayfc + (k.i12 * gz) * in.fy) * rcs[u] + in.cy;
+    const int tu = min(max((int)ucs[u] >> 4, 0), tw - 1), tv = min(max((int)vcs[u] >> 4, 0), th - 1);
+    Dt[u] = dtab[tv * tw + tu];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // phase 0b
+    const float r = k.rk * rcs[u] + 2.5f;
+    const bool ok = czs[u] > k.zmin && fabsf(ucs[u] - k.hw) + r <= k.hw && fabsf(vcs[u] - k.hh) + r <= k.hh;
+    const float dc = __builtin_amdgcn_sqrtf(gz2[u] + c.pnc);
+    const bool dead = !in_range[u] || (ok && (dc * 0.99999f - Dt[u].x > k.cull_thr));
+    const bool fr = in_range[u] && ok && (dc * 1.00001f + k.free_thr <= Dt[u].y);
+    mask[u] = one[u] = fr ? 0xFu : 0u;
+    detail |= ((!dead && !fr) ? 1u : 0u) << u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) F[u][j] = 0.0f;
+  }
+  if (__ballot(detail != 0) == 0ull) return;
+  int pix[U][4];
+  unsigned nearb = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // phase 1
+    const bool lv = (detail >> u) & 1u;
+    const float bx = k.i02 * gzv[u], by = k.i12 * gzv[u], bz = k.i22 * gzv[u];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float camz = c.az[j] + bz;
+      const float inv_a = __builtin_amdgcn_rcpf(camz);
+      const float fu = ((c.ax[j] + bx) * in.fx) * inv_a + in.cx;
+      const float fv = ((c.ay[j] + by) * in.fy) * inv_a + in.cy;
+      const float ru = rintf(fu), rv = rintf(fv);
+      const int uu = (int)ru, vv = (int)rv;
+      const bool front = lv && camz > 0.0f && fabsf(fu) < 1.0e5f && fabsf(fv) < 1.0e5f;
+      const bool inb = front && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
+      const bool nb = front && fmaxf(fabsf(fu - ru), fabsf(fv - rv)) > 0.5f - 3.0e-4f;
+      pix[u][j] = inb ? vv * W + uu : -1;
+      nearb |= (nb ? 1u : 0u) << (u * 4 + j);
+    }
+  }
+  if (nearb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float bx = k.i02 * gzv[u], by = k.i12 * gzv[u], bz = k.i22 * gzv[u];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (nearb & (1u << (u * 4 + j))) {
+          const float inv_z = 1.0f / (c.az[j] + bz);
+          const float fu = ((c.ax[j] + bx) * in.fx) * inv_z + in.cx;
+          const float fv = ((c.ay[j] + by) * in.fy) * inv_z + in.cy;
+          int uu, vv;
+          pix[u][j] = (hsk_rint_guard(fu, uu) && hsk_rint_guard(fv, vv) && uu >= 0 && vv >= 0 && uu < W && vv < H) ? vv * W + uu
+                                                                                                                : -1;
+        }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)  // phase 2: all gathers in flight
+#pragma unroll
+    for (int j = 0; j < 4; ++j) F[u][j] = scaled[max(pix[u][j], 0)];
+  unsigned unsure = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u)  // phase 2b
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float Ds = F[u][j];
+      const float sdf_a = Ds - __builtin_amdgcn_sqrtf(gz2[u] + c.pn[j]);
+      const bool val = pix[u][j] >= 0 && Ds != 0.0f;
+      const bool sure = val && sdf_a * vp.tau_inv > 1.0001f;
+      const bool maybe = val && !sure && sdf_a >= -vp.tau - 2.0e-6f;
+      mask[u] |= (sure ? 1u : 0u) << j;
+      one[u] |= (sure ? 1u : 0u) << j;
+      unsure |= (maybe ? 1u : 0u) << (u * 4 + j);
+    }
+  if (unsure) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (unsure & (1u << (u * 4 + j))) {
+          const float sdf = F[u][j] - sqrtf(gz2[u] + c.pn[j]);
+          if (sdf >= -vp.tau) {
+            const float f = sdf * vp.tau_inv;
+            mask[u] |= 1u << j;
+            if (f < 1.0f)
+              F[u][j] = f;
+            else
+              one[u] |= 1u << j;
+          }
+        }
+  }
+}
+
 static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]);
 
 // All four voxels of the vector observed as free space (F == 1).  When all four already store +1 the running
@@ -309,7 +443,9 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
                                                    const TrackState* __restrict__ st, VolParams vp, int W, int H,
                                                    Intr in, int zchunk, unsigned long long* __restrict__ counter,
                                                    unsigned* __restrict__ flags, const float2* __restrict__ dtab,
-                                                   int tw, int th, const int2* __restrict__ zint) {
+                                                   int tw, int th, const int2* __restrict__ zint,
+                                                   unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
+                                                   unsigned qcap, const float2* __restrict__ ftab, int fw, int fh) {
   // dtab: per 16x16-pixel tile (max, min-if-all-valid) of the scaled depth, 3x3-dilated.  It is 9.6 KB and stays
   // hot in every CU's vector L1; staging it in LDS per workgroup cost ~2.5 us of each short-lived block's life.
   const int lane = threadIdx.x;
@@ -374,13 +510,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     }
     const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
     const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
-    const int bricks_x = vp.X >> vp.bshift, bricks_y = vp.Y >> vp.bshift;
-    // Two levels.  A lane's 4(x) x 4(z) block is classified ONCE against the tile table; when no lane of the
-    // wave needs a closer look the four planes are dead or deep free space and the wave does four batched
-    // vector updates (loads in flight together) with no per-plane work at all.  Otherwise the four planes go
-    // through the per-plane path.
+    // Pass A.  A lane's 4(x) x 4(z) block is classified ONCE against the tile table: dead blocks cost nothing
+    // more, deep-free-space blocks get four batched vector updates right here (loads in flight together), and the
+    // uncertain ones (near a surface, at the frustum rim, close to the camera) are appended to a queue that pass B
+    // (k_integrate_detail) walks with the per-voxel path on DENSE waves -- uncertain blocks hug the surfaces and
+    // would otherwise drag their whole 64-lane wave through that path (profiles/r01/integrate_analysis.md).
+    const int qx = vp.X / 4;
     for (int zb = wl & ~3; zb <= wh; zb += 4) {
-      // ---- block classification (conservative, same argument as the per-plane one with a 2.2-cell radius)
       const bool in_any = (zb + 3 >= zl) && (zb <= zh) && active;
       const bool in_all = (zb >= zl) && (zb + 3 <= zh) && active;
       bool free44 = false, other = in_any;
@@ -398,11 +534,52 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         const bool dead4 = ok && (dc * 0.99999f - Dt.x > k.cull_thr4);
         free44 = in_all && ok && (dc * 1.00001f + k.free_thr4 <= Dt.y);
         other = in_any && !dead4 && !free44;
+        // ---- second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
+        //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
+        //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
+        //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
+        if (__ballot(other) != 0ull) {
+          const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - k.tz;
+          const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - k.tz;
+          float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f, zmn = 1e30f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = (q & 1) ? 3 : 0;
+            const float gq = (q & 2) ? gzb : gza;
+            const float cz = c.az[j] + k.i22 * gq;
+            const float rq = __builtin_amdgcn_rcpf(cz);
+            const float uq = ((c.ax[j] + k.i02 * gq) * in.fx) * rq + in.cx;
+            const float vq = ((c.ay[j] + k.i12 * gq) * in.fy) * rq + in.cy;
+            zmn = fminf(zmn, cz);
+            umin = fminf(umin, uq);
+            umax = fmaxf(umax, uq);
+            vmin = fminf(vmin, vq);
+            vmax = fmaxf(vmax, vq);
+          }
+          umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
+          const int tu0 = (int)umin >> 3, tv0 = (int)vmin >> 3;
+          const bool ok2 = zmn > 0.05f && umin >= 0.0f && vmin >= 0.0f && umax <= (float)(W - 1) && vmax <= (float)(H - 1) &&
+                           ((int)umax >> 3) <= tu0 + 2 && ((int)vmax >> 3) <= tv0 + 2;
+          float Dx = 0.0f, Dn = 1e30f;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              const int tx = min(max(tu0 + b, 0), fw - 1), ty = min(max(tv0 + a, 0), fh - 1);
+              const float2 t = ftab[ty * fw + tx];
+              Dx = fmaxf(Dx, t.x);
+              Dn = fminf(Dn, t.y);
+            }
+          const bool dead2 = ok2 && (dc * 0.99999f - Dx > k.cull_thr4);
+          const bool free2 = in_all && ok2 && (dc * 1.00001f + k.free_thr4 <= Dn);
+          if (other && free2) free44 = true;
+          other = other && !dead2 && !free2;
+        }
       }
-      if (__ballot(other) == 0ull) {
+      if (free44) {
         if (COUNT_ONLY) {
-          cnt += free44 ? 16 : 0;
-        } else if (free44) {
+          cnt += 16;
+        } else {
           uint4 q4[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) q4[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
@@ -412,30 +589,117 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
             vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
           }
         }
-        continue;
       }
-      // ---- per-plane path for these four planes
-#pragma unroll 1
-      for (int u = 0; u < 4; ++u) {
-        const int zz = zb + u;
-        if (zz < wl || zz > wh) continue;
-        unsigned mask, one;
-        float F[4];
-        classify_plane(zz, active && zz >= zl && zz <= zh, c, k, vp, W, H, in, dtab, tw, th, scaled, mask, one, F);
-        if (COUNT_ONLY) {
-          cnt += __popc(mask);
-        } else if (mask) {
-          uint4 q = vol[idx0 + (size_t)zz * plane_vec];
-          const bool neg = update_vector(q, mask, one, F);
-          vol[idx0 + (size_t)zz * plane_vec] = q;
-          if (neg) {
-            const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
-            // test first: after the first frames the bit is already set and no atomic is issued (a stale
-            // read only costs a redundant OR)
-            if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
-              __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
+      // wave-aggregated append of the uncertain lane-blocks
+      const unsigned long long bo = __ballot(other);
+      if (bo != 0ull) {
+        // one of HSK_NQUEUES queues by block index: a single counter saturates at ~88 atomics/us chip-wide
+        const unsigned qi = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % HSK_NQUEUES;
+        unsigned base = 0;
+        if (lane == (int)__builtin_ctzll(bo)) base = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo));
+        base = __shfl(base, (int)__builtin_ctzll(bo), 64);
+        if (other)
+          queue[(size_t)qi * qcap + base + (unsigned)__popcll(bo & ((1ull << lane) - 1ull))] =
+              (unsigned)(((zb >> 2) * vp.Y + y) * qx + (x0 >> 2));
+      }
+    }
+  }
+  if (COUNT_ONLY) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if (lane == 0 && cnt) atomicAdd(counter, cnt);
+  }
+}
+
+// Pass B of integrate: the queued (uncertain) lane-blocks, one per lane, four planes each, per-voxel path.
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(uint4* __restrict__ vol,
+                                                                         const float* __restrict__ scaled,
+                                                                         const TrackState* __restrict__ st, VolParams vp,
+                                                                         int W, int H, Intr in,
+                                                                         unsigned long long* __restrict__ counter,
+                                                                         unsigned* __restrict__ flags,
+                                                                         const float2* __restrict__ dtab, int tw, int th,
+                                                                         const int2* __restrict__ zint,
+                                                                         const unsigned* __restrict__ queue_all,
+                                                                         const unsigned* __restrict__ qcount,
+                                                                         unsigned qcap) {
+  if (!COUNT_ONLY && st->lost) return;
+  const int lane = threadIdx.x & 63;
+  // blockIdx.y = queue, blockIdx.x = one of gridDim.x blocks striding over it
+  const unsigned n = qcount[blockIdx.y * HSK_QCOUNT_STRIDE];
+  const unsigned* __restrict__ queue = queue_all + (size_t)blockIdx.y * qcap;
+  const unsigned stride = gridDim.x * blockDim.x;
+  unsigned long long cnt = 0;
+  const float tx = st->t[0], ty = st->t[1];
+  const float i00 = st->R[0], i01 = st->R[3], i10 = st->R[1], i11 = st->R[4], i20 = st->R[2], i21 = st->R[5];
+  IntegrateConst k;
+  k.i02 = st->R[6];
+  k.i12 = st->R[7];
+  k.i22 = st->R[8];
+  k.tz = st->t[2];
+  const float cellm = fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2]));
+  k.rk = 1.06f * 2.75f * cellm * fmaxf(in.fx, in.fy);
+  k.zmin = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk / ((float)HSK_TILE - 2.5f));
+  k.cull_thr = vp.tau * 1.001f + 1e-4f + 2.0f * vp.cell[0];
+  k.free_thr = vp.tau * 1.0002f + 1e-4f + 2.0f * vp.cell[0];
+  k.hw = 0.5f * (float)(W - 1);
+  k.hh = 0.5f * (float)(H - 1);
+  k.rk4 = k.zmin4 = k.cull_thr4 = k.free_thr4 = 0.0f;  // unused here
+  const int qx = vp.X / 4;
+  const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
+  const int bricks_x = vp.X >> vp.bshift, bricks_y = vp.Y >> vp.bshift;
+  for (unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < n; e0 += stride) {  // wave-uniform trip count
+    const unsigned e = e0 + lane;
+    const bool have = e < n;
+    const unsigned id = have ? queue[e] : 0u;
+    const int x0 = (int)(id % (unsigned)qx) * 4, y = (int)((id / (unsigned)qx) % (unsigned)vp.Y);
+    const int zb = (int)(id / ((unsigned)qx * (unsigned)vp.Y)) * 4;
+    const int2 zr = zint[(size_t)y * qx + (x0 >> 2)];
+    ColumnTerms c;
+    {
+      const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
+        c.ax[j] = i00 * gx + i01 * gy;
+        c.ay[j] = i10 * gx + i11 * gy;
+        c.az[j] = i20 * gx + i21 * gy;
+        c.pn[j] = gx * gx + gy * gy;
+      }
+      c.axfc = 0.5f * (c.ax[1] + c.ax[2]) * in.fx;
+      c.ayfc = 0.5f * (c.ay[1] + c.ay[2]) * in.fy;
+      c.azc = 0.5f * (c.az[1] + c.az[2]);
+      c.pnc = 0.5f * (c.pn[1] + c.pn[2]);
+    }
+    const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
+    bool in_range[4];
+    unsigned mask[4], one[4];
+    float F[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) in_range[u] = have && (zb + u) >= zr.x && (zb + u) <= zr.y && (zb + u) < vp.nzs;
+    classify_planes<4>(zb, in_range, c, k, vp, W, H, in, dtab, tw, th, scaled, mask, one, F);
+    if (COUNT_ONLY) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cnt += __popc(mask[u]);
+      continue;
+    }
+    uint4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (mask[u]) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!mask[u]) continue;
+      const int zz = zb + u;
+      const bool neg = update_vector(q[u], mask[u], one[u], F[u]);
+      vol[idx0 + (size_t)zz * plane_vec] = q[u];
+      if (neg) {
+        const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
+        // test first: after the first frames the bit is already set and no atomic is issued (a stale read only
+        // costs a redundant OR)
+        if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
+          __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -448,23 +712,39 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax, int2* zint) {
+                      const float* tmax, int2* zint, unsigned* queue) {
   const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
   const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int ncols = (vp.X / 4) * vp.Y;
+  const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
+  float2* ftab = (float2*)(tmax + 4 * tw * th);  // behind the coarse tables in the same allocation
+  hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, ftab, fw, fh);
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks + dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, col_blocks,
                      tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
-  if (count_only)
+  // HSK_NQUEUES counters (one per 256-B line, cleared here), then HSK_NQUEUES queues of qcap entries each; a block
+  // of pass A holds at most 4 waves x 64 lanes x (zchunk / 4) blocks and every HSK_NQUEUES-th block shares a queue
+  unsigned* qcount = queue;
+  unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
+  const unsigned nblk = grid.x * grid.y * grid.z;
+  const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
+  (void)hipMemsetAsync(qcount, 0, (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE * 4, s);
+  const dim3 detail_grid(8, HSK_NQUEUES);  // 8 blocks stride over each queue
+  if (count_only) {
     hipLaunchKernelGGL((k_integrate<true, INTEGRATE_U>), grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint);
-  else
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
+    hipLaunchKernelGGL(k_integrate_detail<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
+                       counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
+  } else {
     hipLaunchKernelGGL((k_integrate<false, INTEGRATE_U>), grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
+    hipLaunchKernelGGL(k_integrate_detail<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
+                       counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
+  }
 }
 
 // rebuild the brick bitfield from a volume that was uploaded rather than integrated
