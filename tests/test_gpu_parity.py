@@ -348,3 +348,72 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
             assert_same_bits(e.t.download_map(3, level), ref.download_map(3, level), f"slab {r} model nmap {level}")
         e.t.close()
     ref.close()
+
+
+def _pose_err(p, gt):
+    dt = np.linalg.norm(p[:3, 3] - gt[:3, 3]) * 1000.0
+    ang = np.degrees(np.arccos(np.clip((np.trace(p[:3, :3].astype(np.float64).T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+    return dt, ang
+
+
+def test_config2_256_tracker_vs_oracle_and_truth(hsk, oracle, synth_frames):
+    """BASELINE configs[1]: 640x480 into 256^3, integrate + ICP + raycast; poses bit-identical to the oracle and
+    within the stated tolerance of the scripted ground truth: 3 mm / 0.1 deg"""
+    n = 256
+    ot = oracle.Tracker(oracle.default_config(n), omp=True)
+    trk = hsk.KinfuTracker(n=n)
+    for k in range(8):
+        gt, depth = synth_frames(k)
+        po, _ = ot.process(depth)
+        ph, ok = trk.process_frame(depth)
+        assert ok == (k > 0)
+        assert_same_bits(ph, po, f"pose frame {k}")
+        dt, ang = _pose_err(ph, gt)
+        assert dt < 3.0 and ang < 0.1, (k, dt, ang)
+    assert_same_bits(trk.download_tsdf(), ot.volume(), "256^3 tsdf after 8 frames")
+    trk.close()
+
+
+def test_noisy_stream_trajectory(hsk):
+    """SURVEY.md 8(d) noise run: sigma = 1.2 mm * (z / 1 m)^2 (seed 1234) + 2 % dropout (seed 5678); not a parity
+    test -- the tracker must stay locked: < 10 mm / 0.5 deg from ground truth over 40 frames at 256^3"""
+    trk = hsk.KinfuTracker(n=256)
+    rn, rd = np.random.default_rng(1234), np.random.default_rng(5678)
+    worst = (0.0, 0.0)
+    for k in range(40):
+        gt = hsk.synth_pose(k)
+        d = hsk.synth_depth(gt).astype(np.float64)
+        z = d / 1000.0
+        d = d + rn.normal(size=d.shape) * 1.2 * z * z
+        d[rd.random(d.shape) < 0.02] = 0
+        pose, ok = trk.process_frame(np.clip(np.rint(d), 0, 65535).astype(np.uint16))
+        assert ok == (k > 0), f"tracking lost at frame {k}"
+        dt, ang = _pose_err(pose, gt)
+        worst = (max(worst[0], dt), max(worst[1], ang))
+    assert worst[0] < 10.0 and worst[1] < 0.5, worst
+    trk.close()
+
+
+def test_1024_properties(hsk, synth_frames):
+    """BASELINE configs[3] volume (1024^3, 4 GiB) on one GPU: size-independent properties, nothing downloaded"""
+    trk = hsk.KinfuTracker(n=1024)
+    poses = []
+    for k in range(4):
+        gt, depth = synth_frames(k)
+        p, ok = trk.process_frame(depth)
+        assert ok == (k > 0)
+        dt, ang = _pose_err(p, gt)
+        assert dt < 3.0 and ang < 0.1, (k, dt, ang)
+        poses.append(p)
+    gt, depth = synth_frames(3)
+    n_upd = trk.count_updates(depth, poses[-1])
+    assert 0.1 * 1024 ** 3 < n_upd < 0.6 * 1024 ** 3
+    vm, nm = trk.raycast(poses[-1])
+    R, t = poses[-1][:3, :3], poses[-1][:3, 3]
+    z_cam = np.einsum("i,ihw->hw", R[:, 2], vm - t[:, None, None])       # camera-frame z of the model vertex
+    valid = ~np.isnan(z_cam) & (depth > 0)
+    assert valid.mean() > 0.6
+    assert np.median(np.abs(z_cam[valid] * 1000.0 - depth[valid])) < 3.0   # one 2.93 mm cell
+    pts, total = trk.extract_cloud(cap=100000)
+    assert total > 500000 and np.isfinite(pts).all()
+    trk.close()
