@@ -839,6 +839,7 @@ static __device__ __forceinline__ int vox_fast(float p, float cell, float inv_ce
 #define RC_BLOCK 512    // 8 waves share one staged copy of the 32 KiB bitfield: all 4800 waves of a 640x480 frame are
                         // resident at once (with 256-thread blocks only 4096 fit and a second round formed the tail)
 #define RC_STAGE_MAX 4  // 16-B loads per thread: 32 KiB / (512 x 16 B)
+template <bool SLAB>  // SLAB: this context stores / owns only part of the z range (multi-GPU)
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
                                                  VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
                                                  float* __restrict__ nmap, int* __restrict__ keys,
@@ -909,20 +910,31 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     int px = qx < 0 ? 0 : (qx > vp.X - 1 ? vp.X - 1 : qx);
     int py = qy < 0 ? 0 : (qy > vp.Y - 1 ? vp.Y - 1 : qy);
     int pz = qz < 0 ? 0 : (qz > vp.Z - 1 ? vp.Z - 1 : qz);
-    bool have_prev = false;  // fl_prev is the brick flag of the current near sample
     bool crossing = false;
     int nux = 0, nuy = 0, nuz = 0;  // unclamped voxel of the near sample at the crossing
-    unsigned fl_prev = 0;
+    // brick flag of a voxel inside the grid (0 when its plane is not stored by this slab)
+    auto flag_at = [&](int vx_, int vy_, int vz_) -> unsigned {
+      const int zz = SLAB ? vz_ - vp.zs0 : vz_;
+      const bool stored = !SLAB || (zz >= 0 && zz < vp.nzs);
+      const int bf = __mul24(__mul24(stored ? (zz >> bs) : 0, byn) + (vy_ >> bs), bxn) + (vx_ >> bs);
+      const unsigned w = lflags[bf >> 5];
+      return stored ? ((w >> (bf & 31)) & 1u) : 0u;
+    };
+    unsigned fl_prev = flag_at(px, py, pz);  // always the flag of the current near sample
+    // Voxel of a sample: the spec's floor(p / cell).  q = p * (1 / cell) differs from the correctly rounded quotient
+    // by < 3 * 2^-24 * |q|, so both have the same floor unless q lies within eps of an integer -- for every q inside
+    // or within a voxel of the grid; a sample farther out is outside the grid either way (its error is relative).
+    const float eps = 3.0e-7f * (float)max(vp.X, max(vp.Y, vp.Z)) + 1.0e-5f;
+    bool first = true;  // the near sample of the first step is the (clamped) entry voxel; qx,qy,qz hold it unclamped
     for (; time_curr < max_time; time_curr = time_curr + time_step, ++step) {
       const float tn = time_curr + time_step;
       const float pnx = t0 + d0 * tn, pny = t1 + d1 * tn, pnz = t2 + d2 * tn;
-      // voxel of the far sample: floor(p / cell) of the spec; the products q = p * (1/cell) give the same floor
-      // unless one of them sits within 2.5e-4 of an integer (see vox_fast), checked for the three axes at once
       const float q0 = pnx * ic0, q1 = pny * ic1, q2 = pnz * ic2;
-      float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
-      const float e = fminf(fminf(fabsf(q0 - rintf(q0)), fabsf(q1 - rintf(q1))), fabsf(q2 - rintf(q2)));
-      const float m = fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fabsf(q2));
-      if (!(e > 2.5e-4f && m < 1100.0f)) {
+      const float r0 = __builtin_amdgcn_fractf(q0), r1 = __builtin_amdgcn_fractf(q1), r2 = __builtin_amdgcn_fractf(q2);
+      float f0 = q0 - r0, f1 = q1 - r1, f2 = q2 - r2;  // floor
+      // distance of the fractional parts from 1/2: far from 1/2 means close to an integer
+      const float far_from_half = fmaxf(fmaxf(fabsf(r0 - 0.5f), fabsf(r1 - 0.5f)), fabsf(r2 - 0.5f));
+      if (!(far_from_half < 0.5f - eps)) {  // rare (or NaN): the exact floor(p / cell) of the spec
         f0 = floorf(pnx / vp.cell[0]);
         f1 = floorf(pny / vp.cell[1]);
         f2 = floorf(pnz / vp.cell[2]);
@@ -930,26 +942,17 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
       // v_cvt_i32_f32 saturates; a negative or huge index fails the unsigned bound test below
       const int gx = (int)f0, gy = (int)f1, gz = (int)f2;
       if ((unsigned)gx >= (unsigned)vp.X || (unsigned)gy >= (unsigned)vp.Y || (unsigned)gz >= (unsigned)vp.Z) break;
-      const int cxv = px, cyv = py, czv = pz;  // near sample of this step (already inside the grid)
-      const int ux = qx, uy = qy, uz = qz;     // ... and its unclamped voxel (differs only at step 0)
+      const int cxv = px, cyv = py, czv = pz;  // near sample of this step (inside the grid)
+      const bool was_first = first;
+      const unsigned fl_near = fl_prev;
+      const unsigned fl_far = flag_at(gx, gy, gz);
       px = gx; py = gy; pz = gz;               // the far sample is the next step's near sample
-      qx = gx; qy = gy; qz = gz;
-      if (gz < vp.zo0 || gz >= vp.zo1) {       // step owned by another slab
-        have_prev = false;
-        continue;
-      }
-      // an event needs a negative sample: skip the voxel gathers when neither brick ever held one
-      const int bf = (((gz - vp.zs0) >> bs) * byn + (gy >> bs)) * bxn + (gx >> bs);
-      const unsigned fl_far = (lflags[bf >> 5] >> (bf & 31)) & 1u;
-      unsigned fl_near = fl_prev;
-      if (!have_prev) {
-        const int zzn = czv - vp.zs0;
-        const int bn = ((zzn >> bs) * byn + (cyv >> bs)) * bxn + (cxv >> bs);
-        fl_near = (zzn >= 0 && zzn < vp.nzs) ? ((lflags[bn >> 5] >> (bn & 31)) & 1u) : 0;
-      }
+      first = false;
       fl_prev = fl_far;
-      have_prev = true;
-      if (!(fl_far | fl_near)) continue;
+      // an event needs a negative sample: skip the voxel gathers when neither brick ever held one, and (slab mode)
+      // when the step belongs to another slab
+      const bool owned = !SLAB || (gz >= vp.zo0 && gz < vp.zo1);
+      if (!(owned && (fl_near | fl_far))) continue;
       const int raw_prev = raw_at(vol, vp, cxv, cyv, czv);
       const int raw = raw_at(vol, vp, gx, gy, gz);
       if (raw_prev < 0 && raw > 0) {  // back face
@@ -958,7 +961,9 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
       }
       if (raw_prev > 0 && raw < 0) {  // zero crossing: leave the loop, refine below with every lane of the wave
         crossing = true;
-        nux = ux; nuy = uy; nuz = uz;
+        nux = was_first ? qx : cxv;
+        nuy = was_first ? qy : cyv;
+        nuz = was_first ? qz : czv;
         break;
       }
     }
@@ -1005,8 +1010,13 @@ void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const 
   dim3 block(RC_BLOCK);
   dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
   const int words = hsk_flag_words(vp);
-  hipLaunchKernelGGL(k_raycast, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
-                     keys, flags, words);
+  const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
+  if (slab)
+    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
+                       keys, flags, words);
+  else
+    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap,
+                       nmap, keys, flags, words);
 }
 
 // ------------------------------------------------------------------------------------------------------
