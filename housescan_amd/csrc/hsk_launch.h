@@ -34,7 +34,6 @@ void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, 
                            int row1, double* partials);
 void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, double* out27);
 void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st);
-void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st);
 void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf);
 size_t icp_pose_bytes();
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,

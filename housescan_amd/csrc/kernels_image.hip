@@ -759,34 +759,6 @@ void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st) {
   hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, s, sums27, st);
 }
 
-// fused reduce + solve + update (single-device path): one block
-__global__ __launch_bounds__(256) void k_icp_reduce_update(const double* __restrict__ partials, int nblocks,
-                                                           TrackState* __restrict__ st) {
-  __shared__ double sh[8][32];
-  __shared__ double tot[27];
-  block_reduce27(partials, nblocks, sh, tot);
-  if (threadIdx.x == 0 && !st->lost) {
-    double s[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) s[k] = tot[k];
-    float x6[6];
-    if (!hsk_solve6(s, x6)) {
-      st->lost = 1;
-    } else {
-      float R[9], t[3];
-      for (int i = 0; i < 9; ++i) R[i] = st->R[i];
-      for (int i = 0; i < 3; ++i) t[i] = st->t[i];
-      hsk_pose_update(R, t, x6);
-      for (int i = 0; i < 9; ++i) st->R[i] = R[i];
-      for (int i = 0; i < 3; ++i) st->t[i] = t[i];
-      st->n_iter += 1;
-    }
-  }
-}
-void launch_icp_reduce_update(hipStream_t s, const double* partials, int nblocks, TrackState* st) {
-  hipLaunchKernelGGL(k_icp_reduce_update, dim3(1), dim3(256), 0, s, partials, nblocks, st);
-}
-
 // ---- fused ICP iteration (single-device path) -------------------------------------------------------------
 // Iteration i: every block first reduces the partials of iteration i-1 and solves for the pose increment -- the
 // same deterministic arithmetic in every block, so all blocks agree -- then accumulates its pixels with the new

@@ -19,9 +19,6 @@
 // Bricks (8^3 voxels) that ever received a negative TSDF are flagged for the raycaster's empty-space test.
 // ------------------------------------------------------------------------------------------------------
 #define HSK_TILE 16
-#ifndef INTEGRATE_U
-#define INTEGRATE_U 1  // software-pipeline depth of k_integrate (1 measured fastest: profiles/r01/integrate_analysis.md)
-#endif
 #define HSK_NQUEUES 256       // uncertain lane-blocks are spread over this many queues (pass A -> pass B)
 #define HSK_QCOUNT_STRIDE 64  // words between two queue counters (256 B: one counter per memory-side atomic line)
 #ifndef INTEGRATE_WPE
@@ -168,101 +165,11 @@ struct IntegrateConst {
   float rk4, zmin4, cull_thr4, free_thr4;  // the same for a 4-plane block (voxels within 2.2 cells of its centre)
 };
 
-// Phases 0-2b for ONE plane: which of the lane's 4 voxels are rewritten (mask), which of those with F == 1
-// (one), and F for the others.  Branch-free inside, guarded by wave-uniform ballots; the correctly rounded
-// division / square root of the spec run only for voxels flagged as sitting on a decision boundary.
-static __device__ __forceinline__ void classify_plane(int zz, bool in_range, const ColumnTerms& c,
-                                                      const IntegrateConst& k, const VolParams& vp, int W, int H,
-                                                      const Intr& in, const float2* __restrict__ dtab, int tw, int th,
-                                                      const float* __restrict__ scaled, unsigned& mask, unsigned& one,
-                                                      float F[4]) {
-  mask = 0;
-  one = 0;
-  const float gz = ((float)(vp.zs0 + zz) + 0.5f) * vp.cell[2] - k.tz;
-  const float gz2 = gz * gz;
-  // ---- phase 0: classify the 4-voxel group against the tile table (conservative):
-  //      dead  -- nearest possible point farther than the largest depth around its pixels + tau,
-  //      free4 -- farthest possible point closer than the smallest (all-valid) depth around - tau,
-  //      detail otherwise.
-  const float czc = c.azc + k.i22 * gz;
-  const float rc = __builtin_amdgcn_rcpf(czc);
-  const float uc = (c.axfc + (k.i02 * gz) * in.fx) * rc + in.cx;
-  const float vc = (c.ayfc + (k.i12 * gz) * in.fy) * rc + in.cy;
-  const float r = k.rk * rc + 2.5f;
-  const bool ok = czc > k.zmin && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
-  const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
-  const float2 D = dtab[tv * tw + tu];
-  const float dc = __builtin_amdgcn_sqrtf(gz2 + c.pnc);
-  const bool dead = !in_range || (ok && (dc * 0.99999f - D.x > k.cull_thr));
-  const bool fr = in_range && ok && (dc * 1.00001f + k.free_thr <= D.y);
-  const bool detail = !dead && !fr;
-  if (fr) mask = one = 0xFu;
-  if (__ballot(detail) == 0ull) return;  // no lane of the wave needs voxel detail in this plane
-  // ---- phase 1: project (v_rcp_f32 instead of the division: moves the coordinate by < 1.6e-4 px)
-  const float bx = k.i02 * gz, by = k.i12 * gz, bz = k.i22 * gz;
-  int pix[4];
-  unsigned nearb = 0;  // bit j: pixel coordinate within 3e-4 px of a rounding boundary
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float camz = c.az[j] + bz;
-    const float inv_a = __builtin_amdgcn_rcpf(camz);
-    const float fu = ((c.ax[j] + bx) * in.fx) * inv_a + in.cx;
-    const float fv = ((c.ay[j] + by) * in.fy) * inv_a + in.cy;
-    const float ru = rintf(fu), rv = rintf(fv);
-    const int uu = (int)ru, vv = (int)rv;  // saturating conversion
-    const bool front = detail && camz > 0.0f && fabsf(fu) < 1.0e5f && fabsf(fv) < 1.0e5f;
-    const bool inb = front && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
-    const bool nb = front && fmaxf(fabsf(fu - ru), fabsf(fv - rv)) > 0.5f - 3.0e-4f;
-    pix[j] = inb ? vv * W + uu : -1;
-    nearb |= (nb ? 1u : 0u) << j;
-  }
-  if (nearb) {  // the correctly rounded division of the spec, only where it can change the pixel
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (nearb & (1u << j)) {
-        const float inv_z = 1.0f / (c.az[j] + bz);
-        const float fu = ((c.ax[j] + bx) * in.fx) * inv_z + in.cx;
-        const float fv = ((c.ay[j] + by) * in.fy) * inv_z + in.cy;
-        int uu, vv;
-        pix[j] = (hsk_rint_guard(fu, uu) && hsk_rint_guard(fv, vv) && uu >= 0 && vv >= 0 && uu < W && vv < H) ? vv * W + uu
-                                                                                                            : -1;
-      }
-  }
-  // ---- phase 2: depth gathers, all in flight together (pixel 0 stands in for "no pixel")
-#pragma unroll
-  for (int j = 0; j < 4; ++j) F[j] = scaled[max(pix[j], 0)];
-  // ---- phase 2b: classify with v_sqrt_f32 (moves sdf by < 1e-6 m); undecided voxels get the exact sdf
-  unsigned unsure = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float Ds = F[j];
-    const float sdf_a = Ds - __builtin_amdgcn_sqrtf(gz2 + c.pn[j]);
-    const bool val = pix[j] >= 0 && Ds != 0.0f;
-    const bool sure = val && sdf_a * vp.tau_inv > 1.0001f;
-    const bool maybe = val && !sure && sdf_a >= -vp.tau - 2.0e-6f;
-    mask |= (sure ? 1u : 0u) << j;
-    one |= (sure ? 1u : 0u) << j;
-    unsure |= (maybe ? 1u : 0u) << j;
-  }
-  if (unsure) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (unsure & (1u << j)) {
-        const float sdf = F[j] - sqrtf(gz2 + c.pn[j]);
-        if (sdf >= -vp.tau) {
-          const float f = sdf * vp.tau_inv;
-          mask |= 1u << j;
-          if (f < 1.0f)
-            F[j] = f;
-          else
-            one |= 1u << j;
-        }
-      }
-  }
-}
-
-// classify_plane for U consecutive planes at once, phase by phase, so that the U tile lookups, then the 4U depth
-// gathers, are in flight together (pass B is bound by the number of dependent memory round trips per entry).
+// Per-voxel classification of U consecutive planes of one lane column: which of the lane's 4 voxels per plane are
+// rewritten (mask), which of those with F == 1 (one), and F for the others.  Phase by phase, so that the U tile
+// lookups, then the 4U depth gathers, are in flight together; branch-free inside, guarded by wave-uniform ballots;
+// the correctly rounded division / square root of the spec run only for voxels flagged as sitting on a decision
+// boundary (v_rcp_f32 moves a pixel coordinate by < 1.6e-4 px, v_sqrt_f32 moves sdf by < 1e-6 m).
 template <int U>
 static __device__ __forceinline__ void classify_planes(int zz0, const bool* in_range, const ColumnTerms& c,
                                                        const IntegrateConst& k, const VolParams& vp, int W, int H,
@@ -437,8 +344,8 @@ static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, un
   return neg;
 }
 
-// The integrate kernel (the template parameter D is unused since the two-level loop replaced the pipelined one).
-template <bool COUNT_ONLY, int D>
+// Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
+template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
                                                    const TrackState* __restrict__ st, VolParams vp, int W, int H,
                                                    Intr in, int zchunk, unsigned long long* __restrict__ counter,
@@ -735,12 +642,12 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   (void)hipMemsetAsync(qcount, 0, (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE * 4, s);
   const dim3 detail_grid(8, HSK_NQUEUES);  // 8 blocks stride over each queue
   if (count_only) {
-    hipLaunchKernelGGL((k_integrate<true, INTEGRATE_U>), grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
+    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
     hipLaunchKernelGGL(k_integrate_detail<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
   } else {
-    hipLaunchKernelGGL((k_integrate<false, INTEGRATE_U>), grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
+    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
     hipLaunchKernelGGL(k_integrate_detail<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
