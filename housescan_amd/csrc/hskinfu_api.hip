@@ -40,7 +40,7 @@ struct hsk_ctx {
   double* d_partials2 = nullptr;  // ping-pong partner of d_partials (fused ICP iterations)
   void* d_icp_pose = nullptr;     // two IcpPose slots
   double* d_sums = nullptr;
-  float* d_ws = nullptr;
+  float h_ws[169] = {};  // bilateral spatial weights (host copy: passed to the kernel by value)
   float* d_wc = nullptr;
   int* d_keys = nullptr;
   unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
@@ -165,7 +165,6 @@ static void free_all(hsk_ctx* k) {
   F(k->d_partials2);
   F(k->d_icp_pose);
   F(k->d_sums);
-  F(k->d_ws);
   F(k->d_wc);
   F(k->d_keys);
   F(k->d_flags);
@@ -294,7 +293,6 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipMalloc((void**)&k->d_partials2, (size_t)nb0 * 27 * sizeof(double)));
   CK(hipMalloc(&k->d_icp_pose, icp_pose_bytes()));
   CK(hipMalloc((void**)&k->d_sums, 27 * sizeof(double)));
-  CK(hipMalloc((void**)&k->d_ws, 169 * 4));
   CK(hipMalloc((void**)&k->d_wc, 512 * 4));
   CK(hipMalloc((void**)&k->d_keys, P0 * 4));
   vp.bshift = 3;
@@ -317,7 +315,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   {
     float ws[169], wc[512];
     hsk_bilateral_tables(ws, wc);
-    CK(hipMemcpy(k->d_ws, ws, sizeof(ws), hipMemcpyHostToDevice));
+    memcpy(k->h_ws, ws, sizeof(ws));
     CK(hipMemcpy(k->d_wc, wc, sizeof(wc), hipMemcpyHostToDevice));
   }
   for (auto& e : k->ev) CK(hipEventCreate(&e));
@@ -363,7 +361,7 @@ extern "C" int hsk_synchronize(hsk_ctx* k) {
 // ------------------------------------------------------------------------------------------------------
 static void enqueue_preprocess(hsk_ctx* k) {
   hipStream_t s = k->stream;
-  launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_ws, k->d_wc, k->d_dep[0], k->d_scaled,
+  launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->h_ws, k->d_wc, k->d_dep[0], k->d_scaled,
                          k->d_tmax);
   for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_dep[l]);
   launch_vmap_nmap_pyramid(s, k->d_dep, k->lv, k->d_vcur, k->d_ncur);

@@ -13,14 +13,16 @@
 #define BIL_T 16
 #define BIL_S (BIL_T + 2 * BIL_R)
 
+struct BilateralWs {
+  float w[13 * 13];  // spatial weights: tap-position constants, passed by value so they sit in scalar registers
+};
 __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* __restrict__ src, int W, int H, Intr in,
-                                                         const float* __restrict__ ws_tab,
+                                                         BilateralWs ws,
                                                          const float* __restrict__ wc_tab,
                                                          unsigned short* __restrict__ dst, float* __restrict__ scaled,
                                                          float* __restrict__ tmax, float* __restrict__ tmin) {
   __shared__ int tile[BIL_S][BIL_S + 1];  // -1 marks "outside the image"
   __shared__ float shx[4], shn[4];
-  __shared__ float ws[13 * 13];
   __shared__ float wc[512];
   const int tid = threadIdx.y * BIL_T + threadIdx.x;
   const int bx = blockIdx.x * BIL_T, by = blockIdx.y * BIL_T;
@@ -29,7 +31,6 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
     const int gx = bx + lx - BIL_R, gy = by + ly - BIL_R;
     tile[ly][lx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? (int)src[gy * W + gx] : -1;
   }
-  for (int i = tid; i < 169; i += 256) ws[i] = ws_tab[i];
   for (int i = tid; i < 512; i += 256) wc[i] = wc_tab[i];
   __syncthreads();
   const int x = bx + threadIdx.x, y = by + threadIdx.y;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
     return;
   }
   float sum1 = 0.0f, sum2 = 0.0f;
+#pragma unroll
   for (int dy = 0; dy < 13; ++dy) {
 #pragma unroll
     for (int dx = 0; dx < 13; ++dx) {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
         int dd = value - tmp;
         dd = dd < 0 ? -dd : dd;
         const float wcv = dd < 512 ? wc[dd] : 0.0f;
-        const float w = ws[dy * 13 + dx] * wcv;
+        const float w = ws.w[dy * 13 + dx] * wcv;
         sum1 = sum1 + (float)tmp * w;
         sum2 = sum2 + w;
       }
@@ -92,7 +94,9 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
 void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
                             uint16_t* dst, float* scaled, float* tiles) {
   dim3 block(BIL_T, BIL_T), grid((W + BIL_T - 1) / BIL_T, (H + BIL_T - 1) / BIL_T);
-  hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, ws, wc, dst, scaled, tiles,
+  BilateralWs wsv;
+  for (int i = 0; i < 169; ++i) wsv.w[i] = ws[i];  // ws: HOST pointer to the 13x13 table
+  hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, wsv, wc, dst, scaled, tiles,
                      tiles + grid.x * grid.y);
 }
 
@@ -655,7 +659,7 @@ __host__ __device__ static inline void hsk_sincos(double x, double* s, double* c
 }
 
 __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6) {
-  double A[6][6], b[6], L[6][6];
+  double A[6][6], b[6], L[6][6], D[6];
   int k = 0;
   for (int i = 0; i < 6; ++i)
     for (int j = i; j < 7; ++j) {
@@ -669,33 +673,33 @@ __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6)
     }
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+  // LDL^T (unit lower L, diagonal D) with one reciprocal per pivot: no square roots on the dependent chain
   double det = 1.0;
-  double inv[6];
+  double dinv[6];
   for (int j = 0; j < 6; ++j) {
-    double s = A[j][j];
-    for (int q = 0; q < j; ++q) s = s - L[j][q] * L[j][q];
-    if (!(s > 0.0)) return false;
-    const double d = sqrt(s);
-    L[j][j] = d;
-    inv[j] = 1.0 / d;
-    det = det * s;
+    double dj = A[j][j];
+    for (int q = 0; q < j; ++q) dj = dj - (L[j][q] * L[j][q]) * D[q];
+    if (!(dj > 0.0)) return false;
+    D[j] = dj;
+    dinv[j] = 1.0 / dj;
+    det = det * dj;
     for (int i = j + 1; i < 6; ++i) {
       double r = A[i][j];
-      for (int q = 0; q < j; ++q) r = r - L[i][q] * L[j][q];
-      L[i][j] = r * inv[j];
+      for (int q = 0; q < j; ++q) r = r - (L[i][q] * L[j][q]) * D[q];
+      L[i][j] = r * dinv[j];
     }
   }
   if (!(det >= 1e-15)) return false;
   double yv[6], xv[6];
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < 6; ++i) {  // L y = b
     double r = b[i];
     for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
-    yv[i] = r * inv[i];
+    yv[i] = r;
   }
-  for (int i = 5; i >= 0; --i) {
-    double r = yv[i];
+  for (int i = 5; i >= 0; --i) {  // L^T x = D^-1 y
+    double r = yv[i] * dinv[i];
     for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
-    xv[i] = r * inv[i];
+    xv[i] = r;
   }
   for (int q = 0; q < 6; ++q) {
     if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) return false;

@@ -418,23 +418,24 @@ int ora_icp_solve(const double in27[27], float x6[6]) {
       }
     }
   memset(L, 0, sizeof(L));
+  /* LDL^T (unit lower L, diagonal D), one reciprocal per pivot; numerically equivalent to the Cholesky (LL^T) of
+   * A.5, without square roots on the dependent chain */
   double det = 1.0;
-  double inv[6]; /* one reciprocal per pivot; every later "divide by L[j][j]" is a multiply by it */
+  double D[6], dinv[6];
   for (int j = 0; j < 6; ++j) {
-    double s = A[j][j];
-    for (int q = 0; q < j; ++q) s = s - L[j][q] * L[j][q];
-    if (!(s > 0.0)) {
+    double dj = A[j][j];
+    for (int q = 0; q < j; ++q) dj = dj - (L[j][q] * L[j][q]) * D[q];
+    if (!(dj > 0.0)) {
       for (int q = 0; q < 6; ++q) x6[q] = 0.0f;
       return 0;
     }
-    const double d = sqrt(s);
-    L[j][j] = d;
-    inv[j] = 1.0 / d;
-    det = det * s;
+    D[j] = dj;
+    dinv[j] = 1.0 / dj;
+    det = det * dj;
     for (int i = j + 1; i < 6; ++i) {
       double r = A[i][j];
-      for (int q = 0; q < j; ++q) r = r - L[i][q] * L[j][q];
-      L[i][j] = r * inv[j];
+      for (int q = 0; q < j; ++q) r = r - (L[i][q] * L[j][q]) * D[q];
+      L[i][j] = r * dinv[j];
     }
   }
   if (!(det >= 1e-15)) { /* also catches NaN */
@@ -442,15 +443,15 @@ int ora_icp_solve(const double in27[27], float x6[6]) {
     return 0;
   }
   double yv[6], xv[6];
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < 6; ++i) { /* L y = b */
     double r = b[i];
     for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
-    yv[i] = r * inv[i];
+    yv[i] = r;
   }
-  for (int i = 5; i >= 0; --i) {
-    double r = yv[i];
+  for (int i = 5; i >= 0; --i) { /* L^T x = D^-1 y */
+    double r = yv[i] * dinv[i];
     for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
-    xv[i] = r * inv[i];
+    xv[i] = r;
   }
   for (int q = 0; q < 6; ++q) {
     if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) {
