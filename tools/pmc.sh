@@ -4,7 +4,7 @@
 # usage: tools/pmc.sh <outdir> [bench args...]
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-mkdir -p $ROOT/$OUT
+rm -rf $ROOT/$OUT/p[0-9]*; mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

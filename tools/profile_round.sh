@@ -5,7 +5,7 @@
 #   gpurun_out/round/pmc/...              FETCH_SIZE / WRITE_SIZE / SQ passes (separate runs) + integrate_traffic.json
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/round
-mkdir -p $OUT
+rm -rf $OUT/trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
