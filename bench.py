@@ -174,7 +174,8 @@ def main():
         achieved = alg_bytes / t_int / 1e9
         sweep = 8.0 * n ** 3 / t_int / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_integrate<false> (+ k_column_zrange pre-pass, same event pair)",
+            "bound": "hbm",
+            "kernel": "integrate stage: k_column_zrange + k_integrate<false> (pass A) + k_integrate_detail<false> (pass B), one event pair",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n),
             "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
