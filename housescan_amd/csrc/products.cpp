@@ -65,3 +65,217 @@ extern "C" int hsk_voxel_downsample(const float* xyz, size_t n, float leaf, floa
   *n_out = m;
   return HSK_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Plane detection on the fused cloud: what HouseScan's loadRoom consumes beside the cloud --
+//   <room>/planes.txt               one plane per line "a b c d" in PCL form ax + by + cz + d = 0
+//                                   (parsed by planeEqsFromFile, housescan/Main.hs:1379-1389, which negates d)
+//   <room>/cloud_plane_hull<k>.pcd  polygon vertices of plane k in drawing order (Main.hs:1395-1400, :758-763)
+// Deterministic sequential RANSAC (fixed-seed LCG) + PCA refit + 2-D convex hull of the inliers.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+struct Lcg {
+  uint64_t s;
+  uint32_t next() {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(s >> 33);
+  }
+};
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 matrix (cyclic Jacobi)
+void smallest_eigvec(double A[3][3], double n[3]) {
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 32; ++sweep) {
+    double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (std::fabs(A[p][q]) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int m = 0;
+  if (A[1][1] < A[m][m]) m = 1;
+  if (A[2][2] < A[m][m]) m = 2;
+  for (int k = 0; k < 3; ++k) n[k] = V[k][m];
+}
+}  // namespace
+
+// planes_abcd: up to max_planes x 4 floats (unit normal a,b,c and d of ax+by+cz+d=0); labels (optional, n ints):
+// index of the plane a point was assigned to, or -1.  Planes are reported in detection order (largest first).
+extern "C" int hsk_detect_planes(const float* xyz, size_t n, float dist_thresh, float min_fraction, int max_planes,
+                                 int iterations, float* planes_abcd, int* labels, int* n_planes) {
+  if (!xyz || !planes_abcd || !n_planes || max_planes <= 0 || !(dist_thresh > 0.0f) || iterations <= 0) return HSK_ERR_ARG;
+  std::vector<int> lab(n, -1);
+  std::vector<uint32_t> rest(n);
+  for (size_t i = 0; i < n; ++i) rest[i] = (uint32_t)i;
+  Lcg rng{0x9E3779B97F4A7C15ull};
+  const size_t min_inl = (size_t)std::max(3.0, (double)min_fraction * (double)n);
+  int found = 0;
+  while (found < max_planes && rest.size() >= std::max<size_t>(min_inl, 3)) {
+    // score candidates on a bounded subsample of the remaining points
+    const size_t m = rest.size();
+    const size_t stride = std::max<size_t>(1, m / 20000);
+    double best_n[3] = {0, 0, 1}, best_d = 0;
+    size_t best_cnt = 0;
+    for (int it = 0; it < iterations; ++it) {
+      const float* p0 = xyz + 3 * (size_t)rest[rng.next() % m];
+      const float* p1 = xyz + 3 * (size_t)rest[rng.next() % m];
+      const float* p2 = xyz + 3 * (size_t)rest[rng.next() % m];
+      const double u[3] = {(double)p1[0] - p0[0], (double)p1[1] - p0[1], (double)p1[2] - p0[2]};
+      const double v[3] = {(double)p2[0] - p0[0], (double)p2[1] - p0[1], (double)p2[2] - p0[2]};
+      double nn[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+      const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+      if (len < 1e-9) continue;
+      for (double& c : nn) c /= len;
+      const double d = -(nn[0] * p0[0] + nn[1] * p0[1] + nn[2] * p0[2]);
+      size_t cnt = 0;
+      for (size_t i = 0; i < m; i += stride) {
+        const float* p = xyz + 3 * (size_t)rest[i];
+        if (std::fabs(nn[0] * p[0] + nn[1] * p[1] + nn[2] * p[2] + d) <= dist_thresh) ++cnt;
+      }
+      if (cnt > best_cnt) {
+        best_cnt = cnt;
+        best_d = d;
+        best_n[0] = nn[0];
+        best_n[1] = nn[1];
+        best_n[2] = nn[2];
+      }
+    }
+    if (best_cnt * stride < min_inl) break;
+    // refit twice by PCA on the inliers of the current estimate
+    for (int pass = 0; pass < 2; ++pass) {
+      double mean[3] = {0, 0, 0};
+      size_t cnt = 0;
+      for (uint32_t idx : rest) {
+        const float* p = xyz + 3 * (size_t)idx;
+        if (std::fabs(best_n[0] * p[0] + best_n[1] * p[1] + best_n[2] * p[2] + best_d) <= dist_thresh) {
+          mean[0] += p[0];
+          mean[1] += p[1];
+          mean[2] += p[2];
+          ++cnt;
+        }
+      }
+      if (cnt < 3) break;
+      for (double& c : mean) c /= (double)cnt;
+      double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (uint32_t idx : rest) {
+        const float* p = xyz + 3 * (size_t)idx;
+        if (std::fabs(best_n[0] * p[0] + best_n[1] * p[1] + best_n[2] * p[2] + best_d) <= dist_thresh) {
+          const double q[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) C[a][b] += q[a] * q[b];
+        }
+      }
+      double nn[3];
+      smallest_eigvec(C, nn);
+      const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+      if (len < 1e-12) break;
+      for (int a = 0; a < 3; ++a) best_n[a] = nn[a] / len;
+      best_d = -(best_n[0] * mean[0] + best_n[1] * mean[1] + best_n[2] * mean[2]);
+    }
+    // assign and remove the inliers
+    std::vector<uint32_t> keep;
+    keep.reserve(rest.size());
+    size_t cnt = 0;
+    for (uint32_t idx : rest) {
+      const float* p = xyz + 3 * (size_t)idx;
+      if (std::fabs(best_n[0] * p[0] + best_n[1] * p[1] + best_n[2] * p[2] + best_d) <= dist_thresh) {
+        lab[idx] = found;
+        ++cnt;
+      } else {
+        keep.push_back(idx);
+      }
+    }
+    if (cnt < min_inl) {  // the refit lost the support: undo and stop
+      for (int& l : lab)
+        if (l == found) l = -1;
+      break;
+    }
+    planes_abcd[4 * found + 0] = (float)best_n[0];
+    planes_abcd[4 * found + 1] = (float)best_n[1];
+    planes_abcd[4 * found + 2] = (float)best_n[2];
+    planes_abcd[4 * found + 3] = (float)best_d;
+    ++found;
+    rest.swap(keep);
+  }
+  if (labels)
+    for (size_t i = 0; i < n; ++i) labels[i] = lab[i];
+  *n_planes = found;
+  return HSK_OK;
+}
+
+// Convex hull (in the plane, counter-clockwise about the normal) of the points labelled `plane`; hull_xyz gets up
+// to cap vertices lying exactly on the plane.
+extern "C" int hsk_plane_hull(const float* xyz, size_t n, const int* labels, int plane, const float abcd[4], float* hull_xyz,
+                              size_t cap, size_t* n_hull) {
+  if (!xyz || !labels || !abcd || !n_hull) return HSK_ERR_ARG;
+  const double nn[3] = {abcd[0], abcd[1], abcd[2]};
+  // orthonormal basis (e1, e2) of the plane
+  double a[3] = {1, 0, 0};
+  if (std::fabs(nn[0]) > 0.9) {
+    a[0] = 0;
+    a[1] = 1;
+  }
+  double e1[3] = {a[1] * nn[2] - a[2] * nn[1], a[2] * nn[0] - a[0] * nn[2], a[0] * nn[1] - a[1] * nn[0]};
+  const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  for (double& c : e1) c /= l1;
+  const double e2[3] = {nn[1] * e1[2] - nn[2] * e1[1], nn[2] * e1[0] - nn[0] * e1[2], nn[0] * e1[1] - nn[1] * e1[0]};
+  struct P2 {
+    double x, y;
+  };
+  std::vector<P2> pts;
+  for (size_t i = 0; i < n; ++i)
+    if (labels[i] == plane) {
+      const float* p = xyz + 3 * i;
+      pts.push_back({e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2], e2[0] * p[0] + e2[1] * p[1] + e2[2] * p[2]});
+    }
+  *n_hull = 0;
+  if (pts.size() < 3) return HSK_OK;
+  std::sort(pts.begin(), pts.end(), [](const P2& u, const P2& v) { return u.x != v.x ? u.x < v.x : u.y < v.y; });
+  auto cross = [](const P2& o, const P2& u, const P2& v) { return (u.x - o.x) * (v.y - o.y) - (u.y - o.y) * (v.x - o.x); };
+  std::vector<P2> h(2 * pts.size());
+  size_t k = 0;
+  for (size_t i = 0; i < pts.size(); ++i) {  // Andrew's monotone chain
+    while (k >= 2 && cross(h[k - 2], h[k - 1], pts[i]) <= 0) --k;
+    h[k++] = pts[i];
+  }
+  for (size_t i = pts.size() - 1, t = k + 1; i > 0; --i) {
+    while (k >= t && cross(h[k - 2], h[k - 1], pts[i - 1]) <= 0) --k;
+    h[k++] = pts[i - 1];
+  }
+  h.resize(k > 1 ? k - 1 : k);
+  *n_hull = h.size();
+  const double off = -(double)abcd[3];  // points on the plane: x = u e1 + v e2 + off * n
+  for (size_t i = 0; i < h.size() && i < cap && hull_xyz; ++i)
+    for (int c = 0; c < 3; ++c) hull_xyz[3 * i + c] = (float)(h[i].x * e1[c] + h[i].y * e2[c] + off * nn[c]);
+  return HSK_OK;
+}
+
+// planes.txt in the format planeEqsFromFile parses (Main.hs:1379-1389): "a b c d" per line, lines separated by \n
+extern "C" int hsk_write_planes_txt(const char* path, const float* planes_abcd, int n_planes) {
+  if (!path || (!planes_abcd && n_planes)) return HSK_ERR_ARG;
+  FILE* f = fopen(path, "w");
+  if (!f) return HSK_ERR_STATE;
+  for (int i = 0; i < n_planes; ++i)
+    fprintf(f, "%.9g %.9g %.9g %.9g%s", planes_abcd[4 * i], planes_abcd[4 * i + 1], planes_abcd[4 * i + 2],
+            planes_abcd[4 * i + 3], i + 1 < n_planes ? "\n" : "");
+  return fclose(f) == 0 ? HSK_OK : HSK_ERR_STATE;
+}

@@ -128,6 +128,14 @@ int hsk_synth_render(const float pose[16], int w, int h, float fx, float fy, flo
 /* Products on the file seam (Main.hs:1740, :1320-1345): binary PCD with float32 x y z */
 int hsk_write_pcd_xyz(const char* path, const float* xyz, size_t n_points);
 int hsk_voxel_downsample(const float* xyz, size_t n, float leaf_m, float* out, size_t cap, size_t* n_out);
+/* Plane products loadRoom reads beside the cloud (Main.hs:1392-1404): planes.txt lines "a b c d" in PCL form
+ * ax+by+cz+d=0 (planeEqsFromFile, Main.hs:1379-1389) and cloud_plane_hull<k>.pcd polygons (Main.hs:1395-1400).
+ * Deterministic RANSAC + PCA refit; labels[i] = plane index of point i or -1. */
+int hsk_detect_planes(const float* xyz, size_t n, float dist_thresh_m, float min_fraction, int max_planes, int iterations,
+                      float* planes_abcd /* 4 * max_planes */, int* labels /* n, may be NULL */, int* n_planes);
+int hsk_plane_hull(const float* xyz, size_t n, const int* labels, int plane, const float abcd[4], float* hull_xyz,
+                   size_t cap, size_t* n_hull);
+int hsk_write_planes_txt(const char* path, const float* planes_abcd, int n_planes);
 
 #ifdef __cplusplus
 }

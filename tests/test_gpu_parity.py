@@ -3,6 +3,8 @@
 Bar: bit-exact for the int16 TSDF, the uint16 depth pyramid, the float maps (compared as bit patterns, NaN
 included), the 27 ICP sums (exact by the 2^-26 snapping) and the float poses.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -416,4 +418,20 @@ def test_1024_properties(hsk, synth_frames):
     assert np.median(np.abs(z_cam[valid] * 1000.0 - depth[valid])) < 3.0   # one 2.93 mm cell
     pts, total = trk.extract_cloud(cap=100000)
     assert total > 500000 and np.isfinite(pts).all()
+    trk.close()
+
+
+def test_room_products_from_fused_scan(tmp_path, hsk):
+    """scan -> TSDF -> cloud -> room directory for HouseScan's loadRoom: the detected planes are the scene's walls"""
+    from housescan_amd import products as P
+    trk = hsk.KinfuTracker(n=256)
+    for k in range(0, 120, 2):
+        trk.process_frame(hsk.synth_depth(hsk.synth_pose(k)))
+    cloud, total = trk.extract_cloud()
+    assert total == len(cloud) > 100000
+    planes, n_down = P.write_room_dir(str(tmp_path / "room"), cloud, leaf=0.03, dist_thresh=0.025, min_fraction=0.02)
+    walls = [(0, 0.2), (0, 2.8), (1, 0.3), (1, 2.7), (2, 2.8)]
+    for axis, coord in walls:
+        assert any(abs(p[axis]) > 0.99 and abs(-p[3] / p[axis] - coord) < 0.03 for p in planes), (axis, coord, planes)
+    assert os.path.exists(tmp_path / "room" / "cloud_plane_hull0.pcd") and n_down > 5000
     trk.close()

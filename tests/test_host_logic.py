@@ -55,3 +55,57 @@ def test_oracle_is_not_reachable_from_the_product(hsk):
             if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dp, f)).read()
                 assert "kinfu_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, (dp, f)
+
+
+def _box_cloud(rng):
+    def face(n, axis, val, lo, hi):
+        p = rng.uniform(lo, hi, size=(n, 3))
+        p[:, axis] = val + rng.normal(0, 0.002, n)
+        return p
+    return np.concatenate([
+        face(4000, 0, 0.2, [0, 0.3, 0], [0, 2.7, 2.8]), face(4000, 0, 2.8, [0, 0.3, 0], [0, 2.7, 2.8]),
+        face(5000, 1, 0.3, [0.2, 0, 0], [2.8, 0, 2.8]), face(5000, 1, 2.7, [0.2, 0, 0], [2.8, 0, 2.8]),
+        face(6000, 2, 2.8, [0.2, 0.3, 0], [2.8, 2.7, 0]), rng.uniform(0, 3, size=(800, 3))]).astype(np.float32)
+
+
+def _match_walls(planes, walls, tol=0.02):
+    """every expected wall (axis, coordinate) has a detected plane with |n.e| > 0.99 and the right offset"""
+    for axis, coord in walls:
+        ok = False
+        for a, b, c, d in planes:
+            n = np.array([a, b, c])
+            if abs(n[axis]) > 0.99 and abs(-d / n[axis] - coord) < tol:
+                ok = True
+        assert ok, (axis, coord, planes)
+
+
+def test_plane_detection_and_room_dir(tmp_path, hsk):
+    """the files HouseScan's loadRoom reads: cloud_downsampled.pcd, planes.txt ("a b c d" per line, PCL sign
+    convention -- /root/reference/housescan/Main.hs:1379-1389), cloud_plane_hull<k>.pcd"""
+    from housescan_amd import products as P
+    pts = _box_cloud(np.random.default_rng(0))
+    planes, labels = P.detect_planes(pts)
+    assert len(planes) == 5
+    assert np.allclose(np.linalg.norm(planes[:, :3], axis=1), 1, atol=1e-5)
+    _match_walls(planes, [(0, 0.2), (0, 2.8), (1, 0.3), (1, 2.7), (2, 2.8)], tol=0.005)
+    p2, l2 = P.detect_planes(pts)
+    assert np.array_equal(planes, p2) and np.array_equal(labels, l2)        # deterministic
+    room = tmp_path / "room1"
+    planes_w, n_down = P.write_room_dir(str(room), pts, leaf=0.05)
+    names = sorted(os.listdir(room))
+    assert "cloud_bin.pcd" in names and "cloud_downsampled.pcd" in names and "planes.txt" in names
+    # parse planes.txt the way planeEqsFromFile does: lines split on \n, four whitespace-separated decimals
+    lines = open(room / "planes.txt").read().split("\n")
+    parsed = np.array([[float(t) for t in ln.split()] for ln in lines])
+    assert parsed.shape == (len(planes_w), 4) and np.allclose(parsed, planes_w, atol=1e-6)
+    for k, eq in enumerate(planes_w):
+        raw = open(room / f"cloud_plane_hull{k}.pcd", "rb").read()
+        body = raw.split(b"DATA binary\n", 1)[1]
+        hull = np.frombuffer(body, np.float32).reshape(-1, 3)
+        assert len(hull) >= 4
+        assert np.abs(hull @ eq[:3] + eq[3]).max() < 1e-4        # vertices lie on the plane
+        # convex polygon in drawing order: all turns have the same orientation about the normal
+        e = np.roll(hull, -1, axis=0) - hull
+        turns = np.einsum("ij,j->i", np.cross(e, np.roll(e, -1, axis=0)), eq[:3])
+        assert (turns > -1e-6).all() or (turns < 1e-6).all()
+    assert 0 < n_down < len(pts)
