@@ -66,6 +66,7 @@ SYMBOLS = {
     "hsk_mgpu_frame_begin": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "hsk_mgpu_icp_accumulate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "hsk_mgpu_icp_update": (C.c_int, [_P, _P]),
+    "hsk_mgpu_icp_replicated": (C.c_int, [_P]),
     "hsk_mgpu_integrate": (C.c_int, [_P]),
     "hsk_mgpu_raycast_local": (C.c_int, [_P, _P]),
     "hsk_mgpu_raycast_resolve": (C.c_int, [_P, _P, _P]),

@@ -790,6 +790,15 @@ extern "C" int hsk_mgpu_icp_update(hsk_ctx* k, const void* sums27_dev) {
   return HSK_OK;
 }
 
+extern "C" int hsk_mgpu_icp_replicated(hsk_ctx* k) {
+  if (!k) return HSK_ERR_ARG;
+  if (k->frame == 0) return fail(k, HSK_ERR_STATE, "no model maps yet: the first frame has no ICP");
+  // hsk_mgpu_frame_begin ran k_begin_frame without seeding the pose ping-pong: seed it now, then the fused iterations
+  launch_begin_frame_seed_only(k->stream, k->d_st, k->d_icp_pose);
+  enqueue_icp(k);
+  return HSK_OK;
+}
+
 extern "C" int hsk_mgpu_integrate(hsk_ctx* k) {
   if (!k) return HSK_ERR_ARG;
   enqueue_integrate(k);

@@ -886,6 +886,21 @@ void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf) {
   hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, s, st, (IcpPose*)icp_pose_buf);
 }
 
+// pose ping-pong seed alone (slab mode: k_begin_frame already ran in hsk_mgpu_frame_begin)
+__global__ void k_icp_seed(const TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
+  if (threadIdx.x != 0) return;
+  IcpPose p;
+  for (int i = 0; i < 9; ++i) p.R[i] = st->R[i];
+  for (int i = 0; i < 3; ++i) p.t[i] = st->t[i];
+  p.lost = st->lost;
+  p.n_iter = 0;
+  p.pad[0] = p.pad[1] = 0;
+  *pose0 = p;
+}
+void launch_begin_frame_seed_only(hipStream_t s, const TrackState* st, void* icp_pose_buf) {
+  hipLaunchKernelGGL(k_icp_seed, dim3(1), dim3(64), 0, s, st, (IcpPose*)icp_pose_buf);
+}
+
 // host mirrors (used by hsk_icp_solve and by tests through the C ABI)
 bool host_solve6(const double* in27, float* x6) { return hsk_solve6(in27, x6); }
 void host_pose_update(float* R, float* t, const float* x6) { hsk_pose_update(R, t, x6); }

@@ -66,16 +66,19 @@ class SlabOrchestrator:
         e.frame_begin(depth)
         if first:
             return e.frame_end(None, None)
-        for level in range(LEVELS - 1, -1, -1):
-            h = self.H >> level
-            for _ in range(self.icp_iters[level]):
-                if self.icp == "allreduce" and self.coll:
-                    r0, r1 = row_range(self.rank, self.world, h)
-                    sums = e.icp_accumulate(level, r0, r1)
-                    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-                else:
-                    sums = e.icp_accumulate(level, 0, h)
-                e.icp_update(sums)
+        if self.icp == "replicated" and hasattr(e, "icp_replicated"):
+            e.icp_replicated()  # the engine runs all 19 iterations itself (fused kernels, no host round trips)
+        else:
+            for level in range(LEVELS - 1, -1, -1):
+                h = self.H >> level
+                for _ in range(self.icp_iters[level]):
+                    if self.icp == "allreduce" and self.coll:
+                        r0, r1 = row_range(self.rank, self.world, h)
+                        sums = e.icp_accumulate(level, r0, r1)
+                        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+                    else:
+                        sums = e.icp_accumulate(level, 0, h)
+                    e.icp_update(sums)
         e.integrate()
         keys = e.raycast_local()
         if self.coll:
@@ -115,6 +118,9 @@ class HipSlabEngine:
 
     def icp_update(self, sums):
         self._ck(self.lib.hsk_mgpu_icp_update(self.t.h, self.C.c_void_p(sums.data_ptr())))
+
+    def icp_replicated(self):
+        self._ck(self.lib.hsk_mgpu_icp_replicated(self.t.h))
 
     def integrate(self):
         self._ck(self.lib.hsk_mgpu_integrate(self.t.h))

@@ -102,6 +102,7 @@ int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_point
 int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, int h); /* preprocess + (frame 0) transform */
 int hsk_mgpu_icp_accumulate(hsk_ctx* k, int level, int row0, int row1, void* sums27_dev /* double[27] */);
 int hsk_mgpu_icp_update(hsk_ctx* k, const void* sums27_dev);                /* solve + pose update on device */
+int hsk_mgpu_icp_replicated(hsk_ctx* k); /* the whole 19-iteration ICP on this rank's (composited) maps, fused kernels */
 int hsk_mgpu_integrate(hsk_ctx* k);
 int hsk_mgpu_raycast_local(hsk_ctx* k, void* keys_dev /* int32[h*w] */);    /* slab-local march */
 int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, void* maps_bits_dev /* int32[6*h*w] */);

@@ -322,14 +322,18 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
         if first:
             outs = [e.frame_end(None, None) for e in engines]
         else:
-            for level in (2, 1, 0):
-                for _ in range([10, 5, 4][level]):
-                    # "allreduce" mode: each engine sums half of the rows, the sums are added exactly
-                    h = 480 >> level
-                    parts = [e.icp_accumulate(level, r * h // 2, (r + 1) * h // 2).clone() for r, e in enumerate(engines)]
-                    tot = parts[0] + parts[1]
-                    for e in engines:
-                        e.icp_update(tot)
+            if k % 2 == 1:
+                for e in engines:   # "replicated" mode: every slab context runs the fused 19-iteration ICP itself
+                    e.icp_replicated()
+            else:
+                for level in (2, 1, 0):
+                    for _ in range([10, 5, 4][level]):
+                        # "allreduce" mode: each engine sums half of the rows, the sums are added exactly
+                        h = 480 >> level
+                        parts = [e.icp_accumulate(level, r * h // 2, (r + 1) * h // 2).clone() for r, e in enumerate(engines)]
+                        tot = parts[0] + parts[1]
+                        for e in engines:
+                            e.icp_update(tot)
             for e in engines:
                 e.integrate()
             keys = [e.raycast_local().clone() for e in engines]
