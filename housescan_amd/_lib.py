@@ -85,6 +85,14 @@ SYMBOLS = {
     "hsk_detect_planes": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, _P, _P, _I]),
     "hsk_plane_hull": (C.c_int, [_P, C.c_size_t, _P, C.c_int, _F, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_write_planes_txt": (C.c_int, [C.c_char_p, _P, C.c_int]),
+    "hsk_write_xf": (C.c_int, [C.c_char_p, _F]),
+    "hsk_read_xf": (C.c_int, [C.c_char_p, _F]),
+    "hsk_transform_cloud": (C.c_int, [_P, C.c_size_t, _F, _P]),
+    "hsk_stream_create": (_P, [C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "hsk_stream_open": (_P, [C.c_char_p, _I, _I, _I, _F]),
+    "hsk_stream_write": (C.c_int, [_P, _P]),
+    "hsk_stream_read": (C.c_int, [_P, C.c_int, _P]),
+    "hsk_stream_close": (C.c_int, [_P]),
 }
 
 _lib = None

@@ -279,3 +279,118 @@ extern "C" int hsk_write_planes_txt(const char* path, const float* planes_abcd, 
             planes_abcd[4 * i + 3], i + 1 < n_planes ? "\n" : "");
   return fclose(f) == 0 ? HSK_OK : HSK_ERR_STATE;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Transforms on the seam back from HouseScan: HouseScan exports each room's placement as a
+// row-major, LEFT-multiplicative 4x4 -- as one CSV line for `pcl_transform_point_cloud -matrix`
+// (roomProjectionToString, housescan/Main.hs:2271-2284) and as a 4-line .xf file for `plyxform`
+// (roomProjectionToXfFormat, Main.hs:2289-2302).  These read/write both forms and apply them to a cloud.
+// ------------------------------------------------------------------------------------------------------
+extern "C" int hsk_write_xf(const char* path, const float m[16]) {
+  if (!path || !m) return HSK_ERR_ARG;
+  FILE* f = fopen(path, "w");
+  if (!f) return HSK_ERR_STATE;
+  for (int r = 0; r < 4; ++r) fprintf(f, "%.9g %.9g %.9g %.9g\n", m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
+  return fclose(f) == 0 ? HSK_OK : HSK_ERR_STATE;
+}
+
+// accepts the .xf layout (whitespace separated) and the CSV layout (comma separated): 16 numbers, row-major
+extern "C" int hsk_read_xf(const char* path, float m[16]) {
+  if (!path || !m) return HSK_ERR_ARG;
+  FILE* f = fopen(path, "r");
+  if (!f) return HSK_ERR_STATE;
+  int n = 0;
+  double v;
+  while (n < 16) {
+    int c = fgetc(f);
+    if (c == EOF) break;
+    if (c == ',' || c == ' ' || c == '\n' || c == '\t' || c == '\r') continue;
+    ungetc(c, f);
+    if (fscanf(f, "%lf", &v) != 1) break;
+    m[n++] = (float)v;
+  }
+  fclose(f);
+  return n == 16 ? HSK_OK : HSK_ERR_STATE;
+}
+
+// p' = M p for packed xyz points (in place allowed); w is assumed 1 and the last row (0 0 0 1)
+extern "C" int hsk_transform_cloud(const float* xyz, size_t n, const float m[16], float* out) {
+  if ((!xyz && n) || !m || (!out && n)) return HSK_ERR_ARG;
+  for (size_t i = 0; i < n; ++i) {
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    out[3 * i] = m[0] * x + m[1] * y + m[2] * z + m[3];
+    out[3 * i + 1] = m[4] * x + m[5] * y + m[6] * z + m[7];
+    out[3 * i + 2] = m[8] * x + m[9] * y + m[10] * z + m[11];
+  }
+  return HSK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Recorded depth streams: no OpenNI / .oni here, so the core has its own raw container.
+//   bytes 0..3 "HSKD", u32 version = 1, u32 width, u32 height, u32 n_frames, f32 fx, fy, cx, cy, then
+//   n_frames x (width*height) little-endian uint16 millimetres, row-major -- the frame layout of
+//   takeDepthSnapshot (housescan/HoniHelper.hs:20-36).
+// ------------------------------------------------------------------------------------------------------
+struct hsk_depth_stream {
+  FILE* f;
+  uint32_t w, h, n;
+  float intr[4];
+  bool writing;
+};
+
+extern "C" hsk_depth_stream* hsk_stream_create(const char* path, int w, int h, float fx, float fy, float cx, float cy) {
+  if (!path || w <= 0 || h <= 0) return nullptr;
+  FILE* f = fopen(path, "wb");
+  if (!f) return nullptr;
+  hsk_depth_stream* s = new hsk_depth_stream{f, (uint32_t)w, (uint32_t)h, 0, {fx, fy, cx, cy}, true};
+  const uint32_t hdr[5] = {0x444B5348u /* "HSKD" */, 1u, s->w, s->h, 0u};
+  fwrite(hdr, 4, 5, f);
+  fwrite(s->intr, 4, 4, f);
+  return s;
+}
+
+extern "C" hsk_depth_stream* hsk_stream_open(const char* path, int* w, int* h, int* n_frames, float intr[4]) {
+  if (!path) return nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return nullptr;
+  uint32_t hdr[5];
+  float in4[4];
+  if (fread(hdr, 4, 5, f) != 5 || fread(in4, 4, 4, f) != 4 || hdr[0] != 0x444B5348u || hdr[1] != 1u) {
+    fclose(f);
+    return nullptr;
+  }
+  hsk_depth_stream* s = new hsk_depth_stream{f, hdr[2], hdr[3], hdr[4], {in4[0], in4[1], in4[2], in4[3]}, false};
+  if (w) *w = (int)s->w;
+  if (h) *h = (int)s->h;
+  if (n_frames) *n_frames = (int)s->n;
+  if (intr)
+    for (int i = 0; i < 4; ++i) intr[i] = in4[i];
+  return s;
+}
+
+extern "C" int hsk_stream_write(hsk_depth_stream* s, const uint16_t* depth) {
+  if (!s || !s->writing || !depth) return HSK_ERR_ARG;
+  const size_t px = (size_t)s->w * s->h;
+  if (fwrite(depth, 2, px, s->f) != px) return HSK_ERR_STATE;
+  s->n += 1;
+  return HSK_OK;
+}
+
+// frame `index` (0-based) into depth; HSK_ERR_ARG when out of range
+extern "C" int hsk_stream_read(hsk_depth_stream* s, int index, uint16_t* depth) {
+  if (!s || s->writing || !depth || index < 0 || (uint32_t)index >= s->n) return HSK_ERR_ARG;
+  const size_t px = (size_t)s->w * s->h;
+  if (fseek(s->f, (long)(36 + (size_t)index * px * 2), SEEK_SET) != 0) return HSK_ERR_STATE;
+  return fread(depth, 2, px, s->f) == px ? HSK_OK : HSK_ERR_STATE;
+}
+
+extern "C" int hsk_stream_close(hsk_depth_stream* s) {
+  if (!s) return HSK_ERR_ARG;
+  int rc = HSK_OK;
+  if (s->writing) {  // patch the frame count
+    if (fseek(s->f, 16, SEEK_SET) != 0 || fwrite(&s->n, 4, 1, s->f) != 1) rc = HSK_ERR_STATE;
+  }
+  if (fclose(s->f) != 0) rc = HSK_ERR_STATE;
+  delete s;
+  return rc;
+}

@@ -73,3 +73,72 @@ def write_room_dir(room_dir, cloud_xyz, leaf=0.03, **plane_args):
     for k, eq in enumerate(planes):
         write_pcd(os.path.join(room_dir, f"cloud_plane_hull{k}.pcd"), plane_hull(down, labels, k, eq))
     return planes, len(down)
+
+
+def write_xf(path, m):
+    lib = _lib.load()
+    a = np.ascontiguousarray(m, np.float32).reshape(16)
+    _ck(lib.hsk_write_xf(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_float))), "hsk_write_xf")
+
+
+def read_xf(path):
+    lib = _lib.load()
+    a = np.empty(16, np.float32)
+    _ck(lib.hsk_read_xf(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_float))), "hsk_read_xf")
+    return a.reshape(4, 4)
+
+
+def transform_cloud(xyz, m):
+    lib = _lib.load()
+    pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    a = np.ascontiguousarray(m, np.float32).reshape(16)
+    out = np.empty_like(pts)
+    _ck(lib.hsk_transform_cloud(pts.ctypes.data, len(pts), a.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data), "hsk_transform_cloud")
+    return out
+
+
+class DepthStreamWriter:
+    """HSKD raw depth recording (frames in the layout of HoniHelper.takeDepthSnapshot)."""
+
+    def __init__(self, path, w=640, h=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
+        self.lib = _lib.load()
+        self.h = self.lib.hsk_stream_create(os.fsencode(path), w, h, fx, fy, cx, cy)
+        if not self.h:
+            raise RuntimeError(f"cannot create {path}")
+        self.shape = (h, w)
+
+    def write(self, depth):
+        d = np.ascontiguousarray(depth, np.uint16)
+        assert d.shape == self.shape
+        _ck(self.lib.hsk_stream_write(self.h, d.ctypes.data), "hsk_stream_write")
+
+    def close(self):
+        if self.h:
+            _ck(self.lib.hsk_stream_close(self.h), "hsk_stream_close")
+            self.h = None
+
+
+class DepthStreamReader:
+    def __init__(self, path):
+        self.lib = _lib.load()
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        intr = (C.c_float * 4)()
+        self.h = self.lib.hsk_stream_open(os.fsencode(path), C.byref(w), C.byref(h), C.byref(n), intr)
+        if not self.h:
+            raise RuntimeError(f"{path} is not an HSKD stream")
+        self.w, self.hgt, self.n, self.intr = w.value, h.value, n.value, tuple(intr)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        d = np.empty((self.hgt, self.w), np.uint16)
+        rc = self.lib.hsk_stream_read(self.h, int(i), d.ctypes.data)
+        if rc != 0:
+            raise IndexError(i)
+        return d
+
+    def close(self):
+        if self.h:
+            self.lib.hsk_stream_close(self.h)
+            self.h = None

@@ -138,6 +138,20 @@ int hsk_plane_hull(const float* xyz, size_t n, const int* labels, int plane, con
                    size_t cap, size_t* n_hull);
 int hsk_write_planes_txt(const char* path, const float* planes_abcd, int n_planes);
 
+/* Room placements coming back from HouseScan: row-major left-multiplicative 4x4, as the 4-line .xf file
+ * (roomProjectionToXfFormat, Main.hs:2289-2302) or the one-line CSV (roomProjectionToString, Main.hs:2271-2284). */
+int hsk_write_xf(const char* path, const float m[16]);
+int hsk_read_xf(const char* path, float m[16]);              /* accepts both layouts */
+int hsk_transform_cloud(const float* xyz, size_t n, const float m[16], float* out /* may alias xyz */);
+
+/* Recorded depth streams ("HSKD" raw container; frames in the layout of takeDepthSnapshot, HoniHelper.hs:20-36). */
+typedef struct hsk_depth_stream hsk_depth_stream;
+hsk_depth_stream* hsk_stream_create(const char* path, int w, int h, float fx, float fy, float cx, float cy);
+hsk_depth_stream* hsk_stream_open(const char* path, int* w, int* h, int* n_frames, float intr[4]);
+int hsk_stream_write(hsk_depth_stream* s, const uint16_t* depth);
+int hsk_stream_read(hsk_depth_stream* s, int index, uint16_t* depth);
+int hsk_stream_close(hsk_depth_stream* s);
+
 #ifdef __cplusplus
 }
 #endif

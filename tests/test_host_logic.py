@@ -109,3 +109,39 @@ def test_plane_detection_and_room_dir(tmp_path, hsk):
         turns = np.einsum("ij,j->i", np.cross(e, np.roll(e, -1, axis=0)), eq[:3])
         assert (turns > -1e-6).all() or (turns < 1e-6).all()
     assert 0 < n_down < len(pts)
+
+
+def test_xf_round_trip_and_apply(tmp_path, hsk):
+    """row-major left-multiplicative 4x4 in HouseScan's two export layouts (Main.hs:2271-2302)"""
+    from housescan_amd import products as P
+    th = np.radians(30.0)
+    m = np.array([[np.cos(th), 0, np.sin(th), 1.5], [0, 1, 0, -0.25], [-np.sin(th), 0, np.cos(th), 2.0], [0, 0, 0, 1]], np.float32)
+    P.write_xf(str(tmp_path / "room.xf"), m)
+    txt = open(tmp_path / "room.xf").read().strip().split("\n")
+    assert len(txt) == 4 and all(len(r.split()) == 4 for r in txt)          # roomProjectionToXfFormat layout
+    assert np.array_equal(P.read_xf(str(tmp_path / "room.xf")), m)
+    open(tmp_path / "room.csv", "w").write(",".join(repr(float(x)) for x in m.reshape(-1)))   # roomProjectionToString
+    assert np.allclose(P.read_xf(str(tmp_path / "room.csv")), m)
+    pts = np.random.default_rng(2).uniform(-1, 1, (1000, 3)).astype(np.float32)
+    out = P.transform_cloud(pts, m)
+    ref = (m[:3, :3].astype(np.float64) @ pts.T.astype(np.float64)).T + m[:3, 3]
+    assert np.allclose(out, ref, atol=1e-5)                                   # p' = M p (left-multiplicative)
+
+
+def test_depth_stream_container(tmp_path, hsk):
+    from housescan_amd import products as P
+    path = str(tmp_path / "scan.hskd")
+    frames = [hsk.synth_depth(hsk.synth_pose(k), 160, 120, 131.25, 131.25, 79.75, 59.75) for k in range(5)]
+    w = P.DepthStreamWriter(path, 160, 120, 131.25, 131.25, 79.75, 59.75)
+    for f in frames:
+        w.write(f)
+    w.close()
+    r = P.DepthStreamReader(path)
+    assert len(r) == 5 and (r.w, r.hgt) == (160, 120) and r.intr == (131.25, 131.25, 79.75, 59.75)
+    for k in (4, 0, 2):
+        assert np.array_equal(r[k], frames[k])
+    import pytest
+    with pytest.raises(IndexError):
+        r[5]
+    r.close()
+    assert os.path.getsize(path) == 36 + 5 * 160 * 120 * 2
