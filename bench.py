@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of the submit/wait pair")
     ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
     ap.add_argument("--host-frames", action="store_true", help="also time hsk_process_frame with HOST depth buffers (PCIe-inclusive)")
@@ -127,11 +128,22 @@ def main():
     lost = 0
     for i in range(1 + Wm):
         _, ok = step(dev_frames[i])
+    use_async = world == 1 and not args.force_sharded and not args.sync_api
     barrier()
     t0 = time.perf_counter()
-    for i in range(1 + Wm, total):
-        pose, ok = step(dev_frames[i])
+    if use_async:
+        # hsk_submit_frame_dev / hsk_wait_frame: frame i+1 is enqueued before the pose of frame i is read back
+        trk.submit_frame_dev(dev_frames[1 + Wm].data_ptr())
+        for i in range(2 + Wm, total):
+            trk.submit_frame_dev(dev_frames[i].data_ptr())
+            pose, ok = trk.wait_frame()
+            lost += (not ok)
+        pose, ok = trk.wait_frame()
         lost += (not ok)
+    else:
+        for i in range(1 + Wm, total):
+            pose, ok = step(dev_frames[i])
+            lost += (not ok)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -153,7 +165,7 @@ def main():
                                "3 m cube, integrate + 19-iteration ICP + raycast per frame" % n,
                    "volume": n, "image": [640, 480], "icp_iters": [10, 5, 4],
                    "parallelism": ("1 gpu" if world == 1 else f"{args.mode}{world}" + (f"-icp-{args.icp}" if args.mode == "slab" else "")),
-                   "graph": bool(args.graph)},
+                   "graph": bool(args.graph), "api": "submit/wait (1 frame in flight ahead)" if use_async else "process_frame (sync per frame)"},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3)},
     }
 

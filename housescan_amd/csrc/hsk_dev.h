@@ -25,7 +25,7 @@ struct TrackState {
   int lost;            // set by the solve when the 6x6 system is singular (A.5)
   int frame;
   int n_iter;
-  int pad;
+  int need_reset;      // sticky after a tracking loss: later frames already in flight are dropped until the host resets
   double sums[27];     // last reduced normal equations (debug / hsk_icp_accumulate)
 };
 

@@ -54,6 +54,12 @@ struct hsk_ctx {
   unsigned long long* d_rowoff = nullptr;
   int frame = 0;
   std::string err;
+  // asynchronous submission ring (hsk_submit_frame_dev / hsk_wait_frame)
+  TrackState* h_ring = nullptr;  // pinned, HSK_MAX_IN_FLIGHT + 1 slots
+  hipEvent_t ring_ev[HSK_MAX_IN_FLIGHT + 1] = {};
+  int ring_kind[HSK_MAX_IN_FLIGHT + 1] = {};  // 0 tracked-frame candidate, 1 first frame (already complete)
+  int ring_head = 0, ring_count = 0;
+  bool pending_reset = false;
   // hipGraph of the steady-state frame
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -176,6 +182,9 @@ static void free_all(hsk_ctx* k) {
   F(k->d_rowoff);
   if (k->h_st) (void)hipHostFree(k->h_st);
   if (k->h_stage) (void)hipHostFree(k->h_stage);
+  if (k->h_ring) (void)hipHostFree(k->h_ring);
+  for (auto& e : k->ring_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : k->ev)
     if (e) (void)hipEventDestroy(e);
   if (k->own_stream && k->stream) (void)hipStreamDestroy(k->stream);
@@ -202,6 +211,7 @@ static int do_reset(hsk_ctx* k) {
   memcpy(k->h_st->Rp, k->init_R, sizeof(k->init_R));
   memcpy(k->h_st->tp, k->init_t, sizeof(k->init_t));
   k->frame = 0;
+  k->pending_reset = false;
   return upload_state(k);
 }
 
@@ -288,6 +298,8 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipMalloc((void**)&k->d_st, sizeof(TrackState)));
   CK(hipHostMalloc((void**)&k->h_st, sizeof(TrackState), hipHostMallocDefault));
   CK(hipHostMalloc((void**)&k->h_stage, P0 * 2, hipHostMallocDefault));
+  CK(hipHostMalloc((void**)&k->h_ring, sizeof(TrackState) * (HSK_MAX_IN_FLIGHT + 1), hipHostMallocDefault));
+  for (auto& e : k->ring_ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const int nb0 = icp_num_blocks(c->width, c->height);
   CK(hipMalloc((void**)&k->d_partials, (size_t)nb0 * 27 * sizeof(double)));
   CK(hipMalloc((void**)&k->d_partials2, (size_t)nb0 * 27 * sizeof(double)));
@@ -335,6 +347,11 @@ extern "C" void hsk_destroy(hsk_ctx* k) {
 
 extern "C" int hsk_reset(hsk_ctx* k) {
   if (!k) return HSK_ERR_ARG;
+  for (int i = 0; i < k->ring_count; ++i) {  // frames still in flight are dropped
+    const int sl = (k->ring_head + i) % (HSK_MAX_IN_FLIGHT + 1);
+    HIPCHK(k, hipEventSynchronize(k->ring_ev[sl]));
+    if (k->ring_kind[sl] == 0) k->ring_kind[sl] = 2;
+  }
   return do_reset(k);
 }
 
@@ -495,6 +512,7 @@ static int stage_depth_host(hsk_ctx* k, const uint16_t* depth) {
 extern "C" int hsk_process_frame(hsk_ctx* k, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked) {
   int r = check_dims(k, depth, w, h);
   if (r != HSK_OK) return r;
+  if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
@@ -504,9 +522,103 @@ extern "C" int hsk_process_frame(hsk_ctx* k, const uint16_t* depth, int w, int h
 extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float pose_out[16], int* tracked) {
   int r = check_dims(k, depth_dev, w, h);
   if (r != HSK_OK) return r;
+  if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
   return frame_common(k, pose_out, tracked);
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// asynchronous submission
+// ------------------------------------------------------------------------------------------------------
+extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h) {
+  int r = check_dims(k, depth_dev, w, h);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  if (k->ring_count >= HSK_MAX_IN_FLIGHT) return fail(k, HSK_ERR_STATE, "too many frames in flight: call hsk_wait_frame first");
+  hipStream_t s = k->stream;
+  const bool sync_path = k->frame == 0 || k->pending_reset || k->cfg.integrate_move_thresh > 0.0f || k->prof;
+  if (sync_path) {
+    // first frame of a (re)started scan, gated or profiled mode: run it synchronously and park the result
+    if (k->pending_reset) {
+      // results of the frames that were in flight when tracking was lost stay in the ring (they report tracked = 0);
+      // the reset itself happens here, before new work
+      for (int i = 0; i < k->ring_count; ++i) {
+        const int sl = (k->ring_head + i) % (HSK_MAX_IN_FLIGHT + 1);
+        HIPCHK(k, hipEventSynchronize(k->ring_ev[sl]));
+        if (k->ring_kind[sl] == 0) k->ring_kind[sl] = 2;  // dropped on the device (need_reset was set)
+      }
+      r = do_reset(k);
+      if (r != HSK_OK) return r;
+    }
+    HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
+    float pose[16];
+    int tracked = 0;
+    r = frame_common(k, pose, &tracked);
+    if (r != HSK_OK) return r;
+    const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
+    k->h_ring[slot] = *k->h_st;
+    k->h_ring[slot].lost = tracked ? 0 : 1;
+    k->ring_kind[slot] = 1;
+    HIPCHK(k, hipEventRecord(k->ring_ev[slot], s));
+    k->ring_count += 1;
+    return HSK_OK;
+  }
+  HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
+  if (k->cfg.use_graph) {
+    if (!k->graph_ready) {
+      HIPCHK(k, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      enqueue_tracked_frame(k, false);
+      HIPCHK(k, hipStreamEndCapture(s, &k->graph));
+      HIPCHK(k, hipGraphInstantiate(&k->gexec, k->graph, nullptr, nullptr, 0));
+      k->graph_ready = true;
+    }
+    HIPCHK(k, hipGraphLaunch(k->gexec, s));
+  } else {
+    enqueue_tracked_frame(k, false);
+  }
+  const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
+  HIPCHK(k, hipMemcpyAsync(&k->h_ring[slot], k->d_st, sizeof(TrackState), hipMemcpyDeviceToHost, s));
+  HIPCHK(k, hipEventRecord(k->ring_ev[slot], s));
+  k->ring_kind[slot] = 0;
+  k->ring_count += 1;
+  return HSK_OK;
+}
+
+extern "C" int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked) {
+  if (!k) return HSK_ERR_ARG;
+  if (k->ring_count == 0) return fail(k, HSK_ERR_STATE, "no frame in flight");
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const int slot = k->ring_head;
+  HIPCHK(k, hipEventSynchronize(k->ring_ev[slot]));
+  const TrackState& st = k->h_ring[slot];
+  k->ring_head = (k->ring_head + 1) % (HSK_MAX_IN_FLIGHT + 1);
+  k->ring_count -= 1;
+  if (pose_out) rt_to_pose16(st.R, st.t, pose_out);
+  if (k->ring_kind[slot] == 1) {  // completed synchronously at submission
+    if (tracked) *tracked = st.lost ? 0 : 1;
+    return HSK_OK;
+  }
+  if (k->ring_kind[slot] == 2) {  // was in flight behind a lost frame; the reset has already happened
+    if (tracked) *tracked = 0;
+    if (pose_out) rt_to_pose16(k->init_R, k->init_t, pose_out);
+    return HSK_OK;
+  }
+  if (st.lost) {
+    // the volume is reset lazily: at the next submission, or now if nothing else is in flight
+    k->pending_reset = true;
+    if (tracked) *tracked = 0;
+    if (pose_out) rt_to_pose16(k->init_R, k->init_t, pose_out);
+    if (k->ring_count == 0) {
+      int r = do_reset(k);
+      if (r != HSK_OK) return r;
+    }
+    return HSK_OK;
+  }
+  k->frame += 1;
+  if (tracked) *tracked = 1;
+  return HSK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------

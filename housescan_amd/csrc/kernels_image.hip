@@ -829,6 +829,7 @@ __global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ p
     for (int k = 0; k < 27; ++k) st->sums[k] = tot[k];
     if (p.lost) {
       st->lost = 1;
+      st->need_reset = 1;
     } else {
       for (int i = 0; i < 9; ++i) st->R[i] = p.R[i];
       for (int i = 0; i < 3; ++i) st->t[i] = p.t[i];
@@ -868,6 +869,11 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
 // start of a tracked frame: previous pose <- current pose, clear the lost flag
 __global__ void k_begin_frame(TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
   if (threadIdx.x != 0) return;
+  if (st->need_reset) {  // a frame queued behind a lost one (asynchronous submission): dropped, state untouched
+    st->lost = 1;
+    if (pose0) pose0->lost = 1;
+    return;
+  }
   for (int i = 0; i < 9; ++i) st->Rp[i] = st->R[i];
   for (int i = 0; i < 3; ++i) st->tp[i] = st->t[i];
   st->lost = 0;

@@ -89,6 +89,16 @@ class KinfuTracker:
                                                 C.byref(tracked)))
         return pose.reshape(4, 4), bool(tracked.value)
 
+    def submit_frame_dev(self, depth_dev_ptr):
+        """enqueue a frame (device pointer) without waiting; collect poses in order with wait_frame()"""
+        self._ck(self.lib.hsk_submit_frame_dev(self.h, C.c_void_p(depth_dev_ptr), self.w, self.hgt))
+
+    def wait_frame(self):
+        pose = np.empty(16, np.float32)
+        tracked = C.c_int()
+        self._ck(self.lib.hsk_wait_frame(self.h, _fp(pose), C.byref(tracked)))
+        return pose.reshape(4, 4), bool(tracked.value)
+
     def reset(self):
         self._ck(self.lib.hsk_reset(self.h))
 

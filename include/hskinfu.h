@@ -74,6 +74,14 @@ int hsk_process_frame(hsk_ctx* k, const uint16_t* depth, int w, int h, float pos
 /* Same, the depth frame already resident in device memory (HBM) */
 int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float pose_out[16], int* tracked);
 
+/* Asynchronous form of the tracker step (throughput): hsk_submit_frame_dev enqueues a frame and returns at once,
+ * hsk_wait_frame returns the pose of the OLDEST submitted frame (FIFO).  Up to HSK_MAX_IN_FLIGHT frames may be
+ * outstanding, so the GPU runs frame k+1 while the host reads frame k's pose.  After a tracking loss the frames
+ * already in flight are dropped (tracked = 0) and the volume is reset before the next submission. */
+#define HSK_MAX_IN_FLIGHT 3
+int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h);
+int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked);
+
 /* Stage-level entry points: exist so parity tests and rocprof can isolate each kernel. */
 int hsk_integrate(hsk_ctx* k, const uint16_t* depth, int w, int h, const float pose[16]);
 int hsk_raycast(hsk_ctx* k, const float pose[16], float* vmap /* 3*h*w SoA */, float* nmap, int32_t* keys /* may be NULL */);

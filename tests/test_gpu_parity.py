@@ -439,3 +439,51 @@ def test_room_products_from_fused_scan(tmp_path, hsk):
         assert any(abs(p[axis]) > 0.99 and abs(-p[3] / p[axis] - coord) < 0.03 for p in planes), (axis, coord, planes)
     assert os.path.exists(tmp_path / "room" / "cloud_plane_hull0.pcd") and n_down > 5000
     trk.close()
+
+
+def test_async_submit_wait_matches_sync(hsk, synth_frames):
+    """hsk_submit_frame_dev / hsk_wait_frame with frames in flight gives the same poses and TSDF as the
+    synchronous call, in order"""
+    import torch
+    n = 128
+    a = hsk.KinfuTracker(n=n)
+    b = hsk.KinfuTracker(n=n)
+    frames = [synth_frames(k)[1] for k in range(10)]
+    dev = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
+    sync = [a.process_frame(f) for f in frames]
+    got = []
+    b.submit_frame_dev(dev[0].data_ptr())
+    b.submit_frame_dev(dev[1].data_ptr())
+    for i in range(2, 10):
+        b.submit_frame_dev(dev[i].data_ptr())
+        got.append(b.wait_frame())
+    got.append(b.wait_frame())
+    got.append(b.wait_frame())
+    with pytest.raises(hsk.KinfuError, match="no frame in flight"):
+        b.wait_frame()
+    for k, ((ps, oks), (pa, oka)) in enumerate(zip(sync, got)):
+        assert oks == oka, k
+        assert_same_bits(pa, ps, f"async pose {k}")
+    assert_same_bits(b.download_tsdf(), a.download_tsdf(), "async tsdf")
+    a.close()
+    b.close()
+
+
+def test_async_tracking_loss_drops_in_flight_frames(hsk, synth_frames):
+    import torch
+    trk = hsk.KinfuTracker(n=64)
+    good = [torch.from_numpy(synth_frames(k)[1].view(np.int16)).cuda() for k in range(4)]
+    blank = torch.zeros(480 * 640, dtype=torch.int16, device="cuda")
+    trk.submit_frame_dev(good[0].data_ptr())
+    trk.submit_frame_dev(good[1].data_ptr())
+    assert trk.wait_frame()[1] is False and trk.wait_frame()[1] is True
+    trk.submit_frame_dev(blank.data_ptr())          # singular system => lost
+    trk.submit_frame_dev(good[2].data_ptr())        # in flight behind the lost frame => dropped
+    p1, t1 = trk.wait_frame()
+    p2, t2 = trk.wait_frame()
+    assert not t1 and not t2 and np.allclose(p1[:3, 3], [1.5, 1.5, -0.3])
+    assert not trk.download_tsdf().any()            # reset happened once the ring drained
+    trk.submit_frame_dev(good[0].data_ptr())        # restarts as a first frame
+    trk.submit_frame_dev(good[1].data_ptr())
+    assert trk.wait_frame()[1] is False and trk.wait_frame()[1] is True
+    trk.close()
