@@ -17,6 +17,17 @@
 
 static thread_local std::string g_create_err;
 
+// image-space buffers of one frame; two sets so that the asynchronous path can preprocess frame k+1 on a second
+// stream while frame k is still being tracked / fused / raycast
+struct ImgBufs {
+  uint16_t* d_raw = nullptr;
+  uint16_t* d_dep[HSK_NLEVELS] = {};
+  float* d_scaled = nullptr;
+  float* d_vcur[HSK_NLEVELS] = {};
+  float* d_ncur[HSK_NLEVELS] = {};
+  float* d_tmax = nullptr;  // tile tables of the scaled depth (see launch_tile_max)
+};
+
 struct hsk_ctx {
   hsk_config cfg;
   hipStream_t stream = nullptr;
@@ -27,11 +38,9 @@ struct hsk_ctx {
   // device memory (all sized once at create; nothing is allocated on the frame path)
   void* d_vol = nullptr;
   size_t vol_bytes = 0;
-  uint16_t* d_raw = nullptr;
-  uint16_t* d_dep[HSK_NLEVELS] = {};
-  float* d_scaled = nullptr;
-  float* d_vcur[HSK_NLEVELS] = {};
-  float* d_ncur[HSK_NLEVELS] = {};
+  ImgBufs ib[2];
+  int cur = 0;  // set the enqueue_* helpers work on (0 everywhere except inside the overlapped async submission)
+  ImgBufs& B() { return ib[cur]; }
   float* d_vmod[HSK_NLEVELS] = {};
   float* d_nmod[HSK_NLEVELS] = {};
   TrackState* d_st = nullptr;
@@ -47,7 +56,6 @@ struct hsk_ctx {
   size_t flags_bytes = 0;
   unsigned* d_queue = nullptr;       // integrate pass A -> pass B: count (4 words) + uncertain lane-block ids
   int2* d_zint = nullptr;            // per lane column: stored-plane range inside the padded frustum
-  float* d_tmax = nullptr;           // 16x16-pixel tile maxima of the scaled depth
   uint16_t* h_stage = nullptr;  // pinned staging for the incoming depth frame
   unsigned long long* d_counter = nullptr;
   unsigned* d_rowcnt = nullptr;
@@ -60,6 +68,13 @@ struct hsk_ctx {
   int ring_kind[HSK_MAX_IN_FLIGHT + 1] = {};  // 0 tracked-frame candidate, 1 first frame (already complete)
   int ring_head = 0, ring_count = 0;
   bool pending_reset = false;
+  // overlapped preprocessing: stream, per-set events (preprocess done / set free again), per-set graphs of the rest
+  hipStream_t pstream = nullptr;
+  hipEvent_t ev_pre[2] = {}, ev_free[2] = {};
+  bool set_used[2] = {false, false};
+  int async_set = 1;
+  hipGraph_t mgraph[2] = {};
+  hipGraphExec_t mgexec[2] = {};
   // hipGraph of the steady-state frame
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -153,16 +168,30 @@ static void free_all(hsk_ctx* k) {
   (void)hipSetDevice(k->cfg.device_id);
   if (k->gexec) (void)hipGraphExecDestroy(k->gexec);
   if (k->graph) (void)hipGraphDestroy(k->graph);
+  for (auto& g : k->mgexec)
+    if (g) (void)hipGraphExecDestroy(g);
+  for (auto& g : k->mgraph)
+    if (g) (void)hipGraphDestroy(g);
+  for (auto& e : k->ev_pre)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : k->ev_free)
+    if (e) (void)hipEventDestroy(e);
+  if (k->pstream) (void)hipStreamDestroy(k->pstream);
   auto F = [](void* p) {
     if (p) (void)hipFree(p);
   };
   F(k->d_vol);
-  F(k->d_raw);
-  F(k->d_scaled);
+  for (auto& b : k->ib) {
+    F(b.d_raw);
+    F(b.d_scaled);
+    F(b.d_tmax);
+    for (int l = 0; l < HSK_NLEVELS; ++l) {
+      F(b.d_dep[l]);
+      F(b.d_vcur[l]);
+      F(b.d_ncur[l]);
+    }
+  }
   for (int l = 0; l < HSK_NLEVELS; ++l) {
-    F(k->d_dep[l]);
-    F(k->d_vcur[l]);
-    F(k->d_ncur[l]);
     F(k->d_vmod[l]);
     F(k->d_nmod[l]);
   }
@@ -174,7 +203,6 @@ static void free_all(hsk_ctx* k) {
   F(k->d_wc);
   F(k->d_keys);
   F(k->d_flags);
-  F(k->d_tmax);
   F(k->d_zint);
   F(k->d_queue);
   F(k->d_counter);
@@ -285,16 +313,26 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   k->vol_bytes = (size_t)vp.X * vp.Y * vp.nzs * 4;
   CK(hipMalloc(&k->d_vol, k->vol_bytes));
   const size_t P0 = (size_t)c->width * c->height;
-  CK(hipMalloc((void**)&k->d_raw, P0 * 2));
-  CK(hipMalloc((void**)&k->d_scaled, P0 * 4));
+  for (auto& b : k->ib) {
+    CK(hipMalloc((void**)&b.d_raw, P0 * 2));
+    CK(hipMalloc((void**)&b.d_scaled, P0 * 4));
+    CK(hipMalloc((void**)&b.d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4 +
+                                    (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8));
+    for (int l = 0; l < HSK_NLEVELS; ++l) {
+      const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
+      CK(hipMalloc((void**)&b.d_dep[l], P * 2));
+      CK(hipMalloc((void**)&b.d_vcur[l], P * 12));
+      CK(hipMalloc((void**)&b.d_ncur[l], P * 12));
+    }
+  }
   for (int l = 0; l < HSK_NLEVELS; ++l) {
     const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
-    CK(hipMalloc((void**)&k->d_dep[l], P * 2));
-    CK(hipMalloc((void**)&k->d_vcur[l], P * 12));
-    CK(hipMalloc((void**)&k->d_ncur[l], P * 12));
     CK(hipMalloc((void**)&k->d_vmod[l], P * 12));
     CK(hipMalloc((void**)&k->d_nmod[l], P * 12));
   }
+  CK(hipStreamCreateWithFlags(&k->pstream, hipStreamNonBlocking));
+  for (auto& e : k->ev_pre) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : k->ev_free) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   CK(hipMalloc((void**)&k->d_st, sizeof(TrackState)));
   CK(hipHostMalloc((void**)&k->h_st, sizeof(TrackState), hipHostMallocDefault));
   CK(hipHostMalloc((void**)&k->h_stage, P0 * 2, hipHostMallocDefault));
@@ -321,8 +359,6 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     CK(hipMalloc((void**)&k->d_queue, (256 * 64 + 256 * qcap) * sizeof(unsigned)));
   }
   CK(hipMalloc((void**)&k->d_zint, (size_t)(vp.X / 4) * vp.Y * sizeof(int2)));
-  CK(hipMalloc((void**)&k->d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4 +
-                                       (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8));
   CK(hipMalloc((void**)&k->d_counter, 16));
   {
     float ws[169], wc[512];
@@ -376,22 +412,21 @@ extern "C" int hsk_synchronize(hsk_ctx* k) {
 // ------------------------------------------------------------------------------------------------------
 // frame building blocks (enqueue only; no host synchronisation)
 // ------------------------------------------------------------------------------------------------------
-static void enqueue_preprocess(hsk_ctx* k) {
-  hipStream_t s = k->stream;
-  launch_bilateral_scale(s, k->d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->h_ws, k->d_wc, k->d_dep[0], k->d_scaled,
-                         k->d_tmax);
-  for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->d_dep[l]);
-  launch_vmap_nmap_pyramid(s, k->d_dep, k->lv, k->d_vcur, k->d_ncur);
+static void enqueue_preprocess(hsk_ctx* k, hipStream_t s) {
+  launch_bilateral_scale(s, k->B().d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->h_ws, k->d_wc, k->B().d_dep[0], k->B().d_scaled,
+                         k->B().d_tmax);
+  for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->B().d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->B().d_dep[l]);
+  launch_vmap_nmap_pyramid(s, k->B().d_dep, k->lv, k->B().d_vcur, k->B().d_ncur);
 }
 
 static void enqueue_icp(hsk_ctx* k) {
-  launch_icp_fused(k->stream, k->d_vcur, k->d_ncur, k->d_vmod, k->d_nmod, k->lv, k->cfg.icp_iters, k->d_st,
+  launch_icp_fused(k->stream, k->B().d_vcur, k->B().d_ncur, k->d_vmod, k->d_nmod, k->lv, k->cfg.icp_iters, k->d_st,
                    k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2);
 }
 
 static void enqueue_integrate(hsk_ctx* k) {
-  launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
-                   k->d_counter, k->d_flags, k->d_tmax, k->d_zint, k->d_queue);
+  launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
+                   k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue);
 }
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys) {
@@ -419,7 +454,7 @@ static bool gate_passes(const TrackState* st, float thr) {
 static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
   hipStream_t s = k->stream;
   if (with_events) (void)hipEventRecord(k->ev[0], s);
-  enqueue_preprocess(k);
+  enqueue_preprocess(k, k->stream);
   launch_begin_frame(s, k->d_st, k->d_icp_pose);
   if (with_events) (void)hipEventRecord(k->ev[1], s);
   enqueue_icp(k);
@@ -430,15 +465,23 @@ static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
   if (with_events) (void)hipEventRecord(k->ev[4], s);
 }
 
+// everything after the preprocessing of a tracked frame, on the main stream, for the buffer set k->cur
+static void enqueue_tracked_rest(hsk_ctx* k) {
+  launch_begin_frame(k->stream, k->d_st, k->d_icp_pose);
+  enqueue_icp(k);
+  enqueue_integrate(k);
+  enqueue_raycast_and_resize(k, nullptr);
+}
+
 static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
   // depth is already in d_raw (enqueued on the stream)
   hipStream_t s = k->stream;
   const bool gated = k->cfg.integrate_move_thresh > 0.0f;
   if (k->frame == 0) {
-    enqueue_preprocess(k);
+    enqueue_preprocess(k, k->stream);
     enqueue_integrate(k);
     for (int l = 0; l < HSK_NLEVELS; ++l)
-      launch_transform_maps(s, k->d_vcur[l], k->d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l], k->d_nmod[l]);
+      launch_transform_maps(s, k->B().d_vcur[l], k->B().d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l], k->d_nmod[l]);
     int r = download_state(k);
     if (r != HSK_OK) return r;
     HIPCHK(k, hipGetLastError());
@@ -449,7 +492,7 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
   }
   if (gated) {
     // host decides whether to integrate: one extra synchronisation, only in this non-default mode
-    enqueue_preprocess(k);
+    enqueue_preprocess(k, k->stream);
     launch_begin_frame(s, k->d_st, k->d_icp_pose);
     enqueue_icp(k);
     int r = download_state(k);
@@ -505,7 +548,7 @@ static int check_dims(hsk_ctx* k, const void* depth, int w, int h) {
 static int stage_depth_host(hsk_ctx* k, const uint16_t* depth) {
   const size_t bytes = (size_t)k->cfg.width * k->cfg.height * 2;
   memcpy(k->h_stage, depth, bytes);  // caller's buffer may be freed on return (HoniHelper's Vector is only pinned in unsafeWith)
-  HIPCHK(k, hipMemcpyAsync(k->d_raw, k->h_stage, bytes, hipMemcpyHostToDevice, k->stream));
+  HIPCHK(k, hipMemcpyAsync(k->B().d_raw, k->h_stage, bytes, hipMemcpyHostToDevice, k->stream));
   return HSK_OK;
 }
 
@@ -524,7 +567,7 @@ extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, i
   if (r != HSK_OK) return r;
   if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
+  HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
   return frame_common(k, pose_out, tracked);
 }
 
@@ -552,7 +595,7 @@ extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, in
       r = do_reset(k);
       if (r != HSK_OK) return r;
     }
-    HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
+    HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
     float pose[16];
     int tracked = 0;
     r = frame_common(k, pose, &tracked);
@@ -565,19 +608,38 @@ extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, in
     k->ring_count += 1;
     return HSK_OK;
   }
-  HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
-  if (k->cfg.use_graph) {
-    if (!k->graph_ready) {
-      HIPCHK(k, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      enqueue_tracked_frame(k, false);
-      HIPCHK(k, hipStreamEndCapture(s, &k->graph));
-      HIPCHK(k, hipGraphInstantiate(&k->gexec, k->graph, nullptr, nullptr, 0));
-      k->graph_ready = true;
-    }
-    HIPCHK(k, hipGraphLaunch(k->gexec, s));
-  } else {
-    enqueue_tracked_frame(k, false);
+  // Overlapped path: depth copy + preprocessing of THIS frame go to the second stream and the other buffer set, so
+  // they run while the previous frame is still in its ICP / integrate / raycast on the main stream.
+  const int set = k->async_set;
+  k->async_set ^= 1;
+  k->cur = set;
+  hipError_t e = hipSuccess;
+  if (k->set_used[set]) e = hipStreamWaitEvent(k->pstream, k->ev_free[set], 0);  // its previous user has finished
+  if (e == hipSuccess) e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->pstream);
+  if (e == hipSuccess) {
+    enqueue_preprocess(k, k->pstream);
+    e = hipEventRecord(k->ev_pre[set], k->pstream);
   }
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, k->ev_pre[set], 0);
+  if (e == hipSuccess) {
+    if (k->cfg.use_graph) {
+      if (!k->mgexec[set]) {
+        e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+          enqueue_tracked_rest(k);
+          e = hipStreamEndCapture(s, &k->mgraph[set]);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&k->mgexec[set], k->mgraph[set], nullptr, nullptr, 0);
+      }
+      if (e == hipSuccess) e = hipGraphLaunch(k->mgexec[set], s);
+    } else {
+      enqueue_tracked_rest(k);
+    }
+  }
+  if (e == hipSuccess) e = hipEventRecord(k->ev_free[set], s);
+  k->set_used[set] = true;
+  k->cur = 0;
+  HIPCHK(k, e);
   const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
   HIPCHK(k, hipMemcpyAsync(&k->h_ring[slot], k->d_st, sizeof(TrackState), hipMemcpyDeviceToHost, s));
   HIPCHK(k, hipEventRecord(k->ring_ev[slot], s));
@@ -655,8 +717,8 @@ extern "C" int hsk_integrate(hsk_ctx* k, const uint16_t* depth, int w, int h, co
   if (r != HSK_OK) return r;
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
-  launch_scale_depth(k->stream, k->d_raw, w, h, k->lv[0].in, k->d_scaled);
-  launch_tile_max(k->stream, k->d_scaled, w, h, k->d_tmax);
+  launch_scale_depth(k->stream, k->B().d_raw, w, h, k->lv[0].in, k->B().d_scaled);
+  launch_tile_max(k->stream, k->B().d_scaled, w, h, k->B().d_tmax);
   enqueue_integrate(k);
   HIPCHK(k, hipStreamSynchronize(k->stream));
   HIPCHK(k, hipGetLastError());
@@ -672,11 +734,11 @@ extern "C" int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h
   if (r != HSK_OK) return r;
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
-  launch_scale_depth(k->stream, k->d_raw, w, h, k->lv[0].in, k->d_scaled);
-  launch_tile_max(k->stream, k->d_scaled, w, h, k->d_tmax);
+  launch_scale_depth(k->stream, k->B().d_raw, w, h, k->lv[0].in, k->B().d_scaled);
+  launch_tile_max(k->stream, k->B().d_scaled, w, h, k->B().d_tmax);
   HIPCHK(k, hipMemsetAsync(k->d_counter, 0, 8, k->stream));
-  launch_integrate(k->stream, k->d_vol, k->d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter, k->d_flags,
-                   k->d_tmax, k->d_zint, k->d_queue);
+  launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter, k->d_flags,
+                   k->B().d_tmax, k->d_zint, k->d_queue);
   unsigned long long c = 0;
   HIPCHK(k, hipMemcpyAsync(&c, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));
@@ -708,7 +770,7 @@ extern "C" int hsk_preprocess(hsk_ctx* k, const uint16_t* depth, int w, int h) {
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
-  enqueue_preprocess(k);
+  enqueue_preprocess(k, k->stream);
   HIPCHK(k, hipStreamSynchronize(k->stream));
   HIPCHK(k, hipGetLastError());
   return HSK_OK;
@@ -731,7 +793,7 @@ extern "C" int hsk_icp_accumulate(hsk_ctx* k, int level, const float pose_est[16
   r = upload_state(k);
   if (r != HSK_OK) return r;
   const int nb = icp_num_blocks(k->lv[level].W, row1 - row0);
-  launch_icp_accumulate(k->stream, k->d_vcur[level], k->d_ncur[level], k->d_vmod[level], k->d_nmod[level],
+  launch_icp_accumulate(k->stream, k->B().d_vcur[level], k->B().d_ncur[level], k->d_vmod[level], k->d_nmod[level],
                         k->lv[level].W, k->lv[level].H, k->lv[level].in, k->d_st, k->cfg.icp_dist_thresh_m,
                         k->cfg.icp_angle_thresh_sin, row0, row1, k->d_partials);
   launch_icp_reduce(k->stream, k->d_partials, nb, k->d_sums);
@@ -775,8 +837,8 @@ extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
 
 static float* map_ptr(hsk_ctx* k, int kind, int level) {
   switch (kind) {
-    case 0: return k->d_vcur[level];
-    case 1: return k->d_ncur[level];
+    case 0: return k->B().d_vcur[level];
+    case 1: return k->B().d_ncur[level];
     case 2: return k->d_vmod[level];
     case 3: return k->d_nmod[level];
   }
@@ -802,14 +864,14 @@ extern "C" int hsk_download_depth_level(hsk_ctx* k, int level, uint16_t* out) {
   if (!k || !out || level < 0 || level >= HSK_NLEVELS) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   const size_t P = (size_t)k->lv[level].W * k->lv[level].H;
-  HIPCHK(k, hipMemcpyAsync(out, k->d_dep[level], P * 2, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipMemcpyAsync(out, k->B().d_dep[level], P * 2, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));
   return HSK_OK;
 }
 extern "C" int hsk_download_scaled_depth(hsk_ctx* k, float* out) {
   if (!k || !out) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  HIPCHK(k, hipMemcpyAsync(out, k->d_scaled, (size_t)k->lv[0].W * k->lv[0].H * 4, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipMemcpyAsync(out, k->B().d_scaled, (size_t)k->lv[0].W * k->lv[0].H * 4, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));
   return HSK_OK;
 }
@@ -868,12 +930,12 @@ extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, in
   int r = check_dims(k, depth_dev, w, h);
   if (r != HSK_OK) return r;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  HIPCHK(k, hipMemcpyAsync(k->d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
-  enqueue_preprocess(k);
+  HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
+  enqueue_preprocess(k, k->stream);
   if (k->frame == 0) {
     enqueue_integrate(k);
     for (int l = 0; l < HSK_NLEVELS; ++l)
-      launch_transform_maps(k->stream, k->d_vcur[l], k->d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l],
+      launch_transform_maps(k->stream, k->B().d_vcur[l], k->B().d_ncur[l], k->lv[l].W * k->lv[l].H, k->d_st, k->d_vmod[l],
                             k->d_nmod[l]);
   } else {
     launch_begin_frame(k->stream, k->d_st, nullptr);
@@ -889,7 +951,7 @@ extern "C" int hsk_mgpu_icp_accumulate(hsk_ctx* k, int level, int row0, int row1
     return HSK_OK;
   }
   const int nb = icp_num_blocks(k->lv[level].W, row1 - row0);
-  launch_icp_accumulate(k->stream, k->d_vcur[level], k->d_ncur[level], k->d_vmod[level], k->d_nmod[level],
+  launch_icp_accumulate(k->stream, k->B().d_vcur[level], k->B().d_ncur[level], k->d_vmod[level], k->d_nmod[level],
                         k->lv[level].W, k->lv[level].H, k->lv[level].in, k->d_st, k->cfg.icp_dist_thresh_m,
                         k->cfg.icp_angle_thresh_sin, row0, row1, k->d_partials);
   launch_icp_reduce(k->stream, k->d_partials, nb, (double*)sums27_dev);

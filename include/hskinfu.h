@@ -77,7 +77,9 @@ int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float
 /* Asynchronous form of the tracker step (throughput): hsk_submit_frame_dev enqueues a frame and returns at once,
  * hsk_wait_frame returns the pose of the OLDEST submitted frame (FIFO).  Up to HSK_MAX_IN_FLIGHT frames may be
  * outstanding, so the GPU runs frame k+1 while the host reads frame k's pose.  After a tracking loss the frames
- * already in flight are dropped (tracked = 0) and the volume is reset before the next submission. */
+ * already in flight are dropped (tracked = 0) and the volume is reset before the next submission.  The depth copy
+ * and preprocessing of a submitted frame run on a second stream, overlapped with the previous frame; depth_dev must
+ * therefore stay valid until hsk_wait_frame has returned that frame. */
 #define HSK_MAX_IN_FLIGHT 3
 int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h);
 int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked);
