@@ -415,6 +415,7 @@ extern "C" int hsk_synchronize(hsk_ctx* k) {
 static void enqueue_preprocess(hsk_ctx* k, hipStream_t s) {
   launch_bilateral_scale(s, k->B().d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->h_ws, k->d_wc, k->B().d_dep[0], k->B().d_scaled,
                          k->B().d_tmax);
+  launch_tile_fine(s, k->B().d_scaled, k->lv[0].W, k->lv[0].H, k->B().d_tmax);
   for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->B().d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->B().d_dep[l]);
   launch_vmap_nmap_pyramid(s, k->B().d_dep, k->lv, k->B().d_vcur, k->B().d_ncur);
 }
@@ -719,6 +720,7 @@ extern "C" int hsk_integrate(hsk_ctx* k, const uint16_t* depth, int w, int h, co
   if (r != HSK_OK) return r;
   launch_scale_depth(k->stream, k->B().d_raw, w, h, k->lv[0].in, k->B().d_scaled);
   launch_tile_max(k->stream, k->B().d_scaled, w, h, k->B().d_tmax);
+  launch_tile_fine(k->stream, k->B().d_scaled, w, h, k->B().d_tmax);
   enqueue_integrate(k);
   HIPCHK(k, hipStreamSynchronize(k->stream));
   HIPCHK(k, hipGetLastError());
@@ -736,6 +738,7 @@ extern "C" int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h
   if (r != HSK_OK) return r;
   launch_scale_depth(k->stream, k->B().d_raw, w, h, k->lv[0].in, k->B().d_scaled);
   launch_tile_max(k->stream, k->B().d_scaled, w, h, k->B().d_tmax);
+  launch_tile_fine(k->stream, k->B().d_scaled, w, h, k->B().d_tmax);
   HIPCHK(k, hipMemsetAsync(k->d_counter, 0, 8, k->stream));
   launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, w, h, k->lv[0].in, true, k->d_counter, k->d_flags,
                    k->B().d_tmax, k->d_zint, k->d_queue);

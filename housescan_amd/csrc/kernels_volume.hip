@@ -617,6 +617,14 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
   }
 }
 
+// fine (8-px) tile table: depends only on the depth frame, so it belongs to the preprocessing
+void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles) {
+  const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
+  const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
+  hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, (float2*)(tiles + 4 * tw * th), fw,
+                     fh);
+}
+
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
                       const float* tmax, int2* zint, unsigned* queue) {
@@ -625,8 +633,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int ncols = (vp.X / 4) * vp.Y;
   const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
-  float2* ftab = (float2*)(tmax + 4 * tw * th);  // behind the coarse tables in the same allocation
-  hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, ftab, fw, fh);
+  const float2* ftab = (const float2*)(tmax + 4 * tw * th);  // behind the coarse tables (filled by launch_tile_fine)
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks + dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, col_blocks,
                      tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th);
