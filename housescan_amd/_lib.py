@@ -97,6 +97,56 @@ SYMBOLS = {
     "hsk_stream_close": (C.c_int, [_P]),
 }
 
+# every symbol include/hshouse.h declares (host-side room stitching)
+_U32 = C.POINTER(C.c_uint32)
+_SZ = C.POINTER(C.c_size_t)
+HSH_OBJECTIVE = C.CFUNCTYPE(C.c_double, _D, C.c_int, _P)
+HOUSE_SYMBOLS = {
+    "hsh_create": (_P, []),
+    "hsh_destroy": (None, [_P]),
+    "hsh_last_error": (C.c_char_p, [_P]),
+    "hsh_load_room": (C.c_int, [_P, C.c_char_p, _U32]),
+    "hsh_add_room": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, _P, C.c_int, _P, _P, _U32]),
+    "hsh_room_ids": (C.c_int, [_P, _P, C.c_int, _I]),
+    "hsh_room_planes": (C.c_int, [_P, C.c_uint32, _P, _P, C.c_int, _I]),
+    "hsh_plane_bounds": (C.c_int, [_P, C.c_uint32, _P, C.c_int, _I]),
+    "hsh_room_corners": (C.c_int, [_P, C.c_uint32, C.c_int, _P, _P, C.c_int, _I]),
+    "hsh_room_cloud": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, _SZ]),
+    "hsh_room_means": (C.c_int, [_P, C.c_uint32, _P, _P]),
+    "hsh_set_room_corners": (C.c_int, [_P, C.c_uint32, _P, C.c_int]),
+    "hsh_accept_corner_suggestion": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "hsh_translate_room": (C.c_int, [_P, C.c_uint32, _P]),
+    "hsh_rotate_room": (C.c_int, [_P, C.c_uint32, _P]),
+    "hsh_rotate_kinfu_room": (C.c_int, [_P, C.c_uint32]),
+    "hsh_room_auto_align_axis": (C.c_int, [_P, C.c_uint32, _P]),
+    "hsh_auto_align_floor": (C.c_int, [_P, C.c_uint32]),
+    "hsh_remove_ceiling": (C.c_int, [_P, C.c_uint32]),
+    "hsh_suggest_points": (C.c_int, [_P, C.c_uint32, C.c_float, _I, _I]),
+    "hsh_fit_cuboid_to_room": (C.c_int, [_P, C.c_uint32, C.c_int, _I, _D, _D]),
+    "hsh_connect_walls": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int, C.c_float, _I]),
+    "hsh_disconnect_walls": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "hsh_connected_walls": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _I]),
+    "hsh_optimize_room_positions": (C.c_int, [_P, _D]),
+    "hsh_room_projection": (C.c_int, [_P, C.c_uint32, _F]),
+    "hsh_room_projection_string": (C.c_int, [_P, C.c_uint32, C.c_int, C.c_char_p, C.c_size_t]),
+    "hsh_export_all_room_xf_files": (C.c_int, [_P, C.c_char_p]),
+    "hsh_plane_corner": (C.c_int, [_P, _P, _I]),
+    "hsh_fit_plane": (C.c_int, [_P, C.c_int, _P]),
+    "hsh_rotation_between": (C.c_int, [_P, _P, _P]),
+    "hsh_cuboid_from_params": (C.c_int, [_P, _P]),
+    "hsh_guess_dims": (C.c_int, [_P, _P]),
+    "hsh_errfun": (C.c_int, [_P, _P, C.c_int, _D]),
+    "hsh_fit_cuboid": (C.c_int, [_P, C.c_int, C.c_int, _P, _I, _D]),
+    "hsh_nm_minimize": (C.c_int, [HSH_OBJECTIVE, _P, C.c_int, _P, _P, C.c_double, C.c_int, _P, _D, _I]),
+    "hsh_lstsq_distances": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, _I, _D]),
+    "hsh_group_connected_components": (C.c_int, [_P, _P, C.c_int, _P, _I]),
+    "hsh_show_float": (C.c_int, [C.c_float, C.c_char_p, C.c_size_t]),
+    "hsh_read_pcd_xyz": (C.c_int, [C.c_char_p, _P, C.c_size_t, _SZ]),
+    "hsh_read_planes_txt": (C.c_int, [C.c_char_p, _P, C.c_int, _I]),
+    "hsh_write_ply_points": (C.c_int, [C.c_char_p, _P, C.c_size_t]),
+    "hsh_read_ply_points": (C.c_int, [C.c_char_p, _P, C.c_size_t, _SZ]),
+}
+
 _lib = None
 
 
@@ -110,7 +160,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `make -C housescan_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(HOUSE_SYMBOLS.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

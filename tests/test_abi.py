@@ -32,6 +32,26 @@ def test_every_declared_symbol_is_exported_and_bound(hsk):
     assert set(names) <= exported
 
 
+def test_house_header_symbols_are_exported_and_bound(hsk):
+    """include/hshouse.h (host-side room stitching): same rule as the core header"""
+    from housescan_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hshouse.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(hsh_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) >= 40
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hshouse.h but not exported"
+        assert n in _lib.HOUSE_SYMBOLS, f"{n} has no ctypes binding"
+    assert set(_lib.HOUSE_SYMBOLS) <= set(names), set(_lib.HOUSE_SYMBOLS) - set(names)
+
+
+def test_house_header_is_plain_c(tmp_path):
+    src = tmp_path / "c.c"
+    src.write_text('#include "hshouse.h"\nint main(void){hsh_house* h = 0; (void)h; return 0;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c",
+                           str(src), "-o", str(tmp_path / "c.o")])
+
+
 def test_config_struct_layout_matches_c(tmp_path, hsk):
     from housescan_amd import _lib
     src = tmp_path / "sz.c"
