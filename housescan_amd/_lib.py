@@ -82,6 +82,9 @@ SYMBOLS = {
     "hsk_bilateral_tables": (C.c_int, [_F, _F]),
     "hsk_synth_pose": (C.c_int, [C.c_int, _F]),
     "hsk_synth_render": (C.c_int, [_F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "hsk_synth_room_extents": (C.c_int, [C.c_int, _F]),
+    "hsk_synth_room_pose": (C.c_int, [C.c_int, C.c_int, C.c_int, _F]),
+    "hsk_synth_room_render": (C.c_int, [C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hsk_write_pcd_xyz": (C.c_int, [C.c_char_p, _P, C.c_size_t]),
     "hsk_voxel_downsample": (C.c_int, [_P, C.c_size_t, C.c_float, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_detect_planes": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, _P, _P, _I]),

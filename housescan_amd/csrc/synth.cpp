@@ -124,3 +124,186 @@ extern "C" int hsk_synth_render(const float pose[16], int w, int h, float fx, fl
     }
   return HSK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Closed rooms for the room-stitching configurations (BASELINE configs[0] and [4]): a box room seen from inside,
+// furniture standing on the floor (y grows DOWNWARD in the KinFu frame, so the floor is the high-y wall), and a
+// turntable trajectory that looks all the way round from near the room's centre.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Box {
+  double lo[3], hi[3];
+};
+struct RoomScene {
+  Box room;
+  Box blocks[23];
+  double sphere_c[3], sphere_r;
+};
+
+RoomScene make_room(int variant) {
+  static const double ext[4][6] = {{0.25, 2.75, 0.30, 2.70, 0.20, 2.80},
+                                   {0.40, 2.60, 0.30, 2.70, 0.25, 2.75},
+                                   {0.20, 2.80, 0.35, 2.65, 0.50, 2.50},
+                                   {0.50, 2.50, 0.30, 2.70, 0.30, 2.70}};
+  const double* e = ext[((variant % 4) + 4) % 4];
+  RoomScene s;
+  s.room = {{e[0], e[2], e[4]}, {e[1], e[3], e[5]}};
+  const double x0 = e[0], x1 = e[1], y1 = e[3], z0 = e[4], z1 = e[5];
+  // every wall carries pieces at camera height (y ~ 1.5): their sides and tops pin the translation that a bare wall
+  // leaves free for point-to-plane ICP
+  s.blocks[0] = {{x0, y1 - 0.80, z0}, {x0 + 0.50, y1, z0 + 0.80}};                  // low cupboard, corner (x0, z0)
+  s.blocks[1] = {{x1 - 0.70, y1 - 1.10, z1 - 0.50}, {x1, y1, z1}};                  // chest, corner (x1, z1)
+  s.blocks[2] = {{1.20, y1 - 0.60, z1 - 0.40}, {1.90, y1, z1}};                     // bench on the z1 wall
+  s.blocks[3] = {{x0, y1 - 1.50, 1.30}, {x0 + 0.40, y1, 1.90}};                     // tall cabinet on the x0 wall
+  s.blocks[4] = {{x1 - 0.30, 1.10, 0.90}, {x1, 1.50, 1.60}};                        // shelf on the x1 wall
+  s.blocks[5] = {{x0, 0.80, 2.00}, {x0 + 0.25, 1.15, z1 - 0.15}};                   // shelf on the x0 wall
+  s.blocks[6] = {{0.60, 1.30, z1 - 0.35}, {1.05, y1, z1}};                          // bookcase on the z1 wall
+  s.blocks[7] = {{1.60, 1.00, z0}, {2.20, y1, z0 + 0.45}};                          // wardrobe on the z0 wall
+  s.blocks[8] = {{0.95, 1.25, z0}, {1.35, 1.75, z0 + 0.20}};                        // picture box on the z0 wall
+  s.blocks[9] = {{x1 - 0.55, 0.95, 1.85}, {x1, y1, 2.10}};                          // pillar on the x1 wall
+  s.blocks[10] = {{1.25, 1.15, z1 - 0.25}, {1.85, 1.40, z1}};                       // shelf on the z1 wall
+  s.blocks[11] = {{x0, 1.35, 0.95}, {x0 + 0.20, 1.60, 1.25}};                       // small box on the x0 wall
+  // two rails running round the room (a picture rail and a dado rail): horizontal edges in EVERY view, which is
+  // what keeps the vertical translation observable while the camera faces a flat wall
+  const double rail[2][3] = {{1.15, 1.27, 0.10}, {1.80, 1.90, 0.06}};  // y from, y to, depth
+  for (int r = 0; r < 2; ++r) {
+    const double ya = rail[r][0], yb = rail[r][1], dp = rail[r][2];
+    s.blocks[12 + 4 * r + 0] = {{x0, ya, z0}, {x0 + dp, yb, z1}};
+    s.blocks[12 + 4 * r + 1] = {{x1 - dp, ya, z0}, {x1, yb, z1}};
+    s.blocks[12 + 4 * r + 2] = {{x0, ya, z0}, {x1, yb, z0 + dp}};
+    s.blocks[12 + 4 * r + 3] = {{x0, ya, z1 - dp}, {x1, yb, z1}};
+  }
+  // the ceiling (low y) carries two crossing beams and a lamp box: the upward-looking turn would otherwise see one
+  // flat ceiling and one flat wall, free to slide along their common edge
+  const double y0 = e[2];
+  s.blocks[20] = {{x0, y0, 1.00}, {x1, y0 + 0.15, 1.15}};
+  s.blocks[21] = {{1.70, y0, z0}, {1.85, y0 + 0.12, z1}};
+  s.blocks[22] = {{1.25, y0, 1.75}, {1.55, y0 + 0.35, 2.05}};
+  s.sphere_c[0] = x1 - 0.45;
+  s.sphere_c[1] = 1.55;
+  s.sphere_c[2] = z0 + 0.50;
+  s.sphere_r = 0.25;
+  return s;
+}
+
+double trace_box_outside(const Box& b, const double o[3], const double d[3]) {  // slab method, entry point
+  double t0 = 0.0, t1 = std::numeric_limits<double>::infinity();
+  for (int ax = 0; ax < 3; ++ax) {
+    if (d[ax] == 0.0) {
+      if (o[ax] < b.lo[ax] || o[ax] > b.hi[ax]) return std::numeric_limits<double>::infinity();
+      continue;
+    }
+    double a = (b.lo[ax] - o[ax]) / d[ax], c = (b.hi[ax] - o[ax]) / d[ax];
+    if (a > c) {
+      const double t = a;
+      a = c;
+      c = t;
+    }
+    if (a > t0) t0 = a;
+    if (c < t1) t1 = c;
+    if (t0 > t1) return std::numeric_limits<double>::infinity();
+  }
+  return t0 > 1e-9 ? t0 : std::numeric_limits<double>::infinity();
+}
+
+double trace_room(const RoomScene& s, const double o[3], const double d[3]) {
+  double best = std::numeric_limits<double>::infinity();
+  // the six walls from inside: the exit point of the ray from the room box
+  {
+    double t1 = std::numeric_limits<double>::infinity();
+    bool inside = true;
+    for (int ax = 0; ax < 3; ++ax) {
+      if (o[ax] < s.room.lo[ax] || o[ax] > s.room.hi[ax]) inside = false;
+      if (d[ax] == 0.0) continue;
+      const double c = ((d[ax] > 0.0 ? s.room.hi[ax] : s.room.lo[ax]) - o[ax]) / d[ax];
+      if (c < t1) t1 = c;
+    }
+    if (inside && t1 > 1e-9) best = t1;
+  }
+  for (const Box& b : s.blocks) {
+    const double t = trace_box_outside(b, o, d);
+    if (t < best) best = t;
+  }
+  {
+    const double oc[3] = {o[0] - s.sphere_c[0], o[1] - s.sphere_c[1], o[2] - s.sphere_c[2]};
+    const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double b = 2.0 * (oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2]);
+    const double c = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - s.sphere_r * s.sphere_r;
+    const double disc = b * b - 4.0 * a * c;
+    if (disc >= 0.0) {
+      const double t = (-b - std::sqrt(disc)) / (2.0 * a);
+      if (t > 1e-9 && t < best) best = t;
+    }
+  }
+  return best;
+}
+}  // namespace
+
+// Room `variant` in its own scan frame: extents (x0, x1, y0, y1, z0, z1) in metres.
+extern "C" int hsk_synth_room_extents(int variant, float extents[6]) {
+  if (!extents) return HSK_ERR_ARG;
+  const RoomScene s = make_room(variant);
+  for (int ax = 0; ax < 3; ++ax) {
+    extents[2 * ax] = (float)s.room.lo[ax];
+    extents[2 * ax + 1] = (float)s.room.hi[ax];
+  }
+  return HSK_OK;
+}
+
+// Turntable pose `frame` of `n_frames`: THREE full turns of yaw from near the room's centre -- the first level
+// (pitch 12 deg * sin(3 yaw)), the second swinging up to 38 deg one way and the third 38 deg the other way (half
+// sines), so that ceiling and floor are scanned once the walls are in the model.  Position: a circle of radius
+// 0.10 m about the centre.  Frame 0 looks along +z from (cx, cy, cz - 0.10).
+extern "C" int hsk_synth_room_pose(int variant, int frame, int n_frames, float pose[16]) {
+  if (!pose || n_frames < 1) return HSK_ERR_ARG;
+  const RoomScene s = make_room(variant);
+  const double c[3] = {0.5 * (s.room.lo[0] + s.room.hi[0]), 0.5 * (s.room.lo[1] + s.room.hi[1]), 0.5 * (s.room.lo[2] + s.room.hi[2])};
+  const double u = (double)frame / (double)n_frames;
+  const double yaw = 6.0 * kPi * u;
+  double pitch;
+  if (u < 1.0 / 3.0)
+    pitch = 12.0 * kPi / 180.0 * std::sin(3.0 * yaw);
+  else if (u < 2.0 / 3.0)
+    pitch = 38.0 * kPi / 180.0 * std::sin(3.0 * kPi * (u - 1.0 / 3.0));
+  else
+    pitch = -38.0 * kPi / 180.0 * std::sin(3.0 * kPi * (u - 2.0 / 3.0));
+  const double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+  const double R[9] = {cy, sy * sp, sy * cp, 0.0, cp, -sp, -sy, cy * sp, cy * cp};  // Ry(yaw) Rx(pitch)
+  const double t[3] = {c[0] - 0.10 * std::sin(yaw), c[1], c[2] - 0.10 * std::cos(yaw)};
+  for (int i = 0; i < 3; ++i) {
+    pose[i * 4] = (float)R[i * 3];
+    pose[i * 4 + 1] = (float)R[i * 3 + 1];
+    pose[i * 4 + 2] = (float)R[i * 3 + 2];
+    pose[i * 4 + 3] = (float)t[i];
+  }
+  pose[12] = pose[13] = pose[14] = 0.0f;
+  pose[15] = 1.0f;
+  return HSK_OK;
+}
+
+extern "C" int hsk_synth_room_render(int variant, const float pose[16], int w, int h, float fx, float fy, float cx, float cy,
+                                     uint16_t* depth) {
+  if (!pose || !depth || w <= 0 || h <= 0) return HSK_ERR_ARG;
+  const RoomScene s = make_room(variant);
+  double R[9], o[3];
+  for (int i = 0; i < 3; ++i) {
+    R[i * 3] = pose[i * 4];
+    R[i * 3 + 1] = pose[i * 4 + 1];
+    R[i * 3 + 2] = pose[i * 4 + 2];
+    o[i] = pose[i * 4 + 3];
+  }
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      const double dc[3] = {((double)u - (double)cx) / (double)fx, ((double)v - (double)cy) / (double)fy, 1.0};
+      const double d[3] = {R[0] * dc[0] + R[1] * dc[1] + R[2] * dc[2], R[3] * dc[0] + R[4] * dc[1] + R[5] * dc[2],
+                           R[6] * dc[0] + R[7] * dc[1] + R[8] * dc[2]};
+      const double t = trace_room(s, o, d);
+      uint16_t mm = 0;
+      if (t < 10.0) {
+        const double r = std::nearbyint(t * 1000.0);
+        if (r >= 1.0 && r <= 65535.0) mm = (uint16_t)r;
+      }
+      depth[(size_t)v * w + u] = mm;
+    }
+  return HSK_OK;
+}

@@ -227,6 +227,30 @@ def synth_depth(pose, w=640, h=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
     return d
 
 
+def synth_room_extents(variant):
+    """(x0, x1, y0, y1, z0, z1) of closed synthetic room `variant` in its own scan frame"""
+    e = np.empty(6, np.float32)
+    _lib.load().hsk_synth_room_extents(int(variant), _fp(e))
+    return e
+
+
+def synth_room_pose(variant, frame, n_frames):
+    p = np.empty(16, np.float32)
+    rc = _lib.load().hsk_synth_room_pose(int(variant), int(frame), int(n_frames), _fp(p))
+    if rc != 0:
+        raise KinfuError(f"hsk_synth_room_pose failed ({rc})")
+    return p.reshape(4, 4)
+
+
+def synth_room_depth(variant, pose, w=640, h=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
+    p = np.ascontiguousarray(pose, np.float32).reshape(16)
+    d = np.empty((h, w), np.uint16)
+    rc = _lib.load().hsk_synth_room_render(int(variant), _fp(p), w, h, fx, fy, cx, cy, d.ctypes.data)
+    if rc != 0:
+        raise KinfuError(f"hsk_synth_room_render failed ({rc})")
+    return d
+
+
 def bilateral_tables():
     lib = _lib.load()
     ws = np.empty(169, np.float32)

@@ -135,6 +135,10 @@ int hsk_bilateral_tables(float ws[169], float wc[512]);
 /* Deterministic synthetic depth stream; host-only, no GPU needed. */
 int hsk_synth_pose(int frame, float pose[16]);
 int hsk_synth_render(const float pose[16], int w, int h, float fx, float fy, float cx, float cy, uint16_t* depth);
+/* closed box rooms with furniture for the room-stitching configurations (BASELINE configs[0], [4]); variant 0..3 */
+int hsk_synth_room_extents(int variant, float extents[6] /* x0 x1 y0 y1 z0 z1 */);
+int hsk_synth_room_pose(int variant, int frame, int n_frames, float pose[16]); /* three turns from near the centre: level, up, down */
+int hsk_synth_room_render(int variant, const float pose[16], int w, int h, float fx, float fy, float cx, float cy, uint16_t* depth);
 
 /* Products on the file seam (Main.hs:1740, :1320-1345): binary PCD with float32 x y z */
 int hsk_write_pcd_xyz(const char* path, const float* xyz, size_t n_points);

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def bits(a):
@@ -487,3 +488,49 @@ def test_async_tracking_loss_drops_in_flight_frames(hsk, synth_frames):
     trk.submit_frame_dev(good[1].data_ptr())
     assert trk.wait_frame()[1] is False and trk.wait_frame()[1] is True
     trk.close()
+
+
+def test_scan_two_rooms_and_stitch(tmp_path, hsk):
+    """BASELINE configs[0] end to end: two closed rooms scanned by the core (three turns each) -> room directories ->
+    loadRoom / orient / corner suggestions / cuboid fit / wall connections / least-squares placement -> .xf and a
+    stitched .ply (tools/stitch_rooms_demo.py is the same flow as a script)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stitch_rooms_demo as demo
+    from housescan_amd import house as H
+    from housescan_amd import products as P
+    dirs, truth = [], []
+    for v in (0, 1):
+        cloud, worst, lost, _ = demo.scan_room(hsk, v, 256, 720)
+        assert lost == 0 and worst < 0.03, (v, lost, worst)
+        d = str(tmp_path / f"room{v}" / "walls")
+        planes, n_down = P.write_room_dir(d, cloud, leaf=0.04, dist_thresh=0.025, min_fraction=0.03)
+        assert len(planes) >= 6 and n_down > 8000
+        dirs.append(d)
+        e = hsk.synth_room_extents(v)
+        truth.append(sorted([e[1] - e[0], e[3] - e[2], e[5] - e[4]]))
+    hs, rooms, rm = demo.stitch(hsk, dirs, [0, 1], log=lambda *_: None)
+    assert np.all(rm < 1e-5)
+    merged = []
+    for rid, d, dims in zip(rooms, dirs, truth):
+        ids, corners = hs.room_corners(rid)
+        ext = corners.max(axis=0) - corners.min(axis=0)
+        assert np.allclose(sorted(ext), dims, atol=0.03), (ext, dims)          # the fitted cuboid is the room
+        M = hs.room_projection(rid)
+        assert abs(np.linalg.det(M[:3, :3].astype(np.float64)) - 1) < 1e-5
+        merged.append(P.transform_cloud(H.read_pcd_xyz(os.path.join(d, "cloud_bin.pcd")), M))
+    a, b = (hs.room_corners(r)[1] for r in rooms)
+    lo = lambda c, ax: np.sort(c[:, ax])[:4].mean()       # noqa: E731  (mean of a fitted cuboid's low / high face)
+    hi = lambda c, ax: np.sort(c[:, ax])[4:].mean()       # noqa: E731
+    assert abs((lo(b, 0) - hi(a, 0)) - 0.1) < 1e-4                             # 10 cm wall between the rooms
+    assert abs(lo(b, 1) - lo(a, 1)) < 1e-4 and abs(lo(b, 2) - lo(a, 2)) < 1e-4  # floors level, low-z walls flush
+    # ... and the full-resolution clouds, moved by the exported matrices, show the same gap: no scan point of either
+    # room lies inside the shared wall
+    gap_lo, gap_hi = hi(a, 0), lo(b, 0)
+    for cloud in merged:
+        inside = (cloud[:, 0] > gap_lo + 0.03) & (cloud[:, 0] < gap_hi - 0.03)
+        assert inside.mean() < 1e-3
+    assert np.percentile(merged[0][:, 0], 99.5) < gap_lo + 0.03 and np.percentile(merged[1][:, 0], 0.5) > gap_hi - 0.03
+    H.write_ply_points(str(tmp_path / "house.ply"), np.concatenate(merged))
+    assert len(H.read_ply_points(str(tmp_path / "house.ply"))) == sum(len(m) for m in merged)
+    hs.close()

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""End to end on one MI355X: scan closed synthetic rooms with the KinFu core, write the room directories HouseScan
+loads, run the host-side stitching chain on them and export one .xf per room plus the stitched cloud as .ply.
+
+  python tools/stitch_rooms_demo.py --rooms 2 --volume 256 --frames 720 --out gpurun_out/stitch
+
+This is BASELINE configs[0] (two rooms -> cuboid fit + translation optimiser -> export) fed by configs[2]-style
+scans; with --rooms 4 it is the single-GPU form of configs[4].  The "user" who clicks corners in HouseScan is
+emulated: of the suggested corners, the 8 nearest to the true room corners are accepted.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def scan_room(hsk, variant, n, frames, device_id=0):
+    """the three-turn scan inside room `variant`; returns (cloud, worst translation error [m], lost frames, fps)"""
+    first = hsk.synth_room_pose(variant, 0, frames)
+    trk = hsk.KinfuTracker(n=n, init_pose=first, device_id=device_id)
+    depth = [hsk.synth_room_depth(variant, hsk.synth_room_pose(variant, k, frames)) for k in range(frames + 1)]
+    worst, lost = 0.0, 0
+    t0 = time.perf_counter()
+    for k, d in enumerate(depth):
+        pose, ok = trk.process_frame(d)
+        lost += (not ok) and k > 0   # frame 0 only seeds the model
+        gt = hsk.synth_room_pose(variant, k, frames)
+        worst = max(worst, float(np.linalg.norm(pose[:3, 3] - gt[:3, 3])))
+    dt = time.perf_counter() - t0
+    cloud, total = trk.extract_cloud()
+    trk.close()
+    return cloud, worst, lost, len(depth) / dt
+
+
+def true_corners(extents):
+    x0, x1, y0, y1, z0, z1 = [float(v) for v in extents]
+    return np.array([[x, y, z] for x in (x0, x1) for y in (y0, y1) for z in (z0, z1)], np.float64)
+
+
+def stitch(hsk, room_dirs, variants, log=print):
+    from housescan_amd import house as H
+    hs = H.House()
+    rooms = []
+    for d, v in zip(room_dirs, variants):
+        rid = hs.loadRoom(d)
+        hs.rotateKinfuRoom(rid)
+        hs.autoAlignFloor(rid)
+        n, adopted = hs.suggestPoints(rid)
+        if not adopted:
+            # the user's clicks: accept the suggestion nearest to each true corner
+            M = hs.room_projection(rid).astype(np.float64)
+            want = true_corners(hsk.synth_room_extents(v)) @ M[:3, :3].T + M[:3, 3]
+            ids, xyz = hs.room_corners(rid, suggested=True)
+            picked = []
+            for c in want:
+                k = int(np.argmin(np.linalg.norm(xyz - c, axis=1)))
+                if ids[k] not in picked:
+                    picked.append(ids[k])
+                    hs.acceptCornerSuggestion(rid, ids[k])
+        p, steps, rmse = hs.fitCuboidToRoom(rid)
+        log(f"room {rid} ({os.path.basename(os.path.dirname(d))}): {n} corner suggestions, cuboid {np.round(np.abs(p[3:6]), 3)} "
+            f"in {steps} steps, RMSE {rmse:.4f}")
+        rooms.append(rid)
+
+    def wall(room, axis, sign):
+        ids, _ = hs.room_planes(room)
+        return max(ids, key=lambda q: sign * hs.plane_bounds(q).mean(axis=0)[axis])
+
+    # a row of rooms along x: shared walls 10 cm thick, floors level, the low-z walls flush
+    for a, b in zip(rooms[:-1], rooms[1:]):
+        hs.connectWalls(wall(a, 0, +1), wall(b, 0, -1), H.OPPOSITE, 0.1)
+        hs.connectWalls(wall(a, 1, -1), wall(b, 1, -1), H.SAME)
+        hs.connectWalls(wall(a, 2, -1), wall(b, 2, -1), H.SAME)
+    rm = hs.optimizeRoomPositions()
+    log(f"placement RMSE per axis: {rm}")
+    return hs, rooms, rm
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rooms", type=int, default=2)
+    ap.add_argument("--volume", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=720, help="frames of the three-turn room trajectory")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stitch"))
+    args = ap.parse_args()
+
+    import housescan_amd as hsk
+    from housescan_amd import house as H
+    from housescan_amd import products as P
+
+    os.makedirs(args.out, exist_ok=True)
+    report = {"rooms": []}
+    dirs, variants = [], list(range(args.rooms))
+    for v in variants:
+        cloud, worst, lost, fps = scan_room(hsk, v, args.volume, args.frames)
+        d = os.path.join(args.out, f"room{v}", "walls")
+        planes, n_down = P.write_room_dir(d, cloud, leaf=0.04, dist_thresh=0.025, min_fraction=0.03)
+        print(f"room{v}: {len(cloud)} points, {n_down} downsampled, {len(planes)} planes, worst pose error {worst * 1000:.1f} mm, "
+              f"lost {lost}, {fps:.0f} frames/s incl. upload")
+        report["rooms"].append({"variant": v, "points": int(len(cloud)), "planes": int(len(planes)), "worst_pose_error_mm": worst * 1000,
+                                "lost": int(lost), "fps_host_frames": fps})
+        dirs.append(d)
+    hs, rooms, rm = stitch(hsk, dirs, variants)
+    merged = []
+    for rid, d in zip(rooms, dirs):
+        M = hs.room_projection(rid)
+        base = os.path.basename(os.path.dirname(d))
+        with open(os.path.join(args.out, base + ".xf"), "w") as f:
+            f.write(hs.roomProjectionToXfFormat(rid))
+        full = H.read_pcd_xyz(os.path.join(os.path.dirname(d), "walls", "cloud_bin.pcd"))
+        merged.append(P.transform_cloud(full, M))
+        print(f"{base}: pcl_transform_point_cloud -matrix {hs.roomProjectionToString(rid)}")
+    merged = np.concatenate(merged)
+    H.write_ply_points(os.path.join(args.out, "house.ply"), merged)
+    report["placement_rmse"] = [None if np.isnan(x) else float(x) for x in rm]
+    report["house_points"] = int(len(merged))
+    with open(os.path.join(args.out, "report.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps(report))
+
+
+if __name__ == "__main__":
+    main()
