@@ -65,6 +65,7 @@ SYMBOLS = {
     "hsk_download_depth_level": (C.c_int, [_P, C.c_int, _P]),
     "hsk_download_scaled_depth": (C.c_int, [_P, _P]),
     "hsk_extract_cloud": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "hsk_extract_mesh": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_mgpu_frame_begin": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "hsk_mgpu_icp_accumulate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "hsk_mgpu_icp_update": (C.c_int, [_P, _P]),
@@ -86,6 +87,8 @@ SYMBOLS = {
     "hsk_synth_room_pose": (C.c_int, [C.c_int, C.c_int, C.c_int, _F]),
     "hsk_synth_room_render": (C.c_int, [C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hsk_write_pcd_xyz": (C.c_int, [C.c_char_p, _P, C.c_size_t]),
+    "hsk_write_ply_mesh": (C.c_int, [C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "hsk_weld_triangles": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t), _P]),
     "hsk_voxel_downsample": (C.c_int, [_P, C.c_size_t, C.c_float, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_detect_planes": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, _P, _P, _I]),
     "hsk_plane_hull": (C.c_int, [_P, C.c_size_t, _P, C.c_int, _F, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -45,6 +45,13 @@ static inline int hsk_flag_words(const VolParams& vp) {
   return (int)(((bits + 31) / 32 + 3) / 4 * 4);  // multiple of 4 words: staged into LDS with 16-B loads
 }
 
+// marching-tetrahedra lookup: per Kuhn tetrahedron and 4-bit inside mask, 0..2 triangles; each triangle corner is an
+// edge of the cube coded (low corner) | (high corner << 4)
+struct TetTable {
+  unsigned char ntri[6][16];
+  unsigned char edge[6][16][2][3];
+};
+
 #define HSK_NANF (__builtin_nanf(""))
 
 static __device__ __forceinline__ bool hsk_isnan(float x) { return x != x; }

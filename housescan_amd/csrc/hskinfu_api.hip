@@ -904,6 +904,34 @@ extern "C" int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size
   return HSK_OK;
 }
 
+// Triangle soup (9 floats per triangle) of the TSDF zero level set, marching tetrahedra, voxel order.
+extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles) {
+  if (!k || !n_triangles) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // >= the mesh rows; shared with hsk_extract_cloud
+  if (!k->d_rowcnt) {
+    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
+    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
+  }
+  TetTable tt;
+  hsk_build_tet_table(&tt);
+  launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
+  unsigned long long total = 0;
+  HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  *n_triangles = (size_t)total;
+  if (!tri_xyz || cap_triangles == 0 || total == 0) return HSK_OK;
+  const size_t nw = total < cap_triangles ? (size_t)total : cap_triangles;
+  float* d_tri = nullptr;
+  HIPCHK(k, hipMalloc((void**)&d_tri, nw * 36));
+  launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, d_tri, nw, 1);
+  hipError_t e = hipMemcpyAsync(tri_xyz, d_tri, nw * 36, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  (void)hipFree(d_tri);
+  HIPCHK(k, e);
+  return HSK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // profiling
 // ------------------------------------------------------------------------------------------------------

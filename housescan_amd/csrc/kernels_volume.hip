@@ -1073,6 +1073,178 @@ __global__ __launch_bounds__(1024) void k_scan_rows(const unsigned* __restrict__
   if (threadIdx.x == 0) *total = carry;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Mesh extraction ("next" row 3): marching tetrahedra over the TSDF, triangle soup in voxel order.
+// A cube (x..x+1, y..y+1, z..z+1) is cut into the six Kuhn tetrahedra round its main diagonal (the same cut in
+// every cube, so faces of neighbouring cubes agree); corner i sits at offset (i&1, i>>1&1, i>>2&1).  A cube counts
+// only when all eight weights are non-zero; a corner is inside when its TSDF is negative.  An edge vertex is
+// P = Pa + (Fa / (Fa - Fb)) (Pb - Pa) with a the LOWER corner index, so both cubes that share an edge produce the
+// same bits (the mesh can be welded by exact comparison).  Triangles wind so that the normal points to free space.
+// ------------------------------------------------------------------------------------------------------
+void hsk_build_tet_table(TetTable* tt) {
+  static const int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
+  for (int t = 0; t < 6; ++t)
+    for (int m = 0; m < 16; ++m) {
+      int in[4], out[4], ni = 0, no = 0;
+      for (int v = 0; v < 4; ++v) {
+        if ((m >> v) & 1)
+          in[ni++] = tet[t][v];
+        else
+          out[no++] = tet[t][v];
+      }
+      int e[2][3][2];
+      int nt = 0;
+      if (ni == 1 || ni == 3) {
+        const int apex = ni == 1 ? in[0] : out[0];
+        const int* base = ni == 1 ? out : in;
+        for (int q = 0; q < 3; ++q) e[0][q][0] = apex, e[0][q][1] = base[q];
+        nt = 1;
+      } else if (ni == 2) {
+        const int quad[4][2] = {{in[0], out[0]}, {in[0], out[1]}, {in[1], out[1]}, {in[1], out[0]}};
+        const int pick[2][3] = {{0, 1, 2}, {0, 2, 3}};
+        for (int k = 0; k < 2; ++k)
+          for (int q = 0; q < 3; ++q) e[k][q][0] = quad[pick[k][q]][0], e[k][q][1] = quad[pick[k][q]][1];
+        nt = 2;
+      }
+      // orientation: the normal of (p0, p1, p2) (edge midpoints) must point from the inside corners to the outside ones
+      double ci[3] = {0, 0, 0}, co[3] = {0, 0, 0};
+      for (int v = 0; v < ni; ++v)
+        for (int a = 0; a < 3; ++a) ci[a] += ((in[v] >> a) & 1) / (double)(ni ? ni : 1);
+      for (int v = 0; v < no; ++v)
+        for (int a = 0; a < 3; ++a) co[a] += ((out[v] >> a) & 1) / (double)(no ? no : 1);
+      for (int k = 0; k < nt; ++k) {
+        double pnt[3][3];
+        for (int q = 0; q < 3; ++q)
+          for (int a = 0; a < 3; ++a) pnt[q][a] = 0.5 * (((e[k][q][0] >> a) & 1) + ((e[k][q][1] >> a) & 1));
+        const double u[3] = {pnt[1][0] - pnt[0][0], pnt[1][1] - pnt[0][1], pnt[1][2] - pnt[0][2]};
+        const double w[3] = {pnt[2][0] - pnt[0][0], pnt[2][1] - pnt[0][1], pnt[2][2] - pnt[0][2]};
+        const double nrm[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+        const double dir = nrm[0] * (co[0] - ci[0]) + nrm[1] * (co[1] - ci[1]) + nrm[2] * (co[2] - ci[2]);
+        if (dir < 0)
+          for (int a = 0; a < 2; ++a) {
+            const int tmp = e[k][1][a];
+            e[k][1][a] = e[k][2][a];
+            e[k][2][a] = tmp;
+          }
+      }
+      tt->ntri[t][m] = (unsigned char)nt;
+      for (int k = 0; k < 2; ++k)
+        for (int q = 0; q < 3; ++q) {
+          const int a = k < nt ? e[k][q][0] : 0, b = k < nt ? e[k][q][1] : 0;
+          tt->edge[t][m][k][q] = (unsigned char)((a < b ? a : b) | ((a < b ? b : a) << 4));  // low corner first
+        }
+    }
+}
+
+// triangles of the cube at (x, y, z); when WRITE, stores 9 floats per triangle at tri + 9 * (at + i) while at + i < cap
+template <bool WRITE>
+static __device__ int cube_triangles(const short2* __restrict__ vol, const VolParams& vp, const TetTable& tt, int x, int y, int z,
+                                     float* __restrict__ tri, unsigned long long at, unsigned long long cap) {
+  short2 v[8];
+  bool ok = true;
+  unsigned m8 = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v[c] = vol[((size_t)(z + (c >> 2) - vp.zs0) * vp.Y + (y + ((c >> 1) & 1))) * vp.X + (x + (c & 1))];
+    ok = ok && v[c].y != 0;
+    m8 |= (v[c].x < 0 ? 1u : 0u) << c;
+  }
+  if (!ok || m8 == 0u || m8 == 255u) return 0;
+  const int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
+  int n = 0;
+  for (int t = 0; t < 6; ++t) {
+    const unsigned m = ((m8 >> tet[t][0]) & 1u) | (((m8 >> tet[t][1]) & 1u) << 1) | (((m8 >> tet[t][2]) & 1u) << 2) |
+                       (((m8 >> tet[t][3]) & 1u) << 3);
+    const int nt = tt.ntri[t][m];
+    if (WRITE) {
+      for (int k = 0; k < nt; ++k) {
+        const unsigned long long slot = at + (unsigned long long)(n + k);
+        if (slot >= cap) continue;
+        for (int q = 0; q < 3; ++q) {
+          const unsigned code = tt.edge[t][m][k][q];
+          const int a = (int)(code & 15u), b = (int)(code >> 4);
+          // dynamic corner selection without a scratch array
+          short fa = 0, fb = 0;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            fa = c == a ? v[c].x : fa;
+            fb = c == b ? v[c].x : fb;
+          }
+          const float Fa = (float)fa / 32767.0f, Fb = (float)fb / 32767.0f;
+          const float w = Fa / (Fa - Fb);
+          const int ga[3] = {x + (a & 1), y + ((a >> 1) & 1), z + (a >> 2)};
+          const int gb[3] = {x + (b & 1), y + ((b >> 1) & 1), z + (b >> 2)};
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const float pa = ((float)ga[ax] + 0.5f) * vp.cell[ax];
+            const float pb = ((float)gb[ax] + 0.5f) * vp.cell[ax];
+            tri[9 * slot + 3 * q + ax] = pa + w * (pb - pa);
+          }
+        }
+      }
+    }
+    n += nt;
+  }
+  return n;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_extract_mesh(const short2* __restrict__ vol, VolParams vp, TetTable tt,
+                                                      unsigned* __restrict__ row_count,
+                                                      const unsigned long long* __restrict__ row_offset,
+                                                      float* __restrict__ tri, unsigned long long cap, int z_end) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int ny = vp.Y - 1;
+  const int nrows = ny * (z_end - vp.zo0);
+  if (row >= nrows) return;
+  const int y = row % ny, z = vp.zo0 + row / ny;
+  unsigned long long base = WRITE ? row_offset[row] : 0;
+  unsigned total = 0;
+  for (int xb = 0; xb < vp.X - 1; xb += 64) {
+    const int x = xb + lane;
+    const int n = x < vp.X - 1 ? cube_triangles<false>(vol, vp, tt, x, y, z, nullptr, 0, 0) : 0;
+    int scan = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(scan, o, 64);
+      if (lane >= o) scan += u;
+    }
+    const int wave_total = __shfl(scan, 63, 64);
+    if (WRITE) {
+      if (n) cube_triangles<true>(vol, vp, tt, x, y, z, tri, base + (unsigned long long)(scan - n), cap);
+      base += wave_total;
+    }
+    total += wave_total;
+  }
+  if (!WRITE && lane == 0) row_count[row] = total;
+}
+
+// cubes whose base plane this context owns and whose upper plane is stored
+int hsk_mesh_z_end(const VolParams& vp) {
+  int z_end = vp.zo1;
+  if (z_end > vp.zs0 + vp.nzs - 1) z_end = vp.zs0 + vp.nzs - 1;
+  if (z_end > vp.Z - 1) z_end = vp.Z - 1;
+  return z_end > vp.zo0 ? z_end : vp.zo0;
+}
+
+void launch_extract_mesh(hipStream_t s, const void* vol, const VolParams& vp, const TetTable& tt, unsigned* row_count,
+                         unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass) {
+  const int z_end = hsk_mesh_z_end(vp);
+  const int nrows = (vp.Y - 1) * (z_end - vp.zo0);
+  if (nrows <= 0) {
+    if (pass == 0) (void)hipMemsetAsync(total, 0, 8, s);
+    return;
+  }
+  dim3 block(256), grid((nrows + 3) / 4);
+  if (pass == 0) {
+    hipLaunchKernelGGL(k_extract_mesh<false>, grid, block, 0, s, (const short2*)vol, vp, tt, row_count, row_offset, tri, cap, z_end);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_count, row_offset, nrows, total);
+  } else {
+    hipLaunchKernelGGL(k_extract_mesh<true>, grid, block, 0, s, (const short2*)vol, vp, tt, row_count, row_offset, tri, cap, z_end);
+  }
+}
+
 void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,
                     unsigned long long* row_offset, unsigned long long* total, float* xyz, unsigned long long cap,
                     int pass) {

@@ -394,3 +394,86 @@ extern "C" int hsk_stream_close(hsk_depth_stream* s) {
   delete s;
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// mesh products: weld a triangle soup by exact vertex coordinates, write a binary .ply mesh
+// ---------------------------------------------------------------------------------------------------------------
+#include <cstring>
+#include <unordered_map>
+
+namespace {
+struct VKey {
+  uint32_t a, b, c;
+  bool operator==(const VKey& o) const { return a == o.a && b == o.b && c == o.c; }
+};
+struct VKeyHash {
+  size_t operator()(const VKey& k) const {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ k.a;
+    h = (h ^ (h >> 29)) * 0xbf58476d1ce4e5b9ull ^ k.b;
+    h = (h ^ (h >> 32)) * 0x94d049bb133111ebull ^ k.c;
+    return (size_t)(h ^ (h >> 31));
+  }
+};
+// vertices in order of first appearance; -0.0 is folded onto +0.0 so that equal points weld
+void weld(const float* tri, size_t n_tri, std::vector<float>& verts, std::vector<int32_t>& idx) {
+  std::unordered_map<VKey, int32_t, VKeyHash> seen;
+  seen.reserve(n_tri * 2);
+  idx.resize(n_tri * 3);
+  for (size_t i = 0; i < n_tri * 3; ++i) {
+    float p[3] = {tri[3 * i] + 0.0f, tri[3 * i + 1] + 0.0f, tri[3 * i + 2] + 0.0f};
+    VKey k;
+    std::memcpy(&k, p, 12);
+    auto it = seen.find(k);
+    if (it == seen.end()) {
+      const int32_t id = (int32_t)(verts.size() / 3);
+      seen.emplace(k, id);
+      verts.insert(verts.end(), p, p + 3);
+      idx[i] = id;
+    } else {
+      idx[i] = it->second;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int hsk_weld_triangles(const float* tri_xyz, size_t n_triangles, float* vertices, size_t cap_vertices, size_t* n_vertices,
+                                  int32_t* indices) {
+  if ((!tri_xyz && n_triangles) || !n_vertices) return HSK_ERR_ARG;
+  std::vector<float> verts;
+  std::vector<int32_t> idx;
+  weld(tri_xyz, n_triangles, verts, idx);
+  *n_vertices = verts.size() / 3;
+  if (!vertices && !indices) return HSK_OK;
+  if (vertices) {
+    if (cap_vertices < verts.size() / 3) return HSK_ERR_ARG;
+    if (!verts.empty()) std::memcpy(vertices, verts.data(), verts.size() * 4);
+  }
+  if (indices && !idx.empty()) std::memcpy(indices, idx.data(), idx.size() * 4);
+  return HSK_OK;
+}
+
+extern "C" int hsk_write_ply_mesh(const char* path, const float* tri_xyz, size_t n_triangles, size_t* n_vertices_out, size_t* n_faces_out) {
+  if (!path || (!tri_xyz && n_triangles)) return HSK_ERR_ARG;
+  std::vector<float> verts;
+  std::vector<int32_t> idx;
+  weld(tri_xyz, n_triangles, verts, idx);
+  size_t faces = 0;
+  for (size_t t = 0; t < n_triangles; ++t)
+    if (idx[3 * t] != idx[3 * t + 1] && idx[3 * t + 1] != idx[3 * t + 2] && idx[3 * t] != idx[3 * t + 2]) ++faces;
+  FILE* f = fopen(path, "wb");
+  if (!f) return HSK_ERR_STATE;
+  fprintf(f,
+          "ply\nformat binary_little_endian 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\n"
+          "element face %zu\nproperty list uchar int vertex_indices\nend_header\n",
+          verts.size() / 3, faces);
+  bool ok = verts.empty() || fwrite(verts.data(), 4, verts.size(), f) == verts.size();
+  for (size_t t = 0; t < n_triangles && ok; ++t) {
+    if (idx[3 * t] == idx[3 * t + 1] || idx[3 * t + 1] == idx[3 * t + 2] || idx[3 * t] == idx[3 * t + 2]) continue;
+    const unsigned char three = 3;
+    ok = fwrite(&three, 1, 1, f) == 1 && fwrite(&idx[3 * t], 4, 3, f) == 3;
+  }
+  const int rc = fclose(f);
+  if (n_vertices_out) *n_vertices_out = verts.size() / 3;
+  if (n_faces_out) *n_faces_out = faces;
+  return (ok && rc == 0) ? HSK_OK : HSK_ERR_STATE;
+}

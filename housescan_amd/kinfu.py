@@ -190,6 +190,17 @@ class KinfuTracker:
             self._ck(self.lib.hsk_extract_cloud(self.h, out.ctypes.data, m, C.byref(n)))
         return out, total
 
+    def extract_mesh(self, cap=None):
+        """TSDF zero level set as triangles [n, 3, 3] (marching tetrahedra, voxel order) -> (triangles, total)"""
+        n = C.c_size_t()
+        self._ck(self.lib.hsk_extract_mesh(self.h, None, 0, C.byref(n)))
+        total = n.value
+        m = total if cap is None else min(cap, total)
+        out = np.empty((m, 3, 3), np.float32)
+        if m:
+            self._ck(self.lib.hsk_extract_mesh(self.h, out.ctypes.data, m, C.byref(n)))
+        return out, total
+
     # ---- streams / profiling -----------------------------------------------------------------------
     def stream(self):
         return self.lib.hsk_stream(self.h)

@@ -35,6 +35,26 @@ def write_pcd(path, xyz):
     _ck(lib.hsk_write_pcd_xyz(os.fsencode(path), pts.ctypes.data, len(pts)), "hsk_write_pcd_xyz")
 
 
+def write_ply_mesh(path, triangles):
+    """triangle soup [n, 3, 3] -> welded binary .ply mesh; returns (vertices, faces) written"""
+    lib = _lib.load()
+    tri = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+    nv, nf = C.c_size_t(), C.c_size_t()
+    _ck(lib.hsk_write_ply_mesh(os.fsencode(path), tri.ctypes.data, len(tri), C.byref(nv), C.byref(nf)), "hsk_write_ply_mesh")
+    return nv.value, nf.value
+
+
+def weld_triangles(triangles):
+    """triangle soup [n, 3, 3] -> (vertices [v, 3] in order of first appearance, indices [n, 3])"""
+    lib = _lib.load()
+    tri = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+    nv = C.c_size_t()
+    verts = np.empty((max(1, 3 * len(tri)), 3), np.float32)
+    idx = np.empty((len(tri), 3), np.int32)
+    _ck(lib.hsk_weld_triangles(tri.ctypes.data, len(tri), verts.ctypes.data, len(verts), C.byref(nv), idx.ctypes.data), "hsk_weld_triangles")
+    return verts[:nv.value].copy(), idx
+
+
 def detect_planes(xyz, dist_thresh=0.02, min_fraction=0.03, max_planes=12, iterations=300):
     """-> (planes [k,4] as a,b,c,d of ax+by+cz+d=0 with unit normal, labels [n])"""
     lib = _lib.load()

@@ -106,6 +106,10 @@ int hsk_download_scaled_depth(hsk_ctx* k, float* out);
 
 /* TSDF zero-crossing cloud: packed float32 xyz (the layout of Cloud.cloudPoints, Main.hs:120) in voxel order. */
 int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_points);
+/* TSDF zero level set as a triangle soup, 9 floats per triangle, marching tetrahedra (6 Kuhn tetrahedra per cube),
+ * deterministic voxel order, normals towards free space.  Edge vertices shared by neighbouring cubes are bit-identical,
+ * so hsk_write_ply_mesh can weld them by exact comparison.  Two-call protocol like hsk_extract_cloud. */
+int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles);
 
 /* Multi-GPU (z-slab) building blocks; device pointers so that the host's collective (RCCL through
  * torch.distributed) can run on them without a host round trip.  All work is enqueued on hsk_stream(). */
@@ -142,6 +146,11 @@ int hsk_synth_room_render(int variant, const float pose[16], int w, int h, float
 
 /* Products on the file seam (Main.hs:1740, :1320-1345): binary PCD with float32 x y z */
 int hsk_write_pcd_xyz(const char* path, const float* xyz, size_t n_points);
+/* binary little-endian .ply mesh (the file plyxform / pcl tools take, README.md:16-17): vertices welded by exact
+ * coordinates, faces as uchar-count + int indices; zero-area triangles are dropped.  Returns counts when non-NULL. */
+int hsk_write_ply_mesh(const char* path, const float* tri_xyz, size_t n_triangles, size_t* n_vertices_out, size_t* n_faces_out);
+/* the same welding without a file: indices[3 * n_triangles] into vertices (cap_vertices x 3); degenerate triangles keep index triples with repeats */
+int hsk_weld_triangles(const float* tri_xyz, size_t n_triangles, float* vertices, size_t cap_vertices, size_t* n_vertices, int32_t* indices);
 int hsk_voxel_downsample(const float* xyz, size_t n, float leaf_m, float* out, size_t cap, size_t* n_out);
 /* Plane products loadRoom reads beside the cloud (Main.hs:1392-1404): planes.txt lines "a b c d" in PCL form
  * ax+by+cz+d=0 (planeEqsFromFile, Main.hs:1379-1389) and cloud_plane_hull<k>.pcd polygons (Main.hs:1395-1400).

@@ -724,6 +724,95 @@ size_t ora_extract_cloud(const int16_t* vol, const int dims[3], const float size
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* A.8 extractMesh: marching tetrahedra (this build's own specification -- PCL's marching-cubes tables are not  */
+/* in /root/reference).  Cube corner i at offset (i&1, i>>1&1, i>>2&1); six Kuhn tetrahedra round the diagonal   */
+/* 0-7; cube valid when all 8 weights != 0; inside = TSDF < 0; edge vertex from the LOWER corner index a:        */
+/* P = Pa + (Fa/(Fa-Fb)) (Pb-Pa); triangles wind so that the normal points to free space; voxel order, then     */
+/* tetrahedron order, then triangle order.                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+static const int ora_tet[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
+
+/* triangles (pairs of cube corners per triangle corner) of tetrahedron t under inside-mask m */
+static int ora_tet_case(int t, int m, int e[2][3][2]) {
+  int in[4], out[4], ni = 0, no = 0, nt = 0;
+  for (int v = 0; v < 4; ++v) {
+    if ((m >> v) & 1) in[ni++] = ora_tet[t][v];
+    else out[no++] = ora_tet[t][v];
+  }
+  if (ni == 1 || ni == 3) {
+    const int apex = ni == 1 ? in[0] : out[0];
+    const int* base = ni == 1 ? out : in;
+    for (int q = 0; q < 3; ++q) { e[0][q][0] = apex; e[0][q][1] = base[q]; }
+    nt = 1;
+  } else if (ni == 2) {
+    const int quad[4][2] = {{in[0], out[0]}, {in[0], out[1]}, {in[1], out[1]}, {in[1], out[0]}};
+    const int pick[2][3] = {{0, 1, 2}, {0, 2, 3}};
+    for (int k = 0; k < 2; ++k)
+      for (int q = 0; q < 3; ++q) { e[k][q][0] = quad[pick[k][q]][0]; e[k][q][1] = quad[pick[k][q]][1]; }
+    nt = 2;
+  }
+  double ci[3] = {0, 0, 0}, co[3] = {0, 0, 0};
+  for (int v = 0; v < ni; ++v)
+    for (int a = 0; a < 3; ++a) ci[a] += ((in[v] >> a) & 1) / (double)ni;
+  for (int v = 0; v < no; ++v)
+    for (int a = 0; a < 3; ++a) co[a] += ((out[v] >> a) & 1) / (double)no;
+  for (int k = 0; k < nt; ++k) {
+    double p[3][3];
+    for (int q = 0; q < 3; ++q)
+      for (int a = 0; a < 3; ++a) p[q][a] = 0.5 * (((e[k][q][0] >> a) & 1) + ((e[k][q][1] >> a) & 1));
+    const double u[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
+    const double w[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+    const double n[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+    if (n[0] * (co[0] - ci[0]) + n[1] * (co[1] - ci[1]) + n[2] * (co[2] - ci[2]) < 0)
+      for (int a = 0; a < 2; ++a) { const int tmp = e[k][1][a]; e[k][1][a] = e[k][2][a]; e[k][2][a] = tmp; }
+  }
+  return nt;
+}
+
+size_t ora_extract_mesh(const int16_t* vol, const int dims[3], const float size[3], float* tri, size_t cap) {
+  const int X = dims[0], Y = dims[1], Z = dims[2];
+  const float cell[3] = {size[0] / (float)X, size[1] / (float)Y, size[2] / (float)Z};
+  size_t n = 0;
+  for (int z = 0; z + 1 < Z; ++z)
+    for (int y = 0; y + 1 < Y; ++y)
+      for (int x = 0; x + 1 < X; ++x) {
+        int16_t f[8];
+        int ok = 1, m8 = 0;
+        for (int c = 0; c < 8; ++c) {
+          const size_t i = ((size_t)(z + (c >> 2)) * Y + (y + ((c >> 1) & 1))) * X + (x + (c & 1));
+          f[c] = vol[2 * i];
+          if (vol[2 * i + 1] == 0) ok = 0;
+          if (f[c] < 0) m8 |= 1 << c;
+        }
+        if (!ok || m8 == 0 || m8 == 255) continue;
+        for (int t = 0; t < 6; ++t) {
+          int m = 0;
+          for (int v = 0; v < 4; ++v) m |= ((m8 >> ora_tet[t][v]) & 1) << v;
+          int e[2][3][2];
+          const int nt = ora_tet_case(t, m, e);
+          for (int k = 0; k < nt; ++k) {
+            if (n < cap)
+              for (int q = 0; q < 3; ++q) {
+                int a = e[k][q][0], b = e[k][q][1];
+                if (a > b) { const int tmp = a; a = b; b = tmp; }
+                const float Fa = (float)f[a] / 32767.0f, Fb = (float)f[b] / 32767.0f;
+                const float w = Fa / (Fa - Fb);
+                const int ga[3] = {x + (a & 1), y + ((a >> 1) & 1), z + (a >> 2)};
+                const int gb[3] = {x + (b & 1), y + ((b >> 1) & 1), z + (b >> 2)};
+                for (int ax = 0; ax < 3; ++ax) {
+                  const float pa = ((float)ga[ax] + 0.5f) * cell[ax];
+                  const float pb = ((float)gb[ax] + 0.5f) * cell[ax];
+                  tri[9 * n + 3 * q + ax] = pa + w * (pb - pa);
+                }
+              }
+            ++n;
+          }
+        }
+      }
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* A.2 tracker state machine                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
 struct ora_tracker {

@@ -88,6 +88,7 @@ void ora_raycast(const int16_t* vol, const int dims[3], const float size[3], flo
 
 /* TSDF zero-crossing cloud extraction (A.7); returns number of points written (<= cap). */
 size_t ora_extract_cloud(const int16_t* vol, const int dims[3], const float size[3], float* xyz, size_t cap);
+size_t ora_extract_mesh(const int16_t* vol, const int dims[3], const float size[3], float* tri, size_t cap);
 
 /* ---- whole tracker (A.2) ---- */
 typedef struct ora_tracker ora_tracker;

@@ -43,6 +43,7 @@ def lib(omp=False):
     L.ora_integrate.restype = C.c_uint64
     L.ora_icp_accumulate.restype = C.c_uint64
     L.ora_extract_cloud.restype = C.c_size_t
+    L.ora_extract_mesh.restype = C.c_size_t
     L.ora_tracker_create.restype = C.c_void_p
     L.ora_tracker_volume.restype = C.POINTER(C.c_int16)
     L.ora_tracker_model_vmap.restype = C.POINTER(C.c_float)
@@ -211,6 +212,17 @@ def extract_cloud(cfg, vol, cap=None):
     out = np.empty((m, 3), np.float32)
     if m:
         lib().ora_extract_cloud(_p(vol), dims, size, _f(out), m)
+    return out, int(n)
+
+
+def extract_mesh(cfg, vol, cap=None):
+    dims = (C.c_int * 3)(*cfg.vol)
+    size = (C.c_float * 3)(*cfg.size)
+    n = lib().ora_extract_mesh(_p(vol), dims, size, None, 0)
+    m = n if cap is None else min(cap, n)
+    out = np.empty((m, 3, 3), np.float32)
+    if m:
+        lib().ora_extract_mesh(_p(vol), dims, size, _f(out), m)
     return out, int(n)
 
 

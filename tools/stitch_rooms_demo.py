@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def scan_room(hsk, variant, n, frames, device_id=0):
+def scan_room(hsk, variant, n, frames, device_id=0, with_mesh=False):
     """the three-turn scan inside room `variant`; returns (cloud, worst translation error [m], lost frames, fps)"""
     first = hsk.synth_room_pose(variant, 0, frames)
     trk = hsk.KinfuTracker(n=n, init_pose=first, device_id=device_id)
@@ -34,7 +34,10 @@ def scan_room(hsk, variant, n, frames, device_id=0):
         worst = max(worst, float(np.linalg.norm(pose[:3, 3] - gt[:3, 3])))
     dt = time.perf_counter() - t0
     cloud, total = trk.extract_cloud()
+    mesh = trk.extract_mesh()[0] if with_mesh else None
     trk.close()
+    if with_mesh:
+        return cloud, worst, lost, len(depth) / dt, mesh
     return cloud, worst, lost, len(depth) / dt
 
 
@@ -96,9 +99,10 @@ def main():
 
     os.makedirs(args.out, exist_ok=True)
     report = {"rooms": []}
-    dirs, variants = [], list(range(args.rooms))
+    dirs, variants, meshes = [], list(range(args.rooms)), []
     for v in variants:
-        cloud, worst, lost, fps = scan_room(hsk, v, args.volume, args.frames)
+        cloud, worst, lost, fps, mesh = scan_room(hsk, v, args.volume, args.frames, with_mesh=True)
+        meshes.append(mesh)
         d = os.path.join(args.out, f"room{v}", "walls")
         planes, n_down = P.write_room_dir(d, cloud, leaf=0.04, dist_thresh=0.025, min_fraction=0.03)
         print(f"room{v}: {len(cloud)} points, {n_down} downsampled, {len(planes)} planes, worst pose error {worst * 1000:.1f} mm, "
@@ -118,6 +122,10 @@ def main():
         print(f"{base}: pcl_transform_point_cloud -matrix {hs.roomProjectionToString(rid)}")
     merged = np.concatenate(merged)
     H.write_ply_points(os.path.join(args.out, "house.ply"), merged)
+    # the README's last step (plyxform on KinFu's mesh): every room's mesh moved by its .xf, one welded .ply
+    moved = [P.transform_cloud(m.reshape(-1, 3), hs.room_projection(rid)).reshape(-1, 3, 3) for m, rid in zip(meshes, rooms)]
+    nv, nf = P.write_ply_mesh(os.path.join(args.out, "house_mesh.ply"), np.concatenate(moved))
+    report["house_mesh"] = {"vertices": nv, "faces": nf}
     report["placement_rmse"] = [None if np.isnan(x) else float(x) for x in rm]
     report["house_points"] = int(len(merged))
     with open(os.path.join(args.out, "report.json"), "w") as f:
