@@ -4,7 +4,9 @@ The library is the product; there is NO fallback: if the shared object is missin
 `hsk_create` fails with HSK_ERR_NOGPU when no HIP device is present.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhskinfu.so")
@@ -156,11 +158,33 @@ HOUSE_SYMBOLS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The torch wheel ships its own libamdhip64.so.7 (ROCm 7.0) beside the system's
+    (ROCm 7.2, the one libhskinfu.so names in its RUNPATH); the loader keeps whichever copy comes first for BOTH, and
+    torch cannot initialise on top of the system copy ("No HIP GPUs are available").  So when torch is installed but not
+    imported yet, its copy is loaded first; without torch the system runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime; a later `import torch` in this process may then fail
+
+
 def load():
     """Load libhskinfu.so and bind every symbol; raises if the library or a symbol is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C housescan_amd/csrc` "

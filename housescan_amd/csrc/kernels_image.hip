@@ -335,7 +335,9 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
 // ICP_PX pixels per lane (template): loads batched so that the dependent chain is 2 memory round trips
 #define ICP_BLOCK 256
 #ifndef ICP_PX_FINE
+#ifndef ICP_PX_FINE
 #define ICP_PX_FINE 4  // pixels per lane at the finest level (1 at the coarse levels)
+#endif
 #endif
 
 // Exact accumulation.  The spec sums quant26(p) = rint(p * 2^26) * 2^-26 over pixels, p the binary64 product of
@@ -787,23 +789,77 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
   p.n_iter += 1;
 }
 
+// The 27 sums travel between launches through sharded accumulators instead of per-block partial rows: the
+// products are integer multiples of 2^-26 (exact in binary64), so hardware f64 atomic adds give the same bits in
+// any arrival order, and the next launch reads ICP_SHARDS x 27 doubles instead of (blocks) x 27 (19 MB of L2 reads
+// per fine iteration before).  Three slots rotate: iteration i adds into slot i % 3, reads slot (i - 1) % 3 and
+// clears slot (i + 1) % 3 for its successor; k_begin_frame clears slot 0.
+#define ICP_SHARDS 32
+#define ICP_SLOT_DOUBLES (ICP_SHARDS * 32)
+static __device__ __forceinline__ void shard_reduce27(const double* __restrict__ slot, double (*sh)[32], double* tot) {
+  const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 slices x 4 shards each
+  double v = 0.0;
+  if (slice < 8) {
+    const double a = slot[(slice)*32 + k], b = slot[(slice + 8) * 32 + k], c = slot[(slice + 16) * 32 + k],
+                 d = slot[(slice + 24) * 32 + k];
+    v = (a + b) + (c + d);
+    sh[slice][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double r = sh[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) r += sh[q][threadIdx.x];
+    tot[threadIdx.x] = r;
+  }
+  __syncthreads();
+}
+
+// block sums -> one f64 atomic add per sum into this block's shard
+static __device__ __forceinline__ void icp_block_sums_atomic(const double* acc, double (*sh)[32], double* __restrict__ slot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double v = wave_sum27(acc, lane);
+  if ((lane & 1) == 0) sh[wave][wave_sum27_index(lane)] = v;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < ICP_BLOCK / 64; ++w) r += sh[w][threadIdx.x];
+    if (r != 0.0)
+      __hip_atomic_fetch_add(slot + (blockIdx.x % ICP_SHARDS) * 32 + threadIdx.x, r * ICP_UNSCALE, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int ICP_PX>
 __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict__ vcur, const float* __restrict__ ncur,
                                                         const float* __restrict__ vprev, const float* __restrict__ nprev,
                                                         int W, int H, Intr in, const TrackState* __restrict__ st,
                                                         float dist_thresh, float angle_thresh,
                                                         const IcpPose* __restrict__ pose_in, IcpPose* __restrict__ pose_out,
-                                                        const double* __restrict__ part_prev, int nb_prev,
-                                                        double* __restrict__ part_out) {
+                                                        double* __restrict__ slots, int iter) {
   __shared__ double sh[8][32];
   __shared__ double tot[27];
   __shared__ IcpPose sp;
   IcpLaneIn<ICP_PX> L;
   icp_load_current<ICP_PX>(vcur, ncur, W, H, 0, H, L);  // independent of the pose: in flight during the prologue
-  if (nb_prev > 0) block_reduce27(part_prev, nb_prev, sh, tot);
+  // the previous pose estimate and the model pose come from other launches (L2 misses): fetch them now, not after
+  // the reduction's barrier where their latency would sit on the critical path of the solve
+  const IcpPose p_in = *pose_in;
+  float Rp[9], tp[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rp[i] = st->Rp[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tp[i] = st->tp[i];
+  double* __restrict__ slot_add = slots + (size_t)(iter % 3) * ICP_SLOT_DOUBLES;
+  const double* __restrict__ slot_read = slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES;
+  double* __restrict__ slot_clear = slots + (size_t)((iter + 1) % 3) * ICP_SLOT_DOUBLES;
+  for (int i = blockIdx.x * ICP_BLOCK + threadIdx.x; i < ICP_SLOT_DOUBLES; i += gridDim.x * ICP_BLOCK)
+    __hip_atomic_store(slot_clear + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (iter > 0) shard_reduce27(slot_read, sh, tot);
   if (threadIdx.x == 0) {
-    IcpPose p = *pose_in;
-    if (nb_prev > 0) icp_solve_step(tot, p);
+    IcpPose p = p_in;
+    if (iter > 0) icp_solve_step(tot, p);
     sp = p;
     if (blockIdx.x == 0) *pose_out = p;
   }
@@ -812,17 +868,17 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   if (!sp.lost)
-    icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, sp.R, sp.t, st->Rp, st->tp, dist_thresh, angle_thresh, acc);
+    icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, sp.R, sp.t, Rp, tp, dist_thresh, angle_thresh, acc);
   __syncthreads();  // sh is reused by the block reduction below
-  icp_block_sums(acc, (double (*)[32])sh, part_out + (size_t)blockIdx.x * 27);
+  icp_block_sums_atomic(acc, (double (*)[32])sh, slot_add);
 }
 
 // after the last iteration: final solve, pose and lost flag into the tracker state
-__global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ pose_in, const double* __restrict__ part_prev,
-                                                   int nb_prev, TrackState* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ pose_in, const double* __restrict__ slots,
+                                                   int iter, TrackState* __restrict__ st) {
   __shared__ double sh[8][32];
   __shared__ double tot[27];
-  block_reduce27(part_prev, nb_prev, sh, tot);
+  shard_reduce27(slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES, sh, tot);
   if (threadIdx.x == 0) {
     IcpPose p = *pose_in;
     icp_solve_step(tot, p);
@@ -838,36 +894,44 @@ __global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ p
   }
 }
 
-size_t icp_pose_bytes() { return 2 * sizeof(IcpPose); }
+// two pose slots (ping-pong) followed by the three accumulator slots
+#define ICP_POSE_AREA 256
+size_t icp_pose_bytes() { return ICP_POSE_AREA + 3 * ICP_SLOT_DOUBLES * sizeof(double); }
+static inline double* icp_slots(void* pose_buf) { return (double*)((char*)pose_buf + ICP_POSE_AREA); }
+static __device__ __forceinline__ double* icp_slots_dev(IcpPose* pose_buf) { return (double*)((char*)pose_buf + ICP_POSE_AREA); }
 
 // enqueue the whole ICP of one frame: levels coarse -> fine, iters[l] iterations each
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
                       void* pose_buf, double* part_a, double* part_b) {
+  (void)part_a;
+  (void)part_b;
+  static_assert(2 * sizeof(IcpPose) <= ICP_POSE_AREA, "pose ping-pong must fit its area");
   IcpPose* pb = (IcpPose*)pose_buf;
-  double* part[2] = {part_a, part_b};
-  int i = 0, nb_prev = 0;
+  double* slots = icp_slots(pose_buf);
+  int i = 0;
   for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
     const int W = lv[l].W, H = lv[l].H;
     const int nb = icp_num_blocks(W, H);
     for (int it = 0; it < iters[l]; ++it, ++i) {
-      const double* pp = part[(i + 1) & 1];
       if (icp_px(W) == ICP_PX_FINE)
         hipLaunchKernelGGL(k_icp_iter<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
-                           H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), pp, nb_prev,
-                           part[i & 1]);
+                           H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
       else
         hipLaunchKernelGGL(k_icp_iter<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W, H,
-                           lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), pp, nb_prev,
-                           part[i & 1]);
-      nb_prev = nb;
+                           lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
     }
   }
-  if (i > 0) hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(256), 0, s, pb + (i & 1), part[(i + 1) & 1], nb_prev, st);
+  if (i > 0) hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(256), 0, s, pb + (i & 1), slots, i, st);
 }
 
 // start of a tracked frame: previous pose <- current pose, clear the lost flag
 __global__ void k_begin_frame(TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
+  if (pose0) {  // accumulator slot 0 of the fused ICP starts the frame empty
+    double* slot0 = icp_slots_dev(pose0);
+    for (int i = threadIdx.x; i < ICP_SLOT_DOUBLES; i += blockDim.x)
+      __hip_atomic_store(slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (threadIdx.x != 0) return;
   if (st->need_reset) {  // a frame queued behind a lost one (asynchronous submission): dropped, state untouched
     st->lost = 1;
@@ -894,6 +958,11 @@ void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf) {
 
 // pose ping-pong seed alone (slab mode: k_begin_frame already ran in hsk_mgpu_frame_begin)
 __global__ void k_icp_seed(const TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
+  {
+    double* slot0 = icp_slots_dev(pose0);
+    for (int i = threadIdx.x; i < ICP_SLOT_DOUBLES; i += blockDim.x)
+      __hip_atomic_store(slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (threadIdx.x != 0) return;
   IcpPose p;
   for (int i = 0; i < 9; ++i) p.R[i] = st->R[i];
