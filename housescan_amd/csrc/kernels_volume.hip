@@ -500,8 +500,12 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       // wave-aggregated append of the uncertain lane-blocks
       const unsigned long long bo = __ballot(other);
       if (bo != 0ull) {
-        // one of HSK_NQUEUES queues by block index: a single counter saturates at ~88 atomics/us chip-wide
-        const unsigned qi = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % HSK_NQUEUES;
+        // one of HSK_NQUEUES queues (a single counter saturates at ~88 atomics/us chip-wide).  The queue must NOT follow
+        // the block's x-y position: surfaces cluster in a few columns, and pass B's time is its longest queue.  Rotate
+        // the assignment by the row of HSK_NQUEUES blocks and by the wave: within a row it stays a bijection, so every
+        // queue still receives at most one wave-quarter of one block per row and wave index (the capacity bound).
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
         unsigned base = 0;
         if (lane == (int)__builtin_ctzll(bo)) base = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo));
         base = __shfl(base, (int)__builtin_ctzll(bo), 64);
@@ -647,7 +651,10 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned nblk = grid.x * grid.y * grid.z;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
   (void)hipMemsetAsync(qcount, 0, (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE * 4, s);
-  const dim3 detail_grid(8, HSK_NQUEUES);  // 8 blocks stride over each queue
+#ifndef DETAIL_GX
+#define DETAIL_GX 4  // 4 x 256 queues x 4 waves = one resident round of the chip at 4 waves per SIMD
+#endif
+  const dim3 detail_grid(DETAIL_GX, HSK_NQUEUES);  // DETAIL_GX blocks stride over each queue
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
