@@ -284,10 +284,12 @@ static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, un
 // All four voxels of the vector observed as free space (F == 1).  When all four already store +1 the running
 // mean leaves +1 ((1*W + 1) / (W + 1) == 1 exactly) and only the weights move: W <- min(W + 1, 128), done on the
 // packed words with one add and one min per voxel.  Otherwise the general update runs.
-static __device__ __forceinline__ void update_vector_free4(uint4& q) {
+static __device__ __forceinline__ bool update_vector_free4(uint4& q) {
   const unsigned a = q.x & q.y & q.z & q.w, o = q.x | q.y | q.z | q.w;
   if ((a & 0x7fffu) == 0x7fffu && (o & 0x8000u) == 0u) {
     const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
+    // all four weights already at the cap: the update leaves the vector as it is, and the store is skipped
+    if (min(min(q.x, q.y), min(q.z, q.w)) >= cap) return false;
     q.x = min(q.x + 0x10000u, cap);
     q.y = min(q.y + 0x10000u, cap);
     q.z = min(q.z + 0x10000u, cap);
@@ -296,6 +298,7 @@ static __device__ __forceinline__ void update_vector_free4(uint4& q) {
     const float F1[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     (void)update_vector(q, 0xFu, 0xFu, F1);  // F == 1 never writes a negative value
   }
+  return true;
 }
 
 // Phase 4 for one plane: running mean (A.4), repack.  Returns true when a negative TSDF was written.
@@ -491,10 +494,8 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 #pragma unroll
           for (int u = 0; u < 4; ++u) q4[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            update_vector_free4(q4[u]);
-            vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
-          }
+          for (int u = 0; u < 4; ++u)
+            if (update_vector_free4(q4[u])) vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
         }
       }
       // wave-aggregated append of the uncertain lane-blocks
@@ -603,8 +604,11 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
     for (int u = 0; u < 4; ++u) {
       if (!mask[u]) continue;
       const int zz = zb + u;
+      const uint4 before = q[u];
       const bool neg = update_vector(q[u], mask[u], one[u], F[u]);
-      vol[idx0 + (size_t)zz * plane_vec] = q[u];
+      // saturated free space (+1 at the weight cap) comes back unchanged: no store
+      if (q[u].x != before.x || q[u].y != before.y || q[u].z != before.z || q[u].w != before.w)
+        vol[idx0 + (size_t)zz * plane_vec] = q[u];
       if (neg) {
         const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
         // test first: after the first frames the bit is already set and no atomic is issued (a stale read only
