@@ -715,14 +715,9 @@ __host__ __device__ static inline void hsk_mat3mul(const float* A, const float* 
     for (int j = 0; j < 3; ++j) O[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
 }
 
-__host__ __device__ static inline void hsk_pose_update(float* R, float* t, const float* x6) {
-  double sd, cd;
-  hsk_sincos((double)x6[0], &sd, &cd);
-  const float sa = (float)sd, ca = (float)cd;
-  hsk_sincos((double)x6[1], &sd, &cd);
-  const float sb = (float)sd, cb = (float)cd;
-  hsk_sincos((double)x6[2], &sd, &cd);
-  const float sg = (float)sd, cg = (float)cd;
+// pose refinement from the solved increment, given the sines and cosines of its three angles
+__host__ __device__ static inline void hsk_pose_update_sc(float* R, float* t, const float* x6, float sa, float ca, float sb,
+                                                          float cb, float sg, float cg) {
   const float Rx[9] = {1.0f, 0.0f, 0.0f, 0.0f, ca, -sa, 0.0f, sa, ca};
   const float Ry[9] = {cb, 0.0f, sb, 0.0f, 1.0f, 0.0f, -sb, 0.0f, cb};
   const float Rz[9] = {cg, -sg, 0.0f, sg, cg, 0.0f, 0.0f, 0.0f, 1.0f};
@@ -737,6 +732,17 @@ __host__ __device__ static inline void hsk_pose_update(float* R, float* t, const
   t[2] = n2;
   hsk_mat3mul(Rinc, R, Rn);
   for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+}
+
+__host__ __device__ static inline void hsk_pose_update(float* R, float* t, const float* x6) {
+  double sd, cd;
+  hsk_sincos((double)x6[0], &sd, &cd);
+  const float sa = (float)sd, ca = (float)cd;
+  hsk_sincos((double)x6[1], &sd, &cd);
+  const float sb = (float)sd, cb = (float)cd;
+  hsk_sincos((double)x6[2], &sd, &cd);
+  const float sg = (float)sd, cg = (float)cd;
+  hsk_pose_update_sc(R, t, x6, sa, ca, sb, cb, sg, cg);
 }
 
 // single-lane kernel: solve the reduced system and refine the pose held in TrackState
@@ -775,18 +781,31 @@ struct IcpPose {
   int lost, n_iter, pad[2];
 };
 
+// Executed by the whole first wave: lane 0 solves, lanes 0..2 evaluate one sine/cosine pair each (the three
+// polynomial evaluations are the longest serial piece after the factorisation), lane 0 applies the increment.
+// Only lane 0's copy of p is meaningful afterwards.
 static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p) {
-  if (p.lost) return;
-  double s[27];
+  const int lane = threadIdx.x & 63;
+  float x6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  bool go = false;
+  if (lane == 0 && !p.lost) {
+    double s[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) s[k] = tot[k];
-  float x6[6];
-  if (!hsk_solve6(s, x6)) {
-    p.lost = 1;
-    return;
+    for (int k = 0; k < 27; ++k) s[k] = tot[k];
+    go = hsk_solve6(s, x6);
+    if (!go) p.lost = 1;
   }
-  hsk_pose_update(p.R, p.t, x6);
-  p.n_iter += 1;
+  const float a0 = __shfl(x6[0], 0, 64), a1 = __shfl(x6[1], 0, 64), a2 = __shfl(x6[2], 0, 64);
+  double sd, cd;
+  hsk_sincos((double)(lane == 0 ? a0 : (lane == 1 ? a1 : a2)), &sd, &cd);
+  const float sf = (float)sd, cf = (float)cd;
+  const float sa = __shfl(sf, 0, 64), ca = __shfl(cf, 0, 64);
+  const float sb = __shfl(sf, 1, 64), cb = __shfl(cf, 1, 64);
+  const float sg = __shfl(sf, 2, 64), cg = __shfl(cf, 2, 64);
+  if (go) {
+    hsk_pose_update_sc(p.R, p.t, x6, sa, ca, sb, cb, sg, cg);
+    p.n_iter += 1;
+  }
 }
 
 // The 27 sums travel between launches through sharded accumulators instead of per-block partial rows: the
@@ -857,11 +876,13 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   for (int i = blockIdx.x * ICP_BLOCK + threadIdx.x; i < ICP_SLOT_DOUBLES; i += gridDim.x * ICP_BLOCK)
     __hip_atomic_store(slot_clear + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (iter > 0) shard_reduce27(slot_read, sh, tot);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // the first wave (icp_solve_step shares the work among its lanes)
     IcpPose p = p_in;
     if (iter > 0) icp_solve_step(tot, p);
-    sp = p;
-    if (blockIdx.x == 0) *pose_out = p;
+    if (threadIdx.x == 0) {
+      sp = p;
+      if (blockIdx.x == 0) *pose_out = p;
+    }
   }
   __syncthreads();
   double acc[27];
@@ -879,9 +900,9 @@ __global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ p
   __shared__ double sh[8][32];
   __shared__ double tot[27];
   shard_reduce27(slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES, sh, tot);
+  IcpPose p = *pose_in;
+  if (threadIdx.x < 64) icp_solve_step(tot, p);
   if (threadIdx.x == 0) {
-    IcpPose p = *pose_in;
-    icp_solve_step(tot, p);
     for (int k = 0; k < 27; ++k) st->sums[k] = tot[k];
     if (p.lost) {
       st->lost = 1;
