@@ -332,9 +332,9 @@ static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, un
       } else if (Fj == 1.0f && tp == HSK_DIVISOR) {
         Fn = 1.0f;
       } else {
-        const float Fp = (float)tp / 32767.0f;
+        const float Fp = hsk_tsdf_unpack(tp);
         const float Wp = (float)wp;
-        Fn = (Fp * Wp + Fj) / (Wp + 1.0f);
+        Fn = hsk_div_small_int(Fp * Wp + Fj, wp + 1);
       }
       int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
       fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
@@ -706,7 +706,7 @@ static __device__ __forceinline__ int raw_at(const short2* __restrict__ vol, con
   return (int)vol[((size_t)zz * vp.Y + y) * vp.X + x].x;
 }
 static __device__ __forceinline__ float tsdf_at(const short2* __restrict__ vol, const VolParams& vp, int x, int y, int z) {
-  return (float)raw_at(vol, vp, x, y, z) / 32767.0f;
+  return hsk_tsdf_unpack(raw_at(vol, vp, x, y, z));
 }
 
 // trilinear TSDF sample (A.6).  Branch-free: indices are clamped for the loads and the NaN of the spec
@@ -733,10 +733,10 @@ static __device__ __forceinline__ float trilinear(const short2* __restrict__ vol
   const size_t row1 = ((size_t)(in1 ? z1 : 0) * vp.Y + gy) * vp.X + gx;
   const int r000 = vol[row0].x, r100 = vol[row0 + 1].x, r010 = vol[row0 + vp.X].x, r110 = vol[row0 + vp.X + 1].x;
   const int r001 = vol[row1].x, r101 = vol[row1 + 1].x, r011 = vol[row1 + vp.X].x, r111 = vol[row1 + vp.X + 1].x;
-  const float f000 = (float)(in0 ? r000 : 0) / 32767.0f, f100 = (float)(in0 ? r100 : 0) / 32767.0f;
-  const float f010 = (float)(in0 ? r010 : 0) / 32767.0f, f110 = (float)(in0 ? r110 : 0) / 32767.0f;
-  const float f001 = (float)(in1 ? r001 : 0) / 32767.0f, f101 = (float)(in1 ? r101 : 0) / 32767.0f;
-  const float f011 = (float)(in1 ? r011 : 0) / 32767.0f, f111 = (float)(in1 ? r111 : 0) / 32767.0f;
+  const float f000 = hsk_tsdf_unpack(in0 ? r000 : 0), f100 = hsk_tsdf_unpack(in0 ? r100 : 0);
+  const float f010 = hsk_tsdf_unpack(in0 ? r010 : 0), f110 = hsk_tsdf_unpack(in0 ? r110 : 0);
+  const float f001 = hsk_tsdf_unpack(in1 ? r001 : 0), f101 = hsk_tsdf_unpack(in1 ? r101 : 0);
+  const float f011 = hsk_tsdf_unpack(in1 ? r011 : 0), f111 = hsk_tsdf_unpack(in1 ? r111 : 0);
   float res = f000 * (1.0f - a) * (1.0f - b) * (1.0f - c);
   res = res + f001 * (1.0f - a) * (1.0f - b) * c;
   res = res + f010 * (1.0f - a) * b * (1.0f - c);

@@ -145,3 +145,32 @@ def test_depth_stream_container(tmp_path, hsk):
         r[5]
     r.close()
     assert os.path.getsize(path) == 36 + 5 * 160 * 120 * 2
+
+
+def test_exact_division_shortcuts_used_by_the_kernels():
+    """hsk_dev.h replaces two correctly-rounded f32 divisions of the specification by binary64 products:
+    raw / 32767 (exhaustive over every int16 raw) and x / n for n = weight + 1 <= 129 with a table of correctly rounded
+    binary64 reciprocals (the proof is in the header; here: every n, many x, and the reciprocal perturbed by a few ulps to
+    show the margin -- v_rcp_f64 itself is far coarser than that and failed the 130-frame GPU parity test)"""
+    raw = np.arange(-32768, 32768, dtype=np.int32)
+    want = raw.astype(np.float32) / np.float32(32767.0)
+    got = (raw.astype(np.float64) * (1.0 / 32767.0)).astype(np.float32)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    rng = np.random.default_rng(11)
+    # numerators as the update forms them: Fp * Wp + F with Fp, F in [-1, 1] on the 1/32767 grid and arbitrary floats too
+    xs = np.concatenate([
+        (rng.integers(-32767, 32768, 200000).astype(np.float32) / np.float32(32767.0)) * rng.integers(1, 129, 200000).astype(np.float32)
+        + rng.uniform(-1, 1, 200000).astype(np.float32),
+        rng.normal(0, 50, 100000).astype(np.float32),
+        np.float32(2.0) ** rng.integers(-20, 20, 2000).astype(np.float32),
+        np.arange(1, 4000, dtype=np.float32),
+    ])
+    for n in range(1, 130):
+        want = xs / np.float32(n)
+        r = 1.0 / np.float64(n)
+        for ulps in (-3, 0, 3):
+            rr = r
+            for _ in range(abs(ulps)):
+                rr = np.nextafter(rr, np.inf if ulps > 0 else -np.inf)
+            got = (xs.astype(np.float64) * rr).astype(np.float32)
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (n, ulps)
