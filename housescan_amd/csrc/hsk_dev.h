@@ -37,6 +37,7 @@ struct VolParams {
   float size[3];
   float tau, tau_inv;
   int bshift;      // log2 of the brick edge of the "has held a negative TSDF" bitfield (3 => 8^3 voxels)
+  double icell[3]; // correctly rounded binary64 reciprocals of cell[] (hsk_div_by_cell)
 };
 
 // words of the brick bitfield; the brick edge is chosen so that it fits 32 KiB of LDS
@@ -79,6 +80,11 @@ __device__ __constant__ static const double hsk_recip_table[130] = {0.0, 1.0 / 1
 static __device__ __forceinline__ float hsk_div_small_int(float x, int n) {
   return (float)((double)x * hsk_recip_table[n]);
 }
+
+// x / c of the specification for a fixed binary32 divisor c, as a binary64 product with the correctly rounded binary64
+// reciprocal rc: a binary32 quotient of two binary32 numbers is either exact or at least 2^-48 (relative) away from a
+// rounding boundary (ties need c to be a power of two, where rc is exact), and the product is within 2^-52 of it.
+static __device__ __forceinline__ float hsk_div_by_const(float x, double rc) { return (float)((double)x * rc); }
 
 static __device__ __forceinline__ float hsk_dot3(float ax, float ay, float az, float bx, float by, float bz) {
   return (ax * bx + ay * by) + az * bz;

@@ -297,6 +297,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   vp.cell[0] = vp.size[0] / (float)vp.X;
   vp.cell[1] = vp.size[1] / (float)vp.Y;
   vp.cell[2] = vp.size[2] / (float)vp.Z;
+  for (int a = 0; a < 3; ++a) vp.icell[a] = 1.0 / (double)vp.cell[a];
   float m = vp.cell[0] > vp.cell[1] ? vp.cell[0] : vp.cell[1];
   m = m > vp.cell[2] ? m : vp.cell[2];
   const float lo = 2.1f * m;

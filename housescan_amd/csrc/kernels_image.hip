@@ -489,16 +489,16 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
   for (int q = 0; q < ICP_PX; ++q) {
     bool valid = ok[q] && !hsk_isnan(np_[q][0]);
     const float ex = vp_[q][0] - g[q][0], ey = vp_[q][1] - g[q][1], ez = vp_[q][2] - g[q][2];
-    const float dist = sqrtf(hsk_dot3(ex, ey, ez, ex, ey, ez));
-    valid = valid && (dist <= dist_thresh);
+    // sqrtf(d2) <= dist_thresh of the spec, as d2 <= (largest float whose correctly rounded root is <= the threshold);
+    // the launcher converts the thresholds (icp_gate_limits), sqrtf being monotone
+    valid = valid && (hsk_dot3(ex, ey, ez, ex, ey, ez) <= dist_thresh);
     const float ngx = (R[0] * nc[q][0] + R[1] * nc[q][1]) + R[2] * nc[q][2];
     const float ngy = (R[3] * nc[q][0] + R[4] * nc[q][1]) + R[5] * nc[q][2];
     const float ngz = (R[6] * nc[q][0] + R[7] * nc[q][1]) + R[8] * nc[q][2];
     const float c0 = ngy * np_[q][2] - ngz * np_[q][1];
     const float c1 = ngz * np_[q][0] - ngx * np_[q][2];
     const float c2 = ngx * np_[q][1] - ngy * np_[q][0];
-    const float sine = sqrtf(hsk_dot3(c0, c1, c2, c0, c1, c2));
-    valid = valid && (sine < angle_thresh);
+    valid = valid && (hsk_dot3(c0, c1, c2, c0, c1, c2) < angle_thresh);  // sqrtf(.) < angle_thresh, same conversion
     if (valid) {
       float row[7];
       row[0] = g[q][1] * np_[q][2] - g[q][2] * np_[q][1];  // s x n
@@ -560,10 +560,41 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __res
 static inline int icp_px(int W) { return W >= 512 ? ICP_PX_FINE : 1; }
 int icp_num_blocks(int W, int rows) { return (W * rows + ICP_BLOCK * icp_px(W) - 1) / (ICP_BLOCK * icp_px(W)); }
 
+// The kernels gate on squared quantities.  dist2_max: the largest binary32 y with sqrtf(y) <= dist_thresh;
+// sine2_lim: the smallest y with sqrtf(y) >= angle_thresh.  With a correctly rounded, monotone sqrtf:
+//   sqrtf(d2) <= dist_thresh  <=>  d2 <= dist2_max      and      sqrtf(c2) < angle_thresh  <=>  c2 < sine2_lim.
+static void icp_gate_limits(float dist_thresh, float angle_thresh, float* dist2_max, float* sine2_lim) {
+  if (!(dist_thresh >= 0.0f)) {
+    *dist2_max = -1.0f;  // nothing passes (also for a NaN threshold)
+  } else {
+    float y = dist_thresh * dist_thresh;
+    if (!(y < INFINITY)) {
+      y = INFINITY;
+    } else {
+      while (sqrtf(y) > dist_thresh) y = nextafterf(y, -INFINITY);
+      while (nextafterf(y, INFINITY) < INFINITY && sqrtf(nextafterf(y, INFINITY)) <= dist_thresh) y = nextafterf(y, INFINITY);
+    }
+    *dist2_max = y;
+  }
+  if (!(angle_thresh > 0.0f)) {
+    *sine2_lim = 0.0f;  // sqrtf(c2) < 0 never holds
+  } else {
+    float y = angle_thresh * angle_thresh;
+    if (!(y < INFINITY)) {
+      y = INFINITY;
+    } else {
+      while (sqrtf(y) < angle_thresh) y = nextafterf(y, INFINITY);
+      while (y > 0.0f && sqrtf(nextafterf(y, -INFINITY)) >= angle_thresh) y = nextafterf(y, -INFINITY);
+    }
+    *sine2_lim = y;
+  }
+}
+
 void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
                            int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,
                            int row1, double* partials) {
   const int nb = icp_num_blocks(W, row1 - row0);
+  icp_gate_limits(dist_thresh, angle_thresh, &dist_thresh, &angle_thresh);  // the kernels take the squared limits
   if (icp_px(W) == ICP_PX_FINE)
     hipLaunchKernelGGL(k_icp_accumulate<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
                        dist_thresh, angle_thresh, row0, row1, partials);
@@ -930,6 +961,7 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
   static_assert(2 * sizeof(IcpPose) <= ICP_POSE_AREA, "pose ping-pong must fit its area");
   IcpPose* pb = (IcpPose*)pose_buf;
   double* slots = icp_slots(pose_buf);
+  icp_gate_limits(dist_thresh, angle_thresh, &dist_thresh, &angle_thresh);  // the kernels take the squared limits
   int i = 0;
   for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
     const int W = lv[l].W, H = lv[l].H;

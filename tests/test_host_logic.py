@@ -174,3 +174,22 @@ def test_exact_division_shortcuts_used_by_the_kernels():
                 rr = np.nextafter(rr, np.inf if ulps > 0 else -np.inf)
             got = (xs.astype(np.float64) * rr).astype(np.float32)
             assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (n, ulps)
+
+
+def test_division_by_a_fixed_cell_size_as_binary64_product():
+    """hsk_div_by_const: x / c (binary32) == float32(float64(x) * (1 / float64(c))) for the cell sizes in use and
+    adversarial numerators (the argument is in hsk_dev.h)"""
+    rng = np.random.default_rng(12)
+    cells = [np.float32(3.0) / np.float32(n) for n in (64, 96, 128, 256, 512, 1024)] + [np.float32(3.0) / np.float32(100), np.float32(0.0123)]
+    for c in cells:
+        rc = 1.0 / np.float64(c)
+        xs = np.concatenate([
+            rng.uniform(-4, 4, 400000).astype(np.float32),
+            (np.arange(-2000, 2000).astype(np.float32) * c),                       # exact multiples
+            (np.arange(-2000, 2000).astype(np.float32) + np.float32(0.5)) * c,     # half-cell offsets
+            np.nextafter((np.arange(1, 2000).astype(np.float32) * c), np.float32(np.inf)),
+            np.nextafter((np.arange(1, 2000).astype(np.float32) * c), np.float32(-np.inf)),
+        ])
+        want = xs / c
+        got = (xs.astype(np.float64) * rc).astype(np.float32)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), float(c)
