@@ -53,6 +53,11 @@ struct TetTable {
   unsigned char edge[6][16][2][3];
 };
 
+// levels 1 and 2 of the model maps, written by the raycast itself when it can (launch_raycast)
+struct MapPyramid {
+  float *v1, *n1, *v2, *n2;
+};
+
 #define HSK_NANF (__builtin_nanf(""))
 
 static __device__ __forceinline__ bool hsk_isnan(float x) { return x != x; }

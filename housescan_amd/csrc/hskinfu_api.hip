@@ -433,6 +433,13 @@ static void enqueue_integrate(hsk_ctx* k) {
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys) {
   hipStream_t s = k->stream;
+  if (raycast_can_fuse_pyramid(k->vp, k->lv[0].W, k->lv[0].H)) {
+    // the raycast writes levels 1 and 2 of the model maps from its own tiles: no second launch, no re-read
+    const MapPyramid pyr = {k->d_vmod[1], k->d_nmod[1], k->d_vmod[2], k->d_nmod[2]};
+    launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys, k->d_flags,
+                   &pyr);
+    return;
+  }
   launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys, k->d_flags);
   launch_resize_maps2(s, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
                       k->d_nmod[2], k->d_st);

@@ -771,6 +771,38 @@ static __device__ __forceinline__ int vox_fast(float p, float cell, float inv_ce
   return (int)f;
 }
 
+// one level of the map pyramid inside a wave that holds an 8x8 pixel tile (lane = y * 8 + x): the lane at the top
+// left of each 2x2 group (dx, dy = lane distance to its right / lower neighbour at this level) forms the mean of the
+// vertex taps and the renormalised mean of the normal taps, NaN when any tap is NaN; other lanes' results are unused
+static __device__ __forceinline__ void pyramid_step(const float* m, int dx, int dy, float* out) {
+  float t1[6], t2[6], t3[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    t1[c] = __shfl_down(m[c], dx, 64);
+    t2[c] = __shfl_down(m[c], dy, 64);
+    t3[c] = __shfl_down(m[c], dx + dy, 64);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int b = 3 * h;
+    float a0 = HSK_NANF, a1 = HSK_NANF, a2 = HSK_NANF;
+    if (!(hsk_isnan(m[b]) || hsk_isnan(t1[b]) || hsk_isnan(t2[b]) || hsk_isnan(t3[b]))) {
+      a0 = (((m[b] + t1[b]) + t2[b]) + t3[b]) / 4.0f;
+      a1 = (((m[b + 1] + t1[b + 1]) + t2[b + 1]) + t3[b + 1]) / 4.0f;
+      a2 = (((m[b + 2] + t1[b + 2]) + t2[b + 2]) + t3[b + 2]) / 4.0f;
+      if (h == 1) {
+        const float inv = 1.0f / sqrtf(hsk_dot3(a0, a1, a2, a0, a1, a2));
+        a0 = a0 * inv;
+        a1 = a1 * inv;
+        a2 = a2 * inv;
+      }
+    }
+    out[b] = a0;
+    out[b + 1] = a1;
+    out[b + 2] = a2;
+  }
+}
+
 #define RC_BLOCK 512    // 8 waves share one staged copy of the 32 KiB bitfield: all 4800 waves of a 640x480 frame are
                         // resident at once (with 256-thread blocks only 4096 fit and a second round formed the tail)
 #define RC_STAGE_MAX 4  // 16-B loads per thread: 32 KiB / (512 x 16 B)
@@ -778,7 +810,7 @@ template <bool SLAB>  // SLAB: this context stores / owns only part of the z ran
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
                                                  VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
                                                  float* __restrict__ nmap, int* __restrict__ keys,
-                                                 const unsigned* __restrict__ flags, int flag_words) {
+                                                 const unsigned* __restrict__ flags, int flag_words, MapPyramid pyr) {
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];
@@ -805,7 +837,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   const int tiles_x = (W + 7) >> 3;
   const int x = (tile % tiles_x) * 8 + (lane & 7);
   const int y = (tile / tiles_x) * 8 + (lane >> 3);
-  if (x >= W || y >= H) return;
+  if (x >= W || y >= H) return;  // (with a fused pyramid every tile is complete: launch_raycast checks W, H % 8)
   if (st->lost) return;
   const size_t P = (size_t)W * H;
   const size_t i = (size_t)y * W + x;
@@ -937,21 +969,48 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   nmap[P + i] = ny;
   nmap[2 * P + i] = nz;
   if (keys) keys[i] = key;
+  if (!SLAB && pyr.v1) {
+    // Model pyramid (resizeVMap / resizeNMap, A.3) from the wave's own 8x8 tile: level 1 is the 2x2 mean held by
+    // the even-even lanes, level 2 the 2x2 mean of those -- the arithmetic and its order are k_resize_maps2's, the
+    // taps arrive by lane shuffles instead of a second launch reading the maps back.
+    float m[6] = {vx, vy, vz, nx, ny, nz};
+    float l1[6], l2[6];
+    pyramid_step(m, 1, 8, l1);
+    pyramid_step(l1, 2, 16, l2);
+    const int w1 = W >> 1, w2 = W >> 2;
+    const size_t P1 = (size_t)w1 * (H >> 1), P2 = (size_t)w2 * (H >> 2);
+    if (((x | y) & 1) == 0) {
+      const size_t o = (size_t)(y >> 1) * w1 + (x >> 1);
+      pyr.v1[o] = l1[0]; pyr.v1[P1 + o] = l1[1]; pyr.v1[2 * P1 + o] = l1[2];
+      pyr.n1[o] = l1[3]; pyr.n1[P1 + o] = l1[4]; pyr.n1[2 * P1 + o] = l1[5];
+    }
+    if (((x | y) & 3) == 0) {
+      const size_t o = (size_t)(y >> 2) * w2 + (x >> 2);
+      pyr.v2[o] = l2[0]; pyr.v2[P2 + o] = l2[1]; pyr.v2[2 * P2 + o] = l2[2];
+      pyr.n2[o] = l2[3]; pyr.n2[P2 + o] = l2[4]; pyr.n2[2 * P2 + o] = l2[5];
+    }
+  }
 }
 
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys, const unsigned* flags) {
+                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid) {
   const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
   dim3 block(RC_BLOCK);
   dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
   const int words = hsk_flag_words(vp);
   const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
+  MapPyramid none = {nullptr, nullptr, nullptr, nullptr};
   if (slab)
     hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
-                       keys, flags, words);
+                       keys, flags, words, none);
   else
     hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap,
-                       nmap, keys, flags, words);
+                       nmap, keys, flags, words, pyramid ? *pyramid : none);
+}
+// the fused pyramid needs complete 8x8 tiles and a single-device volume
+bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H) {
+  const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
+  return !slab && (W % 8) == 0 && (H % 8) == 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
