@@ -37,7 +37,6 @@ void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, 
 void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, double* out27);
 void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st);
 void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf);
-void launch_begin_frame_seed_only(hipStream_t s, const TrackState* st, void* icp_pose_buf);
 size_t icp_pose_bytes();
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,

@@ -343,6 +343,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipMalloc((void**)&k->d_partials, (size_t)nb0 * 27 * sizeof(double)));
   CK(hipMalloc((void**)&k->d_partials2, (size_t)nb0 * 27 * sizeof(double)));
   CK(hipMalloc(&k->d_icp_pose, icp_pose_bytes()));
+  CK(hipMemset(k->d_icp_pose, 0, icp_pose_bytes()));  // accumulator slot 0 must be empty before the first tracked frame
   CK(hipMalloc((void**)&k->d_sums, 27 * sizeof(double)));
   CK(hipMalloc((void**)&k->d_wc, 512 * 4));
   CK(hipMalloc((void**)&k->d_keys, P0 * 4));
@@ -464,7 +465,6 @@ static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
   hipStream_t s = k->stream;
   if (with_events) (void)hipEventRecord(k->ev[0], s);
   enqueue_preprocess(k, k->stream);
-  launch_begin_frame(s, k->d_st, k->d_icp_pose);
   if (with_events) (void)hipEventRecord(k->ev[1], s);
   enqueue_icp(k);
   if (with_events) (void)hipEventRecord(k->ev[2], s);
@@ -476,8 +476,7 @@ static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
 
 // everything after the preprocessing of a tracked frame, on the main stream, for the buffer set k->cur
 static void enqueue_tracked_rest(hsk_ctx* k) {
-  launch_begin_frame(k->stream, k->d_st, k->d_icp_pose);
-  enqueue_icp(k);
+  enqueue_icp(k);  // its first iteration also starts the frame (previous pose <- pose, lost flag)
   enqueue_integrate(k);
   enqueue_raycast_and_resize(k, nullptr);
 }
@@ -502,7 +501,6 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
   if (gated) {
     // host decides whether to integrate: one extra synchronisation, only in this non-default mode
     enqueue_preprocess(k, k->stream);
-    launch_begin_frame(s, k->d_st, k->d_icp_pose);
     enqueue_icp(k);
     int r = download_state(k);
     if (r != HSK_OK) return r;
@@ -1006,9 +1004,7 @@ extern "C" int hsk_mgpu_icp_update(hsk_ctx* k, const void* sums27_dev) {
 extern "C" int hsk_mgpu_icp_replicated(hsk_ctx* k) {
   if (!k) return HSK_ERR_ARG;
   if (k->frame == 0) return fail(k, HSK_ERR_STATE, "no model maps yet: the first frame has no ICP");
-  // hsk_mgpu_frame_begin ran k_begin_frame without seeding the pose ping-pong: seed it now, then the fused iterations
-  launch_begin_frame_seed_only(k->stream, k->d_st, k->d_icp_pose);
-  enqueue_icp(k);
+  enqueue_icp(k);  // the first fused iteration seeds itself from the tracker state (k_begin_frame already ran: idempotent)
   return HSK_OK;
 }
 

@@ -843,7 +843,8 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
 // products are integer multiples of 2^-26 (exact in binary64), so hardware f64 atomic adds give the same bits in
 // any arrival order, and the next launch reads ICP_SHARDS x 27 doubles instead of (blocks) x 27 (19 MB of L2 reads
 // per fine iteration before).  Three slots rotate: iteration i adds into slot i % 3, reads slot (i - 1) % 3 and
-// clears slot (i + 1) % 3 for its successor; k_begin_frame clears slot 0.
+// clears slot (i + 1) % 3 for its successor; slot 0 is empty at the start of a frame (cleared at creation and by
+// k_icp_final).
 #define ICP_SHARDS 32
 #define ICP_SLOT_DOUBLES (ICP_SHARDS * 32)
 static __device__ __forceinline__ void shard_reduce27(const double* __restrict__ slot, double (*sh)[32], double* tot) {
@@ -884,10 +885,9 @@ static __device__ __forceinline__ void icp_block_sums_atomic(const double* acc, 
 template <int ICP_PX>
 __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict__ vcur, const float* __restrict__ ncur,
                                                         const float* __restrict__ vprev, const float* __restrict__ nprev,
-                                                        int W, int H, Intr in, const TrackState* __restrict__ st,
-                                                        float dist_thresh, float angle_thresh,
-                                                        const IcpPose* __restrict__ pose_in, IcpPose* __restrict__ pose_out,
-                                                        double* __restrict__ slots, int iter) {
+                                                        int W, int H, Intr in, TrackState* st, float dist_thresh,
+                                                        float angle_thresh, const IcpPose* __restrict__ pose_in,
+                                                        IcpPose* __restrict__ pose_out, double* __restrict__ slots, int iter) {
   __shared__ double sh[8][32];
   __shared__ double tot[27];
   __shared__ IcpPose sp;
@@ -895,12 +895,37 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   icp_load_current<ICP_PX>(vcur, ncur, W, H, 0, H, L);  // independent of the pose: in flight during the prologue
   // the previous pose estimate and the model pose come from other launches (L2 misses): fetch them now, not after
   // the reduction's barrier where their latency would sit on the critical path of the solve
-  const IcpPose p_in = *pose_in;
+  IcpPose p_in;
   float Rp[9], tp[3];
+  if (iter == 0) {
+    // Start of a tracked frame (what k_begin_frame does for the unfused paths): the estimate starts at the previous
+    // frame's pose, which is also the pose the model maps were raycast from.  A frame queued behind a lost one is
+    // dropped: it runs with the lost flag set and leaves the state alone.  Block 0 publishes the bookkeeping; the
+    // other blocks only read fields that nobody writes here (R, t, need_reset).
 #pragma unroll
-  for (int i = 0; i < 9; ++i) Rp[i] = st->Rp[i];
+    for (int i = 0; i < 9; ++i) p_in.R[i] = Rp[i] = st->R[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) tp[i] = st->tp[i];
+    for (int i = 0; i < 3; ++i) p_in.t[i] = tp[i] = st->t[i];
+    p_in.lost = st->need_reset ? 1 : 0;
+    p_in.n_iter = 0;
+    p_in.pad[0] = p_in.pad[1] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (p_in.lost) {
+        st->lost = 1;
+      } else {
+        for (int i = 0; i < 9; ++i) st->Rp[i] = Rp[i];
+        for (int i = 0; i < 3; ++i) st->tp[i] = tp[i];
+        st->lost = 0;
+        st->n_iter = 0;
+      }
+    }
+  } else {
+    p_in = *pose_in;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rp[i] = st->Rp[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tp[i] = st->tp[i];
+  }
   double* __restrict__ slot_add = slots + (size_t)(iter % 3) * ICP_SLOT_DOUBLES;
   const double* __restrict__ slot_read = slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES;
   double* __restrict__ slot_clear = slots + (size_t)((iter + 1) % 3) * ICP_SLOT_DOUBLES;
@@ -926,11 +951,14 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
 }
 
 // after the last iteration: final solve, pose and lost flag into the tracker state
-__global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ pose_in, const double* __restrict__ slots,
-                                                   int iter, TrackState* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ pose_in, double* __restrict__ slots, int iter,
+                                                   TrackState* __restrict__ st) {
   __shared__ double sh[8][32];
   __shared__ double tot[27];
   shard_reduce27(slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES, sh, tot);
+  // slot 0 is where the next frame's first iteration adds: leave it empty (it may be the slot just read)
+  for (int i = threadIdx.x; i < ICP_SLOT_DOUBLES; i += blockDim.x)
+    __hip_atomic_store(slots + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   IcpPose p = *pose_in;
   if (threadIdx.x < 64) icp_solve_step(tot, p);
   if (threadIdx.x == 0) {
@@ -975,16 +1003,14 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
                            lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
     }
   }
-  if (i > 0) hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(256), 0, s, pb + (i & 1), slots, i, st);
+  if (i > 0)
+    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(256), 0, s, pb + (i & 1), slots, i, st);
+  else
+    launch_begin_frame(s, st, nullptr);  // no iteration configured: the frame still starts (previous pose, lost flag)
 }
 
 // start of a tracked frame: previous pose <- current pose, clear the lost flag
 __global__ void k_begin_frame(TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
-  if (pose0) {  // accumulator slot 0 of the fused ICP starts the frame empty
-    double* slot0 = icp_slots_dev(pose0);
-    for (int i = threadIdx.x; i < ICP_SLOT_DOUBLES; i += blockDim.x)
-      __hip_atomic_store(slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   if (threadIdx.x != 0) return;
   if (st->need_reset) {  // a frame queued behind a lost one (asynchronous submission): dropped, state untouched
     st->lost = 1;
@@ -1009,25 +1035,6 @@ void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf) {
   hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, s, st, (IcpPose*)icp_pose_buf);
 }
 
-// pose ping-pong seed alone (slab mode: k_begin_frame already ran in hsk_mgpu_frame_begin)
-__global__ void k_icp_seed(const TrackState* __restrict__ st, IcpPose* __restrict__ pose0) {
-  {
-    double* slot0 = icp_slots_dev(pose0);
-    for (int i = threadIdx.x; i < ICP_SLOT_DOUBLES; i += blockDim.x)
-      __hip_atomic_store(slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (threadIdx.x != 0) return;
-  IcpPose p;
-  for (int i = 0; i < 9; ++i) p.R[i] = st->R[i];
-  for (int i = 0; i < 3; ++i) p.t[i] = st->t[i];
-  p.lost = st->lost;
-  p.n_iter = 0;
-  p.pad[0] = p.pad[1] = 0;
-  *pose0 = p;
-}
-void launch_begin_frame_seed_only(hipStream_t s, const TrackState* st, void* icp_pose_buf) {
-  hipLaunchKernelGGL(k_icp_seed, dim3(1), dim3(64), 0, s, st, (IcpPose*)icp_pose_buf);
-}
 
 // host mirrors (used by hsk_icp_solve and by tests through the C ABI)
 bool host_solve6(const double* in27, float* x6) { return hsk_solve6(in27, x6); }

@@ -98,8 +98,12 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 // half-spaces gives it.  Conservative by 2 planes (float error).  Empty columns get (INT_MAX, INT_MIN).
 __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
                                 int2* __restrict__ zint, int col_blocks, const float* __restrict__ tmax,
-                                const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th) {
+                                const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th,
+                                unsigned* __restrict__ qcount) {
   if ((int)blockIdx.x >= col_blocks) {  // the last blocks dilate the tile table instead (saves a launch)
+    // ... and the first of them clears the queue counters of pass A (saves a memset node and its boundary)
+    if ((int)blockIdx.x == col_blocks)
+      for (int q = threadIdx.x; q < HSK_NQUEUES; q += blockDim.x) qcount[q * HSK_QCOUNT_STRIDE] = 0u;
     const int i = (blockIdx.x - col_blocks) * blockDim.x + threadIdx.x;
     if (i >= tw * th) return;
     const int ty = i / tw, tx = i - ty * tw;
@@ -643,18 +647,17 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
   const float2* ftab = (const float2*)(tmax + 4 * tw * th);  // behind the coarse tables (filled by launch_tile_fine)
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
+  unsigned* qcount = queue;  // HSK_NQUEUES counters, one per 256-B line, cleared by k_column_zrange
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks + dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, col_blocks,
-                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th);
+                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
-  // HSK_NQUEUES counters (one per 256-B line, cleared here), then HSK_NQUEUES queues of qcap entries each; a block
-  // of pass A holds at most 4 waves x 64 lanes x (zchunk / 4) blocks and every HSK_NQUEUES-th block shares a queue
-  unsigned* qcount = queue;
+  // behind the counters: HSK_NQUEUES queues of qcap entries each; a block of pass A holds at most 4 waves x 64 lanes
+  // x (zchunk / 4) blocks and every HSK_NQUEUES-th block shares a queue
   unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
   const unsigned nblk = grid.x * grid.y * grid.z;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
-  (void)hipMemsetAsync(qcount, 0, (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE * 4, s);
 #ifndef DETAIL_GX
 #define DETAIL_GX 4  // 4 x 256 queues x 4 waves = one resident round of the chip at 4 waves per SIMD
 #endif
