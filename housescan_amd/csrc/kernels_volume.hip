@@ -806,6 +806,15 @@ static __device__ __forceinline__ void pyramid_step(const float* m, int dx, int 
   }
 }
 
+#ifdef HSK_RC_TIMING
+__device__ unsigned long long g_rc_times[8192 * 4];
+extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rc_times), (size_t)n * 8);
+}
+#define RC_STAMP(k) do { if (lane == 0 && tile_id < 8192) g_rc_times[tile_id * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RC_STAMP(k) do { } while (0)
+#endif
 #define RC_BLOCK 512    // 8 waves share one staged copy of the 32 KiB bitfield: all 4800 waves of a 640x480 frame are
                         // resident at once (with 256-thread blocks only 4096 fit and a second round formed the tail)
 #define RC_STAGE_MAX 4  // 16-B loads per thread: 32 KiB / (512 x 16 B)
@@ -817,6 +826,11 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];
+#ifdef HSK_RC_TIMING
+  const int tile_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  RC_STAMP(0);
+#endif
   {
     // 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging loop cost 9 us per
     // block: profiles/r01/raycast_analysis.md)
@@ -835,7 +849,10 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     for (int q = threadIdx.x + RC_STAGE_MAX * RC_BLOCK; q < nq; q += RC_BLOCK) ((uint4*)lflags)[q] = ((const uint4*)flags)[q];
   }
   __syncthreads();
+#ifndef HSK_RC_TIMING
   const int lane = threadIdx.x & 63;
+#endif
+  RC_STAMP(1);
   const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int tiles_x = (W + 7) >> 3;
   const int x = (tile % tiles_x) * 8 + (lane & 7);
@@ -939,6 +956,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     }
     // Deferred hit processing: lanes hit at different steps, and refining inside the loop would run these
     // (memory-latency-bound) taps once per distinct step.  Here the wave runs them once, loads batched.
+    RC_STAMP(2);
     if (crossing) {
       key = (step << 1) | 1;
       const float tn = time_curr + time_step;
@@ -972,6 +990,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   nmap[P + i] = ny;
   nmap[2 * P + i] = nz;
   if (keys) keys[i] = key;
+  RC_STAMP(3);
   if (!SLAB && pyr.v1) {
     // Model pyramid (resizeVMap / resizeNMap, A.3) from the wave's own 8x8 tile: level 1 is the 2x2 mean held by
     // the even-even lanes, level 2 the 2x2 mean of those -- the arithmetic and its order are k_resize_maps2's, the

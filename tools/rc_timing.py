@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Per-wave phase times of k_raycast (debug build with -DHSK_RC_TIMING): staging / march / refine, and where the
+slowest tiles are in the image."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import housescan_amd as hsk
+from housescan_amd import _lib
+trk = hsk.KinfuTracker(n=int(sys.argv[1]) if len(sys.argv) > 1 else 512, use_graph=0)
+for k in range(40):
+    trk.process_frame(hsk.synth_depth(hsk.synth_pose(k)))
+lib = C.CDLL(_lib.LIB_PATH)
+t = np.zeros((4800, 4), np.uint64)
+rc = lib.hsk_debug_rc_times(C.c_void_p(t.ctypes.data), 4800 * 4)
+t = t.astype(np.float64) / 100.0   # s_memrealtime ticks at 100 MHz -> us
+t0 = t[:, 0].min()
+stage, march, refine, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
+print("rc", rc, "span", t[:, 3].max() - t0, "first start spread", (t[:, 0] - t0).max())
+for name, v in (("staging", stage), ("march", march), ("refine", refine), ("life", life), ("end", t[:, 3] - t0)):
+    print(f"{name:8s} mean {v.mean():6.1f}  p50 {np.percentile(v, 50):6.1f}  p90 {np.percentile(v, 90):6.1f}  p99 {np.percentile(v, 99):6.1f}  max {v.max():6.1f}")
+order = np.argsort(-(t[:, 3] - t0))[:12]
+for i in order:
+    print("tile", i, "xy", (i % 80) * 8, (i // 80) * 8, "start %.1f stage %.1f march %.1f refine %.1f end %.1f" % (t[i, 0] - t0, stage[i], march[i], refine[i], t[i, 3] - t0))
