@@ -40,7 +40,10 @@ struct VolParams {
   double icell[3]; // correctly rounded binary64 reciprocals of cell[] (hsk_div_by_cell)
 };
 
-// words of the brick bitfield; the brick edge is chosen so that it fits 32 KiB of LDS
+#ifndef HSK_FLAG_WORDS_MAX
+#define HSK_FLAG_WORDS_MAX 1024  // 4 KiB
+#endif
+// words of the brick bitfield; the brick edge is chosen (hsk_create) so that it fits HSK_FLAG_WORDS_MAX
 static inline int hsk_flag_words(const VolParams& vp) {
   const long bits = (long)(vp.X >> vp.bshift) * (vp.Y >> vp.bshift) * ((vp.nzs + (1 << vp.bshift) - 1) >> vp.bshift);
   return (int)(((bits + 31) / 32 + 3) / 4 * 4);  // multiple of 4 words: staged into LDS with 16-B loads

@@ -355,17 +355,6 @@ static __device__ __forceinline__ double dpp_mov_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-// wave64 sum of one value (any order is fine: the addends are exact integers)
-static __device__ __forceinline__ double wave_sum_f64(double v) {
-  v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov_f64<0x141>(v);  // row_half_mirror
-  v += dpp_mov_f64<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row total
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
 // wave64 sums of 27 values at once by a halving butterfly: at every step the two partner lanes split the
 // remaining values between them, so 16 + 8 + 4 + 2 + 1 + 1 exchanges replace 27 x 6.  On return lane l holds the
 // wave total of value (l >> 1) & 31 for l < 64 (values 27..31 are padding); lanes 2k and 2k+1 both hold value k.
@@ -978,7 +967,6 @@ __global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ p
 #define ICP_POSE_AREA 256
 size_t icp_pose_bytes() { return ICP_POSE_AREA + 3 * ICP_SLOT_DOUBLES * sizeof(double); }
 static inline double* icp_slots(void* pose_buf) { return (double*)((char*)pose_buf + ICP_POSE_AREA); }
-static __device__ __forceinline__ double* icp_slots_dev(IcpPose* pose_buf) { return (double*)((char*)pose_buf + ICP_POSE_AREA); }
 
 // enqueue the whole ICP of one frame: levels coarse -> fine, iters[l] iterations each
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,

@@ -696,13 +696,7 @@ void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, u
 // neighbouring voxels (L1/L2 locality of the 4-B gathers).  Steps are owned by the slab that contains the
 // far sample's z plane; a single-device context owns all of them.
 // ------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ int vox_of(float p, float cell) {
-  const float q = floorf(p / cell);
-  if (!(q >= 0.0f)) return -1;
-  if (q > 1.0e6f) return 1000000;
-  return (int)q;
-}
-// the same from the quotient q = p / cell already formed
+// voxel index from the quotient q = p / cell (floor, with the spec's range guards)
 static __device__ __forceinline__ int vox_of_q(float quot) {
   const float q = floorf(quot);
   if (!(q >= 0.0f)) return -1;
@@ -714,9 +708,6 @@ static __device__ __forceinline__ int raw_at(const short2* __restrict__ vol, con
   const int zz = z - vp.zs0;
   if (zz < 0 || zz >= vp.nzs) return 0;
   return (int)vol[((size_t)zz * vp.Y + y) * vp.X + x].x;
-}
-static __device__ __forceinline__ float tsdf_at(const short2* __restrict__ vol, const VolParams& vp, int x, int y, int z) {
-  return hsk_tsdf_unpack(raw_at(vol, vp, x, y, z));
 }
 
 // trilinear TSDF sample (A.6).  Branch-free: indices are clamped for the loads and the NaN of the spec
@@ -815,9 +806,12 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #else
 #define RC_STAMP(k) do { } while (0)
 #endif
-#define RC_BLOCK 512    // 8 waves share one staged copy of the 32 KiB bitfield: all 4800 waves of a 640x480 frame are
-                        // resident at once (with 256-thread blocks only 4096 fit and a second round formed the tail)
-#define RC_STAGE_MAX 4  // 16-B loads per thread: 32 KiB / (512 x 16 B)
+#ifndef RC_BLOCK
+#define RC_BLOCK 64     // one wave = one 8x8 tile = one workgroup with its own 4 KiB copy of the brick bitfield: the 4800
+#endif                  // waves of a 640x480 frame spread evenly over the SIMDs.  Measured 512^3 / 1024^3 (us): 64 threads
+                        // 99 / 124, 128: 107 / 126, 256: 99 / 131, 512: 107 / 142.  With 512-thread blocks and a 32 KiB
+                        // bitfield 88 of the 256 CUs got a third block and the kernel waited for them (raycast_analysis.md).
+#define RC_STAGE_MAX 4  // 16-B loads per thread: 4 KiB / (64 x 16 B); larger bitfields take the loop below
 template <bool SLAB>  // SLAB: this context stores / owns only part of the z range (multi-GPU)
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
                                                  VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
@@ -835,17 +829,20 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     // 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging loop cost 9 us per
     // block: profiles/r01/raycast_analysis.md)
     const int nq = flag_words >> 2;  // flag_words is a multiple of 4 (hsk_flag_words)
-    uint4 tmp[RC_STAGE_MAX];
-#pragma unroll
-    for (int i = 0; i < RC_STAGE_MAX; ++i) {
-      const int q = threadIdx.x + i * RC_BLOCK;
-      if (q < nq) tmp[i] = ((const uint4*)flags)[q];
-    }
-#pragma unroll
-    for (int i = 0; i < RC_STAGE_MAX; ++i) {
-      const int q = threadIdx.x + i * RC_BLOCK;
-      if (q < nq) ((uint4*)lflags)[q] = tmp[i];
-    }
+    // (an indexed temporary array here was placed in scratch memory by the compiler: named registers instead)
+    const uint4* __restrict__ src = (const uint4*)flags;
+    uint4* dst = (uint4*)lflags;
+    const int q0 = threadIdx.x, q1 = q0 + RC_BLOCK, q2 = q1 + RC_BLOCK, q3 = q2 + RC_BLOCK;
+    static_assert(RC_STAGE_MAX == 4, "the staging below is written for four 16-B loads per thread");
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 a0 = q0 < nq ? src[q0] : zero;
+    const uint4 a1 = q1 < nq ? src[q1] : zero;
+    const uint4 a2 = q2 < nq ? src[q2] : zero;
+    const uint4 a3 = q3 < nq ? src[q3] : zero;
+    if (q0 < nq) dst[q0] = a0;
+    if (q1 < nq) dst[q1] = a1;
+    if (q2 < nq) dst[q2] = a2;
+    if (q3 < nq) dst[q3] = a3;
     for (int q = threadIdx.x + RC_STAGE_MAX * RC_BLOCK; q < nq; q += RC_BLOCK) ((uint4*)lflags)[q] = ((const uint4*)flags)[q];
   }
   __syncthreads();
@@ -913,8 +910,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     // or within a voxel of the grid; a sample farther out is outside the grid either way (its error is relative).
     const float eps = 3.0e-7f * (float)max(vp.X, max(vp.Y, vp.Z)) + 1.0e-5f;
     bool first = true;  // the near sample of the first step is the (clamped) entry voxel; qx,qy,qz hold it unclamped
-    for (; time_curr < max_time; time_curr = time_curr + time_step, ++step) {
-      const float tn = time_curr + time_step;
+    // voxel of the far sample at ray parameter tn (floor(p / cell) of the spec); false when it lies outside the grid
+    auto far_voxel = [&](float tn, int& gx, int& gy, int& gz) -> bool {
       const float pnx = t0 + d0 * tn, pny = t1 + d1 * tn, pnz = t2 + d2 * tn;
       const float q0 = pnx * ic0, q1 = pny * ic1, q2 = pnz * ic2;
       const float r0 = __builtin_amdgcn_fractf(q0), r1 = __builtin_amdgcn_fractf(q1), r2 = __builtin_amdgcn_fractf(q2);
@@ -926,9 +923,15 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
         f1 = floorf(pny / vp.cell[1]);
         f2 = floorf(pnz / vp.cell[2]);
       }
-      // v_cvt_i32_f32 saturates; a negative or huge index fails the unsigned bound test below
-      const int gx = (int)f0, gy = (int)f1, gz = (int)f2;
-      if ((unsigned)gx >= (unsigned)vp.X || (unsigned)gy >= (unsigned)vp.Y || (unsigned)gz >= (unsigned)vp.Z) break;
+      // v_cvt_i32_f32 saturates; a negative or huge index fails the unsigned bound test
+      gx = (int)f0;
+      gy = (int)f1;
+      gz = (int)f2;
+      return (unsigned)gx < (unsigned)vp.X && (unsigned)gy < (unsigned)vp.Y && (unsigned)gz < (unsigned)vp.Z;
+    };
+    for (; time_curr < max_time; time_curr = time_curr + time_step, ++step) {
+      int gx, gy, gz;
+      if (!far_voxel(time_curr + time_step, gx, gy, gz)) break;
       const int cxv = px, cyv = py, czv = pz;  // near sample of this step (inside the grid)
       const bool was_first = first;
       const unsigned fl_near = fl_prev;
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(const unsigned* __restrict__
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-      unsigned long long a = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      unsigned long long a = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
       __syncthreads();
       sh[threadIdx.x] += a;
       __syncthreads();
