@@ -333,11 +333,11 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
 // RCCL all-reduce all give the same bits as a sequential sum.
 // ------------------------------------------------------------------------------------------------------
 // ICP_PX pixels per lane (template): loads batched so that the dependent chain is 2 memory round trips
+#ifndef ICP_BLOCK
 #define ICP_BLOCK 256
-#ifndef ICP_PX_FINE
+#endif
 #ifndef ICP_PX_FINE
 #define ICP_PX_FINE 4  // pixels per lane at the finest level (1 at the coarse levels)
-#endif
 #endif
 
 // Exact accumulation.  The spec sums quant26(p) = rint(p * 2^26) * 2^-26 over pixels, p the binary64 product of
