@@ -140,6 +140,10 @@ def main():
             lost += (not ok)
         pose, ok = trk.wait_frame()
         lost += (not ok)
+    elif world > 1 or args.force_sharded:
+        for i in range(1 + Wm, total):  # the next frame is named so that its preprocessing overlaps this frame
+            pose, ok = step(dev_frames[i], dev_frames[i + 1] if i + 1 < total else None)
+            lost += (not ok)
     else:
         for i in range(1 + Wm, total):
             pose, ok = step(dev_frames[i])
@@ -208,6 +212,27 @@ def main():
             out["pcie_inclusive_fps"] = round(len(hf) / (time.perf_counter() - t1), 2)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_frames, hsk)
+    if (world > 1 or args.force_sharded) and args.mode == "slab":
+        # configs[4] beside the z-slab number: every GPU scans its own room (a full volume per rank, no data-path
+        # collective), aggregated over the ranks -- weak scaling of the same fused frame
+        room = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=args.graph)
+        k2 = min(K, 100)
+        for i in range(1 + Wm):
+            room.process_frame_dev(dev_frames[i].data_ptr())
+        barrier()
+        t1 = time.perf_counter()
+        room.submit_frame_dev(dev_frames[1 + Wm].data_ptr())
+        for i in range(2 + Wm, 1 + Wm + k2):
+            room.submit_frame_dev(dev_frames[i].data_ptr())
+            room.wait_frame()
+        room.wait_frame()
+        barrier()
+        el2 = time.perf_counter() - t1
+        tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out["independent_rooms"] = {"value": round(world * k2 / float(tt.item()), 2), "unit": "frames/s", "scaling": "weak",
+                                    "steps": k2, "note": "one %d^3 volume per GPU, no collective (BASELINE configs[4])" % n}
+        room.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -69,6 +69,8 @@ SYMBOLS = {
     "hsk_extract_cloud": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_extract_mesh": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_mgpu_frame_begin": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "hsk_mgpu_prefetch": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "hsk_mgpu_frame_front": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "hsk_mgpu_icp_accumulate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "hsk_mgpu_icp_update": (C.c_int, [_P, _P]),
     "hsk_mgpu_icp_replicated": (C.c_int, [_P]),

@@ -73,8 +73,14 @@ struct hsk_ctx {
   hipEvent_t ev_pre[2] = {}, ev_free[2] = {};
   bool set_used[2] = {false, false};
   int async_set = 1;
+  const void* pf_ptr = nullptr;   // hsk_mgpu_prefetch: depth pointer whose preprocessing is already enqueued ...
+  int pf_set = -1;                // ... into this buffer set (on pstream, ev_pre[pf_set] recorded)
+  int mgpu_set = 0;               // buffer set of the slab frame in progress
   hipGraph_t mgraph[2] = {};
   hipGraphExec_t mgexec[2] = {};
+  hipGraph_t sgraph[2] = {};       // slab frame front (ICP + integrate + local raycast) per buffer set
+  hipGraphExec_t sgexec[2] = {};
+  void* sgraph_keys = nullptr;     // the keys buffer baked into those graphs
   // hipGraph of the steady-state frame
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -168,6 +174,10 @@ static void free_all(hsk_ctx* k) {
   (void)hipSetDevice(k->cfg.device_id);
   if (k->gexec) (void)hipGraphExecDestroy(k->gexec);
   if (k->graph) (void)hipGraphDestroy(k->graph);
+  for (auto& g : k->sgexec)
+    if (g) (void)hipGraphExecDestroy(g);
+  for (auto& g : k->sgraph)
+    if (g) (void)hipGraphDestroy(g);
   for (auto& g : k->mgexec)
     if (g) (void)hipGraphExecDestroy(g);
   for (auto& g : k->mgraph)
@@ -547,6 +557,15 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
   return HSK_OK;
 }
 
+// the whole-frame entry points always work on buffer set 0 (their hipGraphs are captured with it); the slab entry
+// points may have left the context on the other set or with a prefetch pending
+static void leave_slab_bookkeeping(hsk_ctx* k) {
+  k->cur = 0;
+  k->mgpu_set = 0;
+  k->pf_ptr = nullptr;
+  k->pf_set = -1;
+}
+
 static int check_dims(hsk_ctx* k, const void* depth, int w, int h) {
   if (!k) return HSK_ERR_ARG;
   if (!depth) return fail(k, HSK_ERR_ARG, "depth pointer is null");
@@ -566,6 +585,7 @@ extern "C" int hsk_process_frame(hsk_ctx* k, const uint16_t* depth, int w, int h
   if (r != HSK_OK) return r;
   if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  leave_slab_bookkeeping(k);
   r = stage_depth_host(k, depth);
   if (r != HSK_OK) return r;
   return frame_common(k, pose_out, tracked);
@@ -576,6 +596,7 @@ extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, i
   if (r != HSK_OK) return r;
   if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  leave_slab_bookkeeping(k);
   HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
   return frame_common(k, pose_out, tracked);
 }
@@ -589,6 +610,7 @@ extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, in
   if (r != HSK_OK) return r;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   if (k->ring_count >= HSK_MAX_IN_FLIGHT) return fail(k, HSK_ERR_STATE, "too many frames in flight: call hsk_wait_frame first");
+  if (k->ring_count == 0) leave_slab_bookkeeping(k);
   hipStream_t s = k->stream;
   const bool sync_path = k->frame == 0 || k->pending_reset || k->cfg.integrate_move_thresh > 0.0f || k->prof;
   if (sync_path) {
@@ -965,12 +987,45 @@ extern "C" int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_
 // ------------------------------------------------------------------------------------------------------
 extern "C" int hsk_mgpu_frame_index(const hsk_ctx* k) { return k ? k->frame : -1; }
 
+// Optional: enqueue the depth copy and the preprocessing of the NEXT frame on the second stream, into the buffer set
+// the current frame does not use, so that they run under the current frame's ICP / integrate / raycast and collectives.
+// The following hsk_mgpu_frame_begin with the same pointer picks the result up instead of preprocessing again.
+extern "C" int hsk_mgpu_prefetch(hsk_ctx* k, const void* depth_dev, int w, int h) {
+  int r = check_dims(k, depth_dev, w, h);
+  if (r != HSK_OK) return r;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const int set = k->mgpu_set ^ 1;
+  if (k->set_used[set]) HIPCHK(k, hipStreamWaitEvent(k->pstream, k->ev_free[set], 0));  // its previous frame has finished
+  const int keep = k->cur;
+  k->cur = set;
+  hipError_t e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->pstream);
+  if (e == hipSuccess) {
+    enqueue_preprocess(k, k->pstream);
+    e = hipEventRecord(k->ev_pre[set], k->pstream);
+  }
+  k->cur = keep;
+  HIPCHK(k, e);
+  k->pf_ptr = depth_dev;
+  k->pf_set = set;
+  return HSK_OK;
+}
+
 extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, int h) {
   int r = check_dims(k, depth_dev, w, h);
   if (r != HSK_OK) return r;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
-  enqueue_preprocess(k, k->stream);
+  if (k->pf_ptr == depth_dev && k->pf_set >= 0) {
+    // preprocessed ahead of time by hsk_mgpu_prefetch: the frame works on that buffer set once the event has fired
+    k->mgpu_set = k->pf_set;
+    k->cur = k->mgpu_set;
+    HIPCHK(k, hipStreamWaitEvent(k->stream, k->ev_pre[k->mgpu_set], 0));
+  } else {
+    k->cur = k->mgpu_set;  // same set as the previous frame: stream order protects it
+    HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
+    enqueue_preprocess(k, k->stream);
+  }
+  k->pf_ptr = nullptr;
+  k->pf_set = -1;
   if (k->frame == 0) {
     enqueue_integrate(k);
     for (int l = 0; l < HSK_NLEVELS; ++l)
@@ -979,6 +1034,48 @@ extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, in
   } else {
     launch_begin_frame(k->stream, k->d_st, nullptr);
   }
+  return HSK_OK;
+}
+
+// hsk_mgpu_frame_begin + hsk_mgpu_icp_replicated + hsk_mgpu_integrate + hsk_mgpu_raycast_local as ONE call.  The part
+// after the preprocessing (about 25 launches) is captured into a hipGraph per buffer set on first use: the z-slab host
+// then issues five operations per frame (this, two collectives, resolve, frame end) and stops being launch-bound.
+// keys_dev must be the same buffer on every call (it is part of the captured graph).
+extern "C" int hsk_mgpu_frame_front(hsk_ctx* k, const void* depth_dev, int w, int h, void* keys_dev) {
+  if (!keys_dev) return k ? fail(k, HSK_ERR_ARG, "keys buffer is null") : HSK_ERR_ARG;
+  int r = hsk_mgpu_frame_begin(k, depth_dev, w, h);
+  if (r != HSK_OK) return r;
+  if (k->frame == 0) return HSK_OK;  // first frame: integrate + transformed maps only (frame_begin did it)
+  const int set = k->cur;
+  const size_t P0 = (size_t)k->lv[0].W * k->lv[0].H;
+  auto body = [&]() {
+    enqueue_icp(k);  // (k_begin_frame ran in frame_begin; the first fused iteration repeats its bookkeeping: idempotent)
+    enqueue_integrate(k);
+    launch_raycast(k->stream, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], k->d_keys,
+                   k->d_flags);
+    (void)hipMemcpyAsync(keys_dev, k->d_keys, P0 * 4, hipMemcpyDeviceToDevice, k->stream);
+  };
+  if (!k->cfg.use_graph || k->stream == nullptr) {  // (the legacy default stream cannot be captured)
+    body();
+    HIPCHK(k, hipGetLastError());
+    return HSK_OK;
+  }
+  if (k->sgraph_keys != keys_dev) {  // a different keys buffer: the captured graphs are stale
+    for (int i = 0; i < 2; ++i) {
+      if (k->sgexec[i]) (void)hipGraphExecDestroy(k->sgexec[i]);
+      if (k->sgraph[i]) (void)hipGraphDestroy(k->sgraph[i]);
+      k->sgexec[i] = nullptr;
+      k->sgraph[i] = nullptr;
+    }
+    k->sgraph_keys = keys_dev;
+  }
+  if (!k->sgexec[set]) {
+    HIPCHK(k, hipStreamBeginCapture(k->stream, hipStreamCaptureModeThreadLocal));
+    body();
+    HIPCHK(k, hipStreamEndCapture(k->stream, &k->sgraph[set]));
+    HIPCHK(k, hipGraphInstantiate(&k->sgexec[set], k->sgraph[set], nullptr, nullptr, 0));
+  }
+  HIPCHK(k, hipGraphLaunch(k->sgexec[set], k->stream));
   return HSK_OK;
 }
 
@@ -1043,6 +1140,9 @@ extern "C" int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const vo
     launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1],
                         k->d_vmod[2], k->d_nmod[2], k->d_st);
   }
+  // the frame's image buffers are free again once everything enqueued so far has run
+  HIPCHK(k, hipEventRecord(k->ev_free[k->cur], k->stream));
+  k->set_used[k->cur] = true;  // k->cur keeps naming this frame's set: downloads of its images read the right buffers
   int r = download_state(k);
   if (r != HSK_OK) return r;
   HIPCHK(k, hipGetLastError());

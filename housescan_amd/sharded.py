@@ -60,12 +60,27 @@ class SlabOrchestrator:
         # force_collectives: issue the collectives even at world_size 1 (exercises the RCCL plumbing on a 1-GPU box)
         self.coll = world > 1 or force_collectives
 
-    def process_frame(self, depth):
+    def process_frame(self, depth, next_depth=None):
+        """One frame.  `next_depth` (optional): the frame that will be passed next -- engines that can, start copying and
+        filtering it on a second stream now, under this frame's ICP / integrate / raycast and collectives."""
         e, dist = self.e, self.dist
         first = e.frame_index() == 0
-        e.frame_begin(depth)
+        fused_front = self.icp == "replicated" and hasattr(e, "frame_front")
+        if fused_front:
+            keys = e.frame_front(depth)  # preprocess (or the prefetched result) + ICP + integrate + local raycast: one call
+        else:
+            e.frame_begin(depth)
+        if next_depth is not None and hasattr(e, "prefetch"):
+            e.prefetch(next_depth)
         if first:
             return e.frame_end(None, None)
+        if fused_front:
+            if self.coll:
+                dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+            bits = e.raycast_resolve(keys)
+            if self.coll:
+                dist.all_reduce(bits, op=dist.ReduceOp.SUM)
+            return e.frame_end(keys, bits)
         if self.icp == "replicated" and hasattr(e, "icp_replicated"):
             e.icp_replicated()  # the engine runs all 19 iterations itself (fused kernels, no host round trips)
         else:
@@ -93,12 +108,15 @@ class HipSlabEngine:
     """Engine over the C ABI's hsk_mgpu_* building blocks; all buffers are torch CUDA tensors and all work is
     enqueued on torch's current stream, so RCCL collectives order against the kernels without host syncs."""
 
-    def __init__(self, tracker, torch, device):
+    def __init__(self, tracker, torch, device, stream=None):
+        """`stream`: the torch stream every call and collective of this engine will be issued under (default: the
+        current one).  A non-default stream lets hsk_mgpu_frame_front replay its frame front from a hipGraph -- the legacy
+        default stream cannot be captured."""
         import ctypes as C
         self.C, self.t, self.torch, self.dev = C, tracker, torch, device
         self.lib = tracker.lib
         self.w, self.h = tracker.w, tracker.hgt
-        tracker.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        tracker.set_stream((stream or torch.cuda.current_stream(device)).cuda_stream)
         self.sums = torch.zeros(27, dtype=torch.float64, device=device)
         self.keys = torch.empty(self.h * self.w, dtype=torch.int32, device=device)
         self.bits = torch.empty(6 * self.h * self.w, dtype=torch.int32, device=device)
@@ -111,6 +129,14 @@ class HipSlabEngine:
 
     def frame_begin(self, depth_dev):
         self._ck(self.lib.hsk_mgpu_frame_begin(self.t.h, self.C.c_void_p(depth_dev.data_ptr()), self.w, self.h))
+
+    def frame_front(self, depth_dev):
+        self._ck(self.lib.hsk_mgpu_frame_front(self.t.h, self.C.c_void_p(depth_dev.data_ptr()), self.w, self.h,
+                                               self.C.c_void_p(self.keys.data_ptr())))
+        return self.keys
+
+    def prefetch(self, depth_dev):
+        self._ck(self.lib.hsk_mgpu_prefetch(self.t.h, self.C.c_void_p(depth_dev.data_ptr()), self.w, self.h))
 
     def icp_accumulate(self, level, r0, r1):
         self._ck(self.lib.hsk_mgpu_icp_accumulate(self.t.h, level, r0, r1, self.C.c_void_p(self.sums.data_ptr())))
@@ -156,15 +182,20 @@ class ShardedKinfu:
         dev = torch.device("cuda", local_rank)
         if mode == "rooms":
             self.tracker = KinfuTracker(default_config(n, device_id=local_rank))
-            self.process_frame_dev = lambda t: self.tracker.process_frame_dev(t.data_ptr())
+            self.process_frame_dev = lambda t, next_depth=None: self.tracker.process_frame_dev(t.data_ptr())
             return
-        cfg = default_config(n, device_id=local_rank, use_graph=0)
+        cfg = default_config(n, device_id=local_rank, use_graph=1)  # graphs: the fused slab frame front (hsk_mgpu_frame_front)
         z0, z1 = slab_range(rank, world, n)
         cell_z = cfg.vol_size_m[2] / cfg.vol_z
         tau = max(cfg.trunc_dist_m, 2.1 * max(cfg.vol_size_m[0] / cfg.vol_x, cfg.vol_size_m[1] / cfg.vol_y, cell_z))
         cfg.own_z0, cfg.own_z1, cfg.halo = z0, z1, slab_halo(tau, cell_z)
         self.tracker = KinfuTracker(cfg)
-        self.engine = HipSlabEngine(self.tracker, torch, dev)
+        self.stream = torch.cuda.Stream(dev)  # kernels, graphs and collectives of the slab frame all order on this stream
+        self.engine = HipSlabEngine(self.tracker, torch, dev, self.stream)
         self.orch = SlabOrchestrator(self.engine, dist, rank, world, icp=icp, icp_iters=tuple(cfg.icp_iters),
                                      height=cfg.height, force_collectives=force_collectives)
-        self.process_frame_dev = self.orch.process_frame
+        self._torch = torch
+
+    def process_frame_dev(self, depth, next_depth=None):
+        with self._torch.cuda.stream(self.stream):
+            return self.orch.process_frame(depth, next_depth)

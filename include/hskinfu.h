@@ -114,6 +114,12 @@ int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n
 /* Multi-GPU (z-slab) building blocks; device pointers so that the host's collective (RCCL through
  * torch.distributed) can run on them without a host round trip.  All work is enqueued on hsk_stream(). */
 int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, int h); /* preprocess + (frame 0) transform */
+/* optional: enqueue the copy + preprocessing of the NEXT frame on a second stream, under the current frame's work; the
+ * next hsk_mgpu_frame_begin with the same pointer picks it up (the pointer's contents must not change in between) */
+int hsk_mgpu_prefetch(hsk_ctx* k, const void* depth_dev, int w, int h);
+/* frame_begin + icp_replicated + integrate + raycast_local in one call; everything after the preprocessing is replayed
+ * from a hipGraph (config use_graph).  keys_dev: int32[h*w], the SAME buffer on every call */
+int hsk_mgpu_frame_front(hsk_ctx* k, const void* depth_dev, int w, int h, void* keys_dev);
 int hsk_mgpu_icp_accumulate(hsk_ctx* k, int level, int row0, int row1, void* sums27_dev /* double[27] */);
 int hsk_mgpu_icp_update(hsk_ctx* k, const void* sums27_dev);                /* solve + pose update on device */
 int hsk_mgpu_icp_replicated(hsk_ctx* k); /* the whole 19-iteration ICP on this rank's (composited) maps, fused kernels */

@@ -306,22 +306,43 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
     from housescan_amd.sharded import HipSlabEngine, slab_halo, slab_range
     n, world = 64, 2
     dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(dev)   # a capturable stream: the torch ops below and both engines order on it
     ref = hsk.KinfuTracker(n=n, use_graph=0)
     engines = []
     for r in range(world):
-        cfg = hsk.default_config(n, use_graph=0)
+        cfg = hsk.default_config(n, use_graph=1)   # graphs: hsk_mgpu_frame_front captures its frame front per buffer set
         cfg.own_z0, cfg.own_z1 = slab_range(r, world, n)
         cfg.halo = slab_halo(max(0.03, 2.1 * 3.0 / n), 3.0 / n)
-        engines.append(HipSlabEngine(hsk.KinfuTracker(cfg), torch, dev))
-    for k in range(4):
+        engines.append(HipSlabEngine(hsk.KinfuTracker(cfg), torch, dev, side))
+    held = {}
+    nframes = 7
+    torch.cuda.synchronize()
+    ctx = torch.cuda.stream(side)
+    ctx.__enter__()
+    for k in range(nframes):
         _, depth = synth_frames(k)
         pref, okref = ref.process_frame(depth)
-        d_dev = torch.from_numpy(depth.view(np.int16)).to(dev)
+        d_dev = held.pop(k, None)
+        if d_dev is None:
+            d_dev = torch.from_numpy(depth.view(np.int16)).to(dev)
         first = engines[0].frame_index() == 0
-        for e in engines:
-            e.frame_begin(d_dev)
+        fused = k >= 3   # frames 3..6: the one-call, graph-replayed frame front (capture on 3 and 4, replay on 5 and 6)
+        if fused:
+            keys = [e.frame_front(d_dev).clone() for e in engines]
+        else:
+            for e in engines:
+                e.frame_begin(d_dev)
+        if k + 1 < nframes and k % 2 == 0:   # every other frame: the next frame is copied + filtered ahead, on the second stream
+            nxt = torch.from_numpy(synth_frames(k + 1)[1].view(np.int16)).to(dev)
+            held[k + 1] = nxt          # the prefetched pointer must be the one passed to the next frame_begin / frame_front
+            for e in engines:
+                e.prefetch(nxt)
         if first:
             outs = [e.frame_end(None, None) for e in engines]
+        elif fused:
+            kmin = torch.minimum(keys[0], keys[1])
+            bits = [e.raycast_resolve(kmin).clone() for e in engines]
+            outs = [e.frame_end(kmin, bits[0] + bits[1]) for e in engines]
         else:
             if k % 2 == 1:
                 for e in engines:   # "replicated" mode: every slab context runs the fused 19-iteration ICP itself
@@ -345,6 +366,8 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
         for p, ok in outs:
             assert ok == okref
             assert_same_bits(p, pref, f"slab pose frame {k}")
+    ctx.__exit__(None, None, None)
+    torch.cuda.synchronize()
     full = ref.download_tsdf()
     for r, e in enumerate(engines):
         z0, z1 = slab_range(r, world, n)
