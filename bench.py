@@ -140,8 +140,19 @@ def main():
             lost += (not ok)
         pose, ok = trk.wait_frame()
         lost += (not ok)
+    elif (world > 1 or args.force_sharded) and args.mode == "slab" and args.icp == "replicated" and not args.sync_api:
+        # pipelined slab frames: frame i + 1 (with its collectives) is enqueued before the pose of frame i is read;
+        # the next frame is named so that its preprocessing overlaps on the second stream
+        nxt = lambda i: dev_frames[i + 1] if i + 1 < total else None  # noqa: E731
+        eng.submit_frame_dev(dev_frames[1 + Wm], nxt(1 + Wm))
+        for i in range(2 + Wm, total):
+            eng.submit_frame_dev(dev_frames[i], nxt(i))
+            pose, ok = eng.wait_frame()
+            lost += (not ok)
+        pose, ok = eng.wait_frame()
+        lost += (not ok)
     elif world > 1 or args.force_sharded:
-        for i in range(1 + Wm, total):  # the next frame is named so that its preprocessing overlaps this frame
+        for i in range(1 + Wm, total):
             pose, ok = step(dev_frames[i], dev_frames[i + 1] if i + 1 < total else None)
             lost += (not ok)
     else:
@@ -169,7 +180,10 @@ def main():
                                "3 m cube, integrate + 19-iteration ICP + raycast per frame" % n,
                    "volume": n, "image": [640, 480], "icp_iters": [10, 5, 4],
                    "parallelism": ("1 gpu" if world == 1 else f"{args.mode}{world}" + (f"-icp-{args.icp}" if args.mode == "slab" else "")),
-                   "graph": bool(args.graph), "api": "submit/wait (1 frame in flight ahead)" if use_async else "process_frame (sync per frame)"},
+                   "graph": bool(args.graph),
+                   "api": "submit/wait (1 frame in flight ahead)" if (use_async or ((world > 1 or args.force_sharded) and args.mode == "slab"
+                                                                                    and args.icp == "replicated" and not args.sync_api))
+                   else "process_frame (sync per frame)"},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3)},
     }
 

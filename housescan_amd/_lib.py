@@ -79,6 +79,8 @@ SYMBOLS = {
     "hsk_mgpu_raycast_resolve": (C.c_int, [_P, _P, _P]),
     "hsk_mgpu_frame_end": (C.c_int, [_P, _P, _P, _F, _I]),
     "hsk_mgpu_frame_index": (C.c_int, [_P]),
+    "hsk_mgpu_frame_end_async": (C.c_int, [_P, _P, _P]),
+    "hsk_mgpu_restart_pending": (C.c_int, [_P]),
     "hsk_stream": (_P, [_P]),
     "hsk_set_stream": (C.c_int, [_P, _P]),
     "hsk_synchronize": (C.c_int, [_P]),

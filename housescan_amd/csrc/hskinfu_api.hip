@@ -605,6 +605,17 @@ extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, i
 // ------------------------------------------------------------------------------------------------------
 // asynchronous submission
 // ------------------------------------------------------------------------------------------------------
+// Tracking was lost with frames still in flight: their results stay in the ring (they report tracked = 0), the reset
+// itself happens here, before new work is enqueued.
+static int reset_behind_lost_frame(hsk_ctx* k) {
+  for (int i = 0; i < k->ring_count; ++i) {
+    const int sl = (k->ring_head + i) % (HSK_MAX_IN_FLIGHT + 1);
+    HIPCHK(k, hipEventSynchronize(k->ring_ev[sl]));
+    if (k->ring_kind[sl] == 0) k->ring_kind[sl] = 2;  // dropped on the device (need_reset was set)
+  }
+  return do_reset(k);
+}
+
 extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h) {
   int r = check_dims(k, depth_dev, w, h);
   if (r != HSK_OK) return r;
@@ -616,14 +627,7 @@ extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, in
   if (sync_path) {
     // first frame of a (re)started scan, gated or profiled mode: run it synchronously and park the result
     if (k->pending_reset) {
-      // results of the frames that were in flight when tracking was lost stay in the ring (they report tracked = 0);
-      // the reset itself happens here, before new work
-      for (int i = 0; i < k->ring_count; ++i) {
-        const int sl = (k->ring_head + i) % (HSK_MAX_IN_FLIGHT + 1);
-        HIPCHK(k, hipEventSynchronize(k->ring_ev[sl]));
-        if (k->ring_kind[sl] == 0) k->ring_kind[sl] = 2;  // dropped on the device (need_reset was set)
-      }
-      r = do_reset(k);
+      r = reset_behind_lost_frame(k);
       if (r != HSK_OK) return r;
     }
     HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
@@ -1014,6 +1018,10 @@ extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, in
   int r = check_dims(k, depth_dev, w, h);
   if (r != HSK_OK) return r;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  if (k->pending_reset) {  // a pipelined frame (hsk_mgpu_frame_end_async) lost tracking: restart the scan with this frame
+    r = reset_behind_lost_frame(k);
+    if (r != HSK_OK) return r;
+  }
   if (k->pf_ptr == depth_dev && k->pf_set >= 0) {
     // preprocessed ahead of time by hsk_mgpu_prefetch: the frame works on that buffer set once the event has fired
     k->mgpu_set = k->pf_set;
@@ -1128,11 +1136,39 @@ extern "C" int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, vo
   return HSK_OK;
 }
 
+// 1 when the next frame starts (or restarts) the scan: frame 0, or tracking was lost by a pipelined frame.  Such a frame
+// has no ICP and no composite: hsk_mgpu_frame_begin / hsk_mgpu_frame_front, then the synchronous hsk_mgpu_frame_end.
+extern "C" int hsk_mgpu_restart_pending(const hsk_ctx* k) { return k ? (k->frame == 0 || k->pending_reset) : -1; }
+
+// Pipelined end of a tracked slab frame: adopt the composite, rebuild the model pyramid, and queue the pose read-back
+// instead of waiting for it -- the host goes on to enqueue the next frame; hsk_wait_frame returns the results in order
+// (at most HSK_MAX_IN_FLIGHT outstanding).  Loss semantics are those of hsk_submit_frame_dev: frames already enqueued
+// behind a lost one are dropped on the device and report tracked = 0.
+extern "C" int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev) {
+  if (!k) return HSK_ERR_ARG;
+  if (k->frame == 0 || k->pending_reset) return fail(k, HSK_ERR_STATE, "the first frame of a scan ends with hsk_mgpu_frame_end");
+  if (!keys_min_dev || !maps_bits_dev) return fail(k, HSK_ERR_ARG, "composite buffers are null");
+  if (k->ring_count >= HSK_MAX_IN_FLIGHT) return fail(k, HSK_ERR_STATE, "too many frames in flight: call hsk_wait_frame first");
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0], k->lv[0].W * k->lv[0].H);
+  launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
+                      k->d_nmod[2], k->d_st);
+  HIPCHK(k, hipEventRecord(k->ev_free[k->cur], k->stream));
+  k->set_used[k->cur] = true;
+  const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
+  HIPCHK(k, hipMemcpyAsync(&k->h_ring[slot], k->d_st, sizeof(TrackState), hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipEventRecord(k->ring_ev[slot], k->stream));
+  k->ring_kind[slot] = 0;
+  k->ring_count += 1;
+  return HSK_OK;
+}
+
 extern "C" int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev, float pose_out[16],
                                   int* tracked) {
   if (!k) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   const bool first = (k->frame == 0);
+  if (!first && k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   if (!first) {
     if (!keys_min_dev || !maps_bits_dev) return fail(k, HSK_ERR_ARG, "composite buffers are null");
     launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0],

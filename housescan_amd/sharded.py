@@ -60,6 +60,36 @@ class SlabOrchestrator:
         # force_collectives: issue the collectives even at world_size 1 (exercises the RCCL plumbing on a 1-GPU box)
         self.coll = world > 1 or force_collectives
 
+    # ---- pipelined form: submit() enqueues a whole frame (collectives included) without waiting for its pose ----
+    def submit(self, depth, next_depth=None):
+        """Enqueue one frame; poses come back in order from wait().  Needs an engine with the fused frame front and the
+        pipelined frame end (the HIP engine); at most 3 frames may be outstanding."""
+        e, dist = self.e, self.dist
+        if not hasattr(self, "_fifo"):
+            self._fifo = []
+        if e.restart_pending():
+            # first frame of a (re)started scan: no ICP, no composite, finished synchronously; its result is queued
+            # behind the frames still in flight so that wait() keeps the order
+            e.frame_front(depth)
+            if next_depth is not None:
+                e.prefetch(next_depth)
+            self._fifo.append(e.frame_end(None, None))
+            return
+        keys = e.frame_front(depth)
+        if next_depth is not None:
+            e.prefetch(next_depth)
+        if self.coll:
+            dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+        bits = e.raycast_resolve(keys)
+        if self.coll:
+            dist.all_reduce(bits, op=dist.ReduceOp.SUM)
+        e.frame_end_async(keys, bits)
+        self._fifo.append(None)
+
+    def wait(self):
+        done = self._fifo.pop(0)
+        return done if done is not None else self.e.wait_frame()
+
     def process_frame(self, depth, next_depth=None):
         """One frame.  `next_depth` (optional): the frame that will be passed next -- engines that can, start copying and
         filtering it on a second stream now, under this frame's ICP / integrate / raycast and collectives."""
@@ -135,6 +165,16 @@ class HipSlabEngine:
                                                self.C.c_void_p(self.keys.data_ptr())))
         return self.keys
 
+    def restart_pending(self):
+        return bool(self.lib.hsk_mgpu_restart_pending(self.t.h))
+
+    def frame_end_async(self, keys_min, bits):
+        self._ck(self.lib.hsk_mgpu_frame_end_async(self.t.h, self.C.c_void_p(keys_min.data_ptr()),
+                                                   self.C.c_void_p(bits.data_ptr())))
+
+    def wait_frame(self):
+        return self.t.wait_frame()
+
     def prefetch(self, depth_dev):
         self._ck(self.lib.hsk_mgpu_prefetch(self.t.h, self.C.c_void_p(depth_dev.data_ptr()), self.w, self.h))
 
@@ -199,3 +239,12 @@ class ShardedKinfu:
     def process_frame_dev(self, depth, next_depth=None):
         with self._torch.cuda.stream(self.stream):
             return self.orch.process_frame(depth, next_depth)
+
+    def submit_frame_dev(self, depth, next_depth=None):
+        """pipelined: enqueue the frame and its collectives, collect the pose later with wait_frame()"""
+        with self._torch.cuda.stream(self.stream):
+            self.orch.submit(depth, next_depth)
+
+    def wait_frame(self):
+        with self._torch.cuda.stream(self.stream):
+            return self.orch.wait()

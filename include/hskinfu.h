@@ -128,6 +128,11 @@ int hsk_mgpu_raycast_local(hsk_ctx* k, void* keys_dev /* int32[h*w] */);    /* s
 int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, void* maps_bits_dev /* int32[6*h*w] */);
 int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev, float pose_out[16], int* tracked);
 int hsk_mgpu_frame_index(const hsk_ctx* k);
+/* pipelined form of the frame end: queues the pose read-back instead of waiting; collect with hsk_wait_frame (in order,
+ * at most HSK_MAX_IN_FLIGHT outstanding).  hsk_mgpu_restart_pending() == 1: the next frame (re)starts the scan and must
+ * end with the synchronous hsk_mgpu_frame_end (frame 0, or a pipelined frame lost tracking). */
+int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev);
+int hsk_mgpu_restart_pending(const hsk_ctx* k);
 
 /* streams / profiling */
 void* hsk_stream(hsk_ctx* k);                 /* hipStream_t the context launches on */

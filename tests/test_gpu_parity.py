@@ -315,7 +315,8 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
         cfg.halo = slab_halo(max(0.03, 2.1 * 3.0 / n), 3.0 / n)
         engines.append(HipSlabEngine(hsk.KinfuTracker(cfg), torch, dev, side))
     held = {}
-    nframes = 7
+    pending = []
+    nframes = 9
     torch.cuda.synchronize()
     ctx = torch.cuda.stream(side)
     ctx.__enter__()
@@ -326,7 +327,7 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
         if d_dev is None:
             d_dev = torch.from_numpy(depth.view(np.int16)).to(dev)
         first = engines[0].frame_index() == 0
-        fused = k >= 3   # frames 3..6: the one-call, graph-replayed frame front (capture on 3 and 4, replay on 5 and 6)
+        fused = k >= 3   # frames 3..8: the one-call, graph-replayed frame front (capture on 3 and 4, replay afterwards)
         if fused:
             keys = [e.frame_front(d_dev).clone() for e in engines]
         else:
@@ -342,7 +343,22 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
         elif fused:
             kmin = torch.minimum(keys[0], keys[1])
             bits = [e.raycast_resolve(kmin).clone() for e in engines]
-            outs = [e.frame_end(kmin, bits[0] + bits[1]) for e in engines]
+            bsum = bits[0] + bits[1]
+            if k >= 5:
+                # pipelined end: the pose read-back is queued, the next frame is enqueued before it is collected
+                for e in engines:
+                    assert not e.restart_pending()
+                    e.frame_end_async(kmin, bsum)
+                pending.append((k, pref, okref))
+                if len(pending) < 2 and k + 1 < nframes:
+                    continue
+                kk, pp, oo = pending.pop(0)
+                outs = [e.wait_frame() for e in engines]
+                for p_, ok_ in outs:
+                    assert ok_ == oo
+                    assert_same_bits(p_, pp, f"slab pose frame {kk} (pipelined)")
+                continue
+            outs = [e.frame_end(kmin, bsum) for e in engines]
         else:
             if k % 2 == 1:
                 for e in engines:   # "replicated" mode: every slab context runs the fused 19-iteration ICP itself
@@ -366,6 +382,12 @@ def test_slab_contexts_compose_to_single_volume(hsk, oracle, synth_frames):
         for p, ok in outs:
             assert ok == okref
             assert_same_bits(p, pref, f"slab pose frame {k}")
+    while pending:   # the frames still in flight
+        kk, pp, oo = pending.pop(0)
+        for e in engines:
+            p_, ok_ = e.wait_frame()
+            assert ok_ == oo
+            assert_same_bits(p_, pp, f"slab pose frame {kk} (pipelined, drained)")
     ctx.__exit__(None, None, None)
     torch.cuda.synchronize()
     full = ref.download_tsdf()
