@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--slab-graph", type=int, default=0, help="replay the z-slab frame front from a hipGraph (default: eager)")
     ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of the submit/wait pair")
     ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
@@ -112,7 +113,8 @@ def main():
 
     if world > 1 or args.force_sharded:
         from housescan_amd.sharded import ShardedKinfu
-        eng = ShardedKinfu(n, rank, world, local_rank, mode=args.mode, icp=args.icp, force_collectives=args.force_sharded)
+        eng = ShardedKinfu(n, rank, world, local_rank, mode=args.mode, icp=args.icp, force_collectives=args.force_sharded,
+                           use_graph=args.slab_graph)
         step = eng.process_frame_dev
         trk = eng.tracker
     else:

@@ -61,6 +61,16 @@ struct MapPyramid {
   float *v1, *n1, *v2, *n2;
 };
 
+// Pose read-back without a copy node: the last kernel of a pipelined frame writes the tracker state straight into a
+// pinned host ring slot.  `slot_fifo` (pinned host memory) holds the slot the host assigned to each submitted frame,
+// `seq` (device memory) counts the frames that have written; all null when the launch does not report.
+#define HSK_RING_FIFO 8
+struct RingOut {
+  TrackState* slots;
+  const int* slot_fifo;
+  unsigned* seq;
+};
+
 #define HSK_NANF (__builtin_nanf(""))
 
 static __device__ __forceinline__ bool hsk_isnan(float x) { return x != x; }

@@ -816,7 +816,8 @@ template <bool SLAB>  // SLAB: this context stores / owns only part of the z ran
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
                                                  VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
                                                  float* __restrict__ nmap, int* __restrict__ keys,
-                                                 const unsigned* __restrict__ flags, int flag_words, MapPyramid pyr) {
+                                                 const unsigned* __restrict__ flags, int flag_words, MapPyramid pyr,
+                                                 RingOut ring) {
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];
@@ -854,6 +855,16 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   const int tiles_x = (W + 7) >> 3;
   const int x = (tile % tiles_x) * 8 + (lane & 7);
   const int y = (tile / tiles_x) * 8 + (lane >> 3);
+  if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0) {
+    // the tracker state is final once the ICP has ended (nothing after it writes it): report it to the host now, also
+    // for a lost or dropped frame, which returns just below
+    const unsigned n = *ring.seq;
+    *ring.seq = n + 1u;
+    TrackState* dst = ring.slots + ring.slot_fifo[n % HSK_RING_FIFO];
+    const int* src_w = (const int*)st;
+    int* dst_w = (int*)dst;
+    for (unsigned i = 0; i < sizeof(TrackState) / 4; ++i) dst_w[i] = src_w[i];
+  }
   if (x >= W || y >= H) return;  // (with a fused pyramid every tile is complete: launch_raycast checks W, H % 8)
   if (st->lost) return;
   const size_t P = (size_t)W * H;
@@ -1018,19 +1029,20 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
 }
 
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid) {
+                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring) {
   const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
   dim3 block(RC_BLOCK);
   dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
   const int words = hsk_flag_words(vp);
   const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
-  MapPyramid none = {nullptr, nullptr, nullptr, nullptr};
+  const MapPyramid none = {nullptr, nullptr, nullptr, nullptr};
+  const RingOut quiet = {nullptr, nullptr, nullptr};
   if (slab)
     hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
-                       keys, flags, words, none);
+                       keys, flags, words, none, quiet);
   else
     hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap,
-                       nmap, keys, flags, words, pyramid ? *pyramid : none);
+                       nmap, keys, flags, words, pyramid ? *pyramid : none, ring ? *ring : quiet);
 }
 // the fused pyramid needs complete 8x8 tiles and a single-device volume
 bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H) {
