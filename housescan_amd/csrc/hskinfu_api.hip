@@ -5,6 +5,9 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +70,9 @@ struct hsk_ctx {
   int* h_slot_fifo = nullptr;    // pinned: ring slot of each pipelined frame, read by the frame's last kernel (RingOut)
   unsigned* d_ring_seq = nullptr;  // device: pipelined frames that have reported
   unsigned ring_seq = 0;         // host mirror: pipelined frames submitted
+  unsigned ring_expect[HSK_MAX_IN_FLIGHT + 1] = {};  // mark the frame in each slot will write
+  unsigned set_expect[2] = {0, 0};                     // ... and the one that last used each image buffer set
+  int set_slot[2] = {-1, -1};
   TrackState* d_ring_view = nullptr;  // device-side addresses of h_ring / h_slot_fifo
   int* d_fifo_view = nullptr;
   hipEvent_t ring_ev[HSK_MAX_IN_FLIGHT + 1] = {};
@@ -619,12 +625,36 @@ extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, i
 // ------------------------------------------------------------------------------------------------------
 // asynchronous submission
 // ------------------------------------------------------------------------------------------------------
+// Completion of the frame parked in a ring slot.  Pipelined single-device frames (kind 0 with a mark) are announced by
+// the device itself: the raycast stores the frame's sequence number into the pinned slot after the state words, and
+// the host polls it -- event records on the main stream cost ~16 us of idle GPU per frame (2334 -> 2426 frames/s).
+static int wait_slot(hsk_ctx* k, int slot) {
+  if (k->ring_expect[slot] == 0u) {
+    HIPCHK(k, hipEventSynchronize(k->ring_ev[slot]));
+    return HSK_OK;
+  }
+  volatile TrackState* w = (volatile TrackState*)&k->h_ring[slot];
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long spin = 0; w->ring_mark != k->ring_expect[slot]; ++spin) {
+    if (spin < 4000) {
+      __builtin_ia32_pause();
+    } else {
+      sched_yield();
+      if ((spin & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+        return fail(k, HSK_ERR_HIP, "a pipelined frame did not report within 20 s");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return HSK_OK;
+}
+
 // Tracking was lost with frames still in flight: their results stay in the ring (they report tracked = 0), the reset
 // itself happens here, before new work is enqueued.
 static int reset_behind_lost_frame(hsk_ctx* k) {
   for (int i = 0; i < k->ring_count; ++i) {
     const int sl = (k->ring_head + i) % (HSK_MAX_IN_FLIGHT + 1);
-    HIPCHK(k, hipEventSynchronize(k->ring_ev[sl]));
+    const int r = wait_slot(k, sl);
+    if (r != HSK_OK) return r;
     if (k->ring_kind[sl] == 0) k->ring_kind[sl] = 2;  // dropped on the device (need_reset was set)
   }
   return do_reset(k);
@@ -653,6 +683,7 @@ extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, in
     k->h_ring[slot] = *k->h_st;
     k->h_ring[slot].lost = tracked ? 0 : 1;
     k->ring_kind[slot] = 1;
+    k->ring_expect[slot] = 0u;
     HIPCHK(k, hipEventRecord(k->ring_ev[slot], s));
     k->ring_count += 1;
     return HSK_OK;
@@ -666,25 +697,36 @@ extern "C" int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, in
   const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
   k->h_slot_fifo[k->ring_seq % HSK_RING_FIFO] = slot;
   k->ring_seq += 1;
+  k->ring_expect[slot] = k->ring_seq | 0x80000000u;  // never 0 (0 = "this slot completes through its event")
+  ((volatile TrackState*)&k->h_ring[slot])->ring_mark = 0u;
   hipError_t e = hipSuccess;
-  if (k->set_used[set]) e = hipStreamWaitEvent(k->pstream, k->ev_free[set], 0);  // its previous user has finished
+  // no events on the main stream: the host itself sees, in the pinned ring, that the previous user of this buffer set has
+  // finished (it normally has: its pose was collected before this call)
+  if (k->set_used[set] && k->set_slot[set] >= 0 && k->ring_expect[k->set_slot[set]] == k->set_expect[set]) {
+    const int r2 = wait_slot(k, k->set_slot[set]);
+    if (r2 != HSK_OK) return r2;
+  }
+  k->set_expect[set] = k->ring_seq | 0x80000000u;
+  k->set_slot[set] = slot;
   if (e == hipSuccess) e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->pstream);
   if (e == hipSuccess) {
     enqueue_preprocess(k, k->pstream);
     e = hipEventRecord(k->ev_pre[set], k->pstream);
   }
-  if (e == hipSuccess) e = hipStreamWaitEvent(s, k->ev_pre[set], 0);
+  // The frame's own work needs the preprocessing.  A hipStreamWaitEvent on the main stream would be the obvious form,
+  // but a cross-stream wait costs ~19 us of stalled queue at every frame boundary even when the event fired long ago
+  // (2330 -> 2440 frames/s without it).  The host waits instead: it is a frame ahead of the GPU, the preprocessing takes
+  // ~60 us, and kernels enqueued after the host has seen it complete need no device-side dependency.
+  if (e == hipSuccess) e = hipEventSynchronize(k->ev_pre[set]);
   if (e == hipSuccess) {
     // Eager launches, on purpose: the host runs a frame ahead here, so their launch cost is hidden, while replaying
     // the frame from a hipGraph left ~8 us more idle GPU between consecutive frames (2330 vs 2285 frames/s measured).
     // The graph stays on the synchronous path, where the launch cost is exposed.
     enqueue_tracked_rest(k);
   }
-  if (e == hipSuccess) e = hipEventRecord(k->ev_free[set], s);
   k->set_used[set] = true;
   k->cur = 0;
   HIPCHK(k, e);
-  HIPCHK(k, hipEventRecord(k->ring_ev[slot], s));  // the raycast has written h_ring[slot] by the time this fires
   k->ring_kind[slot] = 0;
   k->ring_count += 1;
   return HSK_OK;
@@ -695,7 +737,10 @@ extern "C" int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked) {
   if (k->ring_count == 0) return fail(k, HSK_ERR_STATE, "no frame in flight");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   const int slot = k->ring_head;
-  HIPCHK(k, hipEventSynchronize(k->ring_ev[slot]));
+  {
+    const int rw = wait_slot(k, slot);
+    if (rw != HSK_OK) return rw;
+  }
   const TrackState& st = k->h_ring[slot];
   k->ring_head = (k->ring_head + 1) % (HSK_MAX_IN_FLIGHT + 1);
   k->ring_count -= 1;
@@ -1166,6 +1211,7 @@ extern "C" int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, co
   HIPCHK(k, hipMemcpyAsync(&k->h_ring[slot], k->d_st, sizeof(TrackState), hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipEventRecord(k->ring_ev[slot], k->stream));
   k->ring_kind[slot] = 0;
+  k->ring_expect[slot] = 0u;  // completes through its event
   k->ring_count += 1;
   return HSK_OK;
 }

@@ -864,6 +864,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     const int* src_w = (const int*)st;
     int* dst_w = (int*)dst;
     for (unsigned i = 0; i < sizeof(TrackState) / 4; ++i) dst_w[i] = src_w[i];
+    __threadfence_system();     // the state words reach the host before the mark that announces them
+    __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (x >= W || y >= H) return;  // (with a fused pyramid every tile is complete: launch_raycast checks W, H % 8)
   if (st->lost) return;
