@@ -30,7 +30,8 @@ void launch_vmap_nmap_pyramid(hipStream_t s, uint16_t* const* depth, const ImgLe
 void launch_transform_maps(hipStream_t s, const float* vs, const float* ns, int P, const TrackState* st, float* vd,
                            float* nd);
 void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W, int H, float* v1, float* n1, float* v2,
-                         float* n2, const TrackState* st);
+                         float* n2, const TrackState* st,
+                         const RingOut* ring = nullptr);
 int icp_num_blocks(int W, int rows);
 void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, const float* vprev, const float* nprev,
                            int W, int H, Intr in, const TrackState* st, float dist_thresh, float angle_thresh, int row0,

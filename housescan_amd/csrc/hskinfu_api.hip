@@ -1203,16 +1203,21 @@ extern "C" int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, co
   if (k->ring_count >= HSK_MAX_IN_FLIGHT) return fail(k, HSK_ERR_STATE, "too many frames in flight: call hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0], k->lv[0].W * k->lv[0].H);
-  launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
-                      k->d_nmod[2], k->d_st);
-  HIPCHK(k, hipEventRecord(k->ev_free[k->cur], k->stream));
-  k->set_used[k->cur] = true;
+  // the frame's last kernel reports the tracker state into the ring slot assigned here (no copy node, no event record
+  // for the pose: see hsk_submit_frame_dev)
   const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
-  HIPCHK(k, hipMemcpyAsync(&k->h_ring[slot], k->d_st, sizeof(TrackState), hipMemcpyDeviceToHost, k->stream));
-  HIPCHK(k, hipEventRecord(k->ring_ev[slot], k->stream));
+  k->h_slot_fifo[k->ring_seq % HSK_RING_FIFO] = slot;
+  k->ring_seq += 1;
+  k->ring_expect[slot] = k->ring_seq | 0x80000000u;
+  ((volatile TrackState*)&k->h_ring[slot])->ring_mark = 0u;
+  const RingOut ring = {k->d_ring_view, k->d_fifo_view, k->d_ring_seq};
+  launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
+                      k->d_nmod[2], k->d_st, &ring);
+  HIPCHK(k, hipEventRecord(k->ev_free[k->cur], k->stream));  // the prefetch of the frame after next waits on it (second stream)
+  k->set_used[k->cur] = true;
   k->ring_kind[slot] = 0;
-  k->ring_expect[slot] = 0u;  // completes through its event
   k->ring_count += 1;
+  HIPCHK(k, hipGetLastError());
   return HSK_OK;
 }
 

@@ -276,7 +276,18 @@ static __device__ __forceinline__ void resize_tap(const float* __restrict__ src,
 // recompute the four level-1 values they average (same arithmetic, so the same bits as reading them back)
 __global__ void k_resize_maps2(const float* __restrict__ v0, const float* __restrict__ n0, int W, int H,
                                float* __restrict__ v1, float* __restrict__ n1, float* __restrict__ v2,
-                               float* __restrict__ n2, const TrackState* __restrict__ st, int nb1) {
+                               float* __restrict__ n2, const TrackState* __restrict__ st, int nb1, RingOut ring) {
+  if (ring.slots && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
+    // last kernel of a pipelined slab frame: report the tracker state into the host ring (see k_raycast)
+    const unsigned n = *ring.seq;
+    *ring.seq = n + 1u;
+    TrackState* dst = ring.slots + ring.slot_fifo[n % HSK_RING_FIFO];
+    const int* src_w = (const int*)st;
+    int* dst_w = (int*)dst;
+    for (unsigned i = 0; i < sizeof(TrackState) / 4; ++i) dst_w[i] = src_w[i];
+    __threadfence_system();
+    __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (st->lost) return;
   const int w1 = W >> 1, h1 = H >> 1, w2 = W >> 2, h2 = H >> 2;
   const size_t P0 = (size_t)W * H, P1 = (size_t)w1 * h1, P2 = (size_t)w2 * h2;
@@ -321,9 +332,11 @@ __global__ void k_resize_maps2(const float* __restrict__ v0, const float* __rest
   }
 }
 void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W, int H, float* v1, float* n1, float* v2,
-                         float* n2, const TrackState* st) {
+                         float* n2, const TrackState* st, const RingOut* ring) {
   const int nb1 = ((W / 2 + 63) / 64) * ((H / 2 + 3) / 4), nb2 = ((W / 4 + 63) / 64) * ((H / 4 + 3) / 4);
-  hipLaunchKernelGGL(k_resize_maps2, dim3(nb1 + nb2), dim3(64, 4), 0, s, v0, n0, W, H, v1, n1, v2, n2, st, nb1);
+  const RingOut quiet = {nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(k_resize_maps2, dim3(nb1 + nb2), dim3(64, 4), 0, s, v0, n0, W, H, v1, n1, v2, n2, st, nb1,
+                     ring ? *ring : quiet);
 }
 
 // ------------------------------------------------------------------------------------------------------
