@@ -403,9 +403,12 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   return HSK_OK;
 }
 
+static int wait_slot(hsk_ctx* k, int slot);
+
 extern "C" void hsk_destroy(hsk_ctx* k) {
   if (!k) return;
-  if (k->stream) (void)hipStreamSynchronize(k->stream);
+  if (k->pstream) (void)hipStreamSynchronize(k->pstream);
+  if (k->stream) (void)hipStreamSynchronize(k->stream);  // frames in flight write into the pinned ring until they end
   free_all(k);
   delete k;
 }
@@ -414,7 +417,8 @@ extern "C" int hsk_reset(hsk_ctx* k) {
   if (!k) return HSK_ERR_ARG;
   for (int i = 0; i < k->ring_count; ++i) {  // frames still in flight are dropped
     const int sl = (k->ring_head + i) % (HSK_MAX_IN_FLIGHT + 1);
-    HIPCHK(k, hipEventSynchronize(k->ring_ev[sl]));
+    const int r = wait_slot(k, sl);
+    if (r != HSK_OK) return r;
     if (k->ring_kind[sl] == 0) k->ring_kind[sl] = 2;
   }
   return do_reset(k);

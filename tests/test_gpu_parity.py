@@ -535,6 +535,35 @@ def test_async_tracking_loss_drops_in_flight_frames(hsk, synth_frames):
     trk.close()
 
 
+def test_reset_and_destroy_with_frames_in_flight(hsk, synth_frames):
+    """hsk_reset waits for the pipelined frames (they report through the pinned ring, not through events) before it
+    clears the volume; their results are still collected, as dropped; closing a context with frames in flight is safe"""
+    import torch
+    trk = hsk.KinfuTracker(n=128)
+    dev = [torch.from_numpy(synth_frames(k)[1].view(np.int16)).cuda() for k in range(6)]
+    for k in range(3):
+        trk.process_frame_dev(dev[k].data_ptr())
+    trk.submit_frame_dev(dev[3].data_ptr())
+    trk.submit_frame_dev(dev[4].data_ptr())
+    trk.reset()                                      # both frames are in flight
+    assert not trk.download_tsdf().any()
+    for _ in range(2):
+        pose, ok = trk.wait_frame()
+        assert not ok and np.allclose(pose[:3, 3], [1.5, 1.5, -0.3])
+    # the scan restarts and matches a fresh context bit for bit
+    ref = hsk.KinfuTracker(n=128)
+    for k in range(3):
+        pa, oa = trk.process_frame_dev(dev[k].data_ptr())
+        pb, ob = ref.process_frame_dev(dev[k].data_ptr())
+        assert oa == ob
+        assert_same_bits(pa, pb, f"pose after reset {k}")
+    assert_same_bits(trk.download_tsdf(), ref.download_tsdf(), "tsdf after reset")
+    trk.submit_frame_dev(dev[3].data_ptr())
+    trk.submit_frame_dev(dev[4].data_ptr())
+    trk.close()                                      # frames in flight: destroy synchronises first
+    ref.close()
+
+
 def test_scan_two_rooms_and_stitch(tmp_path, hsk):
     """BASELINE configs[0] end to end: two closed rooms scanned by the core (three turns each) -> room directories ->
     loadRoom / orient / corner suggestions / cuboid fit / wall connections / least-squares placement -> .xf and a
