@@ -350,7 +350,10 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
 #define ICP_BLOCK 256
 #endif
 #ifndef ICP_PX_FINE
-#define ICP_PX_FINE 4  // pixels per lane at the finest level (1 at the coarse levels)
+#define ICP_PX_FINE 5  // pixels per lane at the finest level: 640x480 / (256 x 5) = 240 blocks, one per CU (with 4 the 300
+#endif                  // blocks gave 44 CUs a second one and every fine iteration waited for them: 178 -> 169 us of ICP)
+#ifndef ICP_PX_MID
+#define ICP_PX_MID 2   // 320x240 / (256 x 2) = 150 blocks
 #endif
 
 // Exact accumulation.  The spec sums quant26(p) = rint(p * 2^26) * 2^-26 over pixels, p the binary64 product of
@@ -558,8 +561,8 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __res
   icp_block_sums(acc, sh, partials + (size_t)blockIdx.x * 27);
 }
 
-// fine level: ICP_PX_FINE pixels per lane; coarse levels: 1 pixel per lane, shorter serial chain
-static inline int icp_px(int W) { return W >= 512 ? ICP_PX_FINE : 1; }
+// pixels per lane by level width, chosen so that a level's blocks fit the 256 CUs in one round (4:3 images)
+static inline int icp_px(int W) { return W >= 512 ? ICP_PX_FINE : (W >= 256 ? ICP_PX_MID : 1); }
 int icp_num_blocks(int W, int rows) { return (W * rows + ICP_BLOCK * icp_px(W) - 1) / (ICP_BLOCK * icp_px(W)); }
 
 // The kernels gate on squared quantities.  dist2_max: the largest binary32 y with sqrtf(y) <= dist_thresh;
@@ -599,6 +602,9 @@ void launch_icp_accumulate(hipStream_t s, const float* vcur, const float* ncur, 
   icp_gate_limits(dist_thresh, angle_thresh, &dist_thresh, &angle_thresh);  // the kernels take the squared limits
   if (icp_px(W) == ICP_PX_FINE)
     hipLaunchKernelGGL(k_icp_accumulate<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
+                       dist_thresh, angle_thresh, row0, row1, partials);
+  else if (icp_px(W) == ICP_PX_MID)
+    hipLaunchKernelGGL(k_icp_accumulate<ICP_PX_MID>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
                        dist_thresh, angle_thresh, row0, row1, partials);
   else
     hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur, ncur, vprev, nprev, W, H, in, st,
@@ -998,6 +1004,9 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
     for (int it = 0; it < iters[l]; ++it, ++i) {
       if (icp_px(W) == ICP_PX_FINE)
         hipLaunchKernelGGL(k_icp_iter<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
+                           H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
+      else if (icp_px(W) == ICP_PX_MID)
+        hipLaunchKernelGGL(k_icp_iter<ICP_PX_MID>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
                            H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
       else
         hipLaunchKernelGGL(k_icp_iter<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W, H,
