@@ -97,25 +97,26 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 // convex, so each column meets it in one interval; clipping the line cam(gz) = a + gz * c against the five
 // half-spaces gives it.  Conservative by 2 planes (float error).  Empty columns get (INT_MAX, INT_MIN).
 __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
-                                int2* __restrict__ zint, int col_blocks, const float* __restrict__ tmax,
+                                int2* __restrict__ zint, int dil_blocks, const float* __restrict__ tmax,
                                 const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th,
                                 unsigned* __restrict__ qcount) {
-  if ((int)blockIdx.x >= col_blocks) {  // the last blocks dilate the tile table instead (saves a launch)
-    // ... and the first of them clears the queue counters of pass A (saves a memset node and its boundary)
-    if ((int)blockIdx.x == col_blocks)
+  // The first blocks also dilate the tile table and clear the queue counters of pass A (no extra launch, memset node or
+  // extra blocks: at 512^3 the column work alone is exactly one block per CU).
+  {
+    if (blockIdx.x == 0)
       for (int q = threadIdx.x; q < HSK_NQUEUES; q += blockDim.x) qcount[q * HSK_QCOUNT_STRIDE] = 0u;
-    const int i = (blockIdx.x - col_blocks) * blockDim.x + threadIdx.x;
-    if (i >= tw * th) return;
-    const int ty = i / tw, tx = i - ty * tw;
-    float mx = 0.0f, mn = 1e30f;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
-        mx = fmaxf(mx, tmax[yy * tw + xx]);
-        mn = fminf(mn, tmin[yy * tw + xx]);
-      }
-    dtab[i] = make_float2(mx, mn);
-    return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tw * th && (int)blockIdx.x < dil_blocks) {
+      const int ty = i / tw, tx = i - ty * tw;
+      float mx = 0.0f, mn = 1e30f;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
+          mx = fmaxf(mx, tmax[yy * tw + xx]);
+          mn = fminf(mn, tmin[yy * tw + xx]);
+        }
+      dtab[i] = make_float2(mx, mn);
+    }
   }
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncol = vp.X / 4;
@@ -648,7 +649,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const float2* ftab = (const float2*)(tmax + 4 * tw * th);  // behind the coarse tables (filled by launch_tile_fine)
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
   unsigned* qcount = queue;  // HSK_NQUEUES counters, one per 256-B line, cleared by k_column_zrange
-  hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks + dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, col_blocks,
+  hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, dil_blocks,
                      tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
