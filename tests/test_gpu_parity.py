@@ -213,6 +213,46 @@ def test_tracker_bit_exact_and_accurate(hsk, oracle, synth_frames, graph):
     trk.close()
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (336, 252), (160, 120)])
+def test_tracker_other_image_sizes(hsk, oracle, w, h):
+    """image sizes other than 640x480 take other kernel shapes (ICP pixels per lane by level width, the raycast's fused
+    pyramid only when both dimensions are multiples of 8, partial tiles otherwise): still bit-exact against the oracle,
+    synchronous and pipelined"""
+    import torch
+    n = 96
+    s = w / 640.0
+    intr = dict(fx=525.0 * s, fy=525.0 * s, cx=w / 2 - 0.5, cy=h / 2 - 0.5)
+    cfg_o = oracle.default_config(n, W=w, H=h, **intr)
+    ot = oracle.Tracker(cfg_o, omp=True)
+    trk = hsk.KinfuTracker(n=n, width=w, height=h, **intr)
+    pipe = hsk.KinfuTracker(n=n, width=w, height=h, **intr)
+    frames = [hsk.synth_depth(hsk.synth_pose(k), w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"]) for k in range(8)]
+    dev = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
+    want = []
+    for k, depth in enumerate(frames):
+        po, oko = ot.process(depth)
+        ph, okh = trk.process_frame(depth)
+        assert oko == okh == (k > 0)
+        assert_same_bits(ph, po, f"{w}x{h} pose frame {k}")
+        want.append((po, oko))
+    assert_same_bits(trk.download_tsdf(), ot.volume(), f"{w}x{h} tsdf")
+    for level in range(3):
+        assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"{w}x{h} model vmap {level}")
+        assert_same_bits(trk.download_map(3, level), ot.model_map(3, level), f"{w}x{h} model nmap {level}")
+    got = []
+    pipe.submit_frame_dev(dev[0].data_ptr())
+    for k in range(1, 8):
+        pipe.submit_frame_dev(dev[k].data_ptr())
+        got.append(pipe.wait_frame())
+    got.append(pipe.wait_frame())
+    for k, ((po, oko), (pp, okp)) in enumerate(zip(want, got)):
+        assert oko == okp
+        assert_same_bits(pp, po, f"{w}x{h} pipelined pose frame {k}")
+    assert_same_bits(pipe.download_tsdf(), ot.volume(), f"{w}x{h} pipelined tsdf")
+    trk.close()
+    pipe.close()
+
+
 def test_tracking_lost_resets(hsk, synth_frames):
     trk = hsk.KinfuTracker(n=64)
     _, d0 = synth_frames(0)
