@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
         //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
         //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
+#ifndef HSK_EXPA_NO_L2
         if (__ballot(other) != 0ull) {
           const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - k.tz;
           const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - k.tz;
@@ -490,8 +491,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
           if (other && free2) free44 = true;
           other = other && !dead2 && !free2;
         }
+#endif
       }
+#ifdef HSK_EXPA_NO_FREE
+      if (false) {
+#else
       if (free44) {
+#endif
         if (COUNT_ONLY) {
           cnt += 16;
         } else {
@@ -504,7 +510,11 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         }
       }
       // wave-aggregated append of the uncertain lane-blocks
+#ifdef HSK_EXPA_NO_QUEUE
+      const unsigned long long bo = 0ull;
+#else
       const unsigned long long bo = __ballot(other);
+#endif
       if (bo != 0ull) {
         // one of HSK_NQUEUES queues (a single counter saturates at ~88 atomics/us chip-wide).  The queue must NOT follow
         // the block's x-y position: surfaces cluster in a few columns, and pass B's time is its longest queue.  Rotate
