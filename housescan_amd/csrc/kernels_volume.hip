@@ -25,7 +25,7 @@
 #define INTEGRATE_WPE 6  // waves per SIMD the register allocator must leave room for (79 VGPRs, no spills)
 #endif
 #ifndef INTEGRATE_DETAIL_WPE
-#define INTEGRATE_DETAIL_WPE 4  // pass B keeps 4 planes x 4 voxels of state per lane: ~120 VGPRs
+#define INTEGRATE_DETAIL_WPE 7  // pass B works one plane (4 voxels per lane) at a time: <= 72 VGPRs, 7 waves per SIMD
 #endif
 #ifndef INTEGRATE_ZCHUNK
 #define INTEGRATE_ZCHUNK 8
@@ -587,36 +587,45 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
       c.pnc = 0.5f * (c.pn[1] + c.pn[2]);
     }
     const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
-    bool in_range[4];
-    unsigned mask[4], one[4];
-    float F[4][4];
+#ifndef DETAIL_U
+#define DETAIL_U 1  // planes of an entry classified and updated together.  Measured 512^3 / 1024^3 (us, with the matching
+                    // occupancy and one resident round of blocks): U = 4 at 4 waves per SIMD 141 / 945, U = 2 at 5: 126 / 876,
+                    // U = 1 at 6: 120 / 858, U = 1 at 7: 119 / 838 -- resident waves hide the gathers better than batching
+#endif
 #pragma unroll
-    for (int u = 0; u < 4; ++u) in_range[u] = have && (zb + u) >= zr.x && (zb + u) <= zr.y && (zb + u) < vp.nzs;
-    classify_planes<4>(zb, in_range, c, k, vp, W, H, in, dtab, tw, th, scaled, mask, one, F);
-    if (COUNT_ONLY) {
+    for (int h0 = 0; h0 < 4; h0 += DETAIL_U) {
+      bool in_range[DETAIL_U];
+      unsigned mask[DETAIL_U], one[DETAIL_U];
+      float F[DETAIL_U][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cnt += __popc(mask[u]);
-      continue;
-    }
-    uint4 q[4];
+      for (int u = 0; u < DETAIL_U; ++u)
+        in_range[u] = have && (zb + h0 + u) >= zr.x && (zb + h0 + u) <= zr.y && (zb + h0 + u) < vp.nzs;
+      classify_planes<DETAIL_U>(zb + h0, in_range, c, k, vp, W, H, in, dtab, tw, th, scaled, mask, one, F);
+      if (COUNT_ONLY) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (mask[u]) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+        for (int u = 0; u < DETAIL_U; ++u) cnt += __popc(mask[u]);
+        continue;
+      }
+      uint4 q[DETAIL_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!mask[u]) continue;
-      const int zz = zb + u;
-      const uint4 before = q[u];
-      const bool neg = update_vector(q[u], mask[u], one[u], F[u]);
-      // saturated free space (+1 at the weight cap) comes back unchanged: no store
-      if (q[u].x != before.x || q[u].y != before.y || q[u].z != before.z || q[u].w != before.w)
-        vol[idx0 + (size_t)zz * plane_vec] = q[u];
-      if (neg) {
-        const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
-        // test first: after the first frames the bit is already set and no atomic is issued (a stale read only
-        // costs a redundant OR)
-        if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
-          __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int u = 0; u < DETAIL_U; ++u)
+        if (mask[u]) q[u] = vol[idx0 + (size_t)(zb + h0 + u) * plane_vec];
+#pragma unroll
+      for (int u = 0; u < DETAIL_U; ++u) {
+        if (!mask[u]) continue;
+        const int zz = zb + h0 + u;
+        const uint4 before = q[u];
+        const bool neg = update_vector(q[u], mask[u], one[u], F[u]);
+        // saturated free space (+1 at the weight cap) comes back unchanged: no store
+        if (q[u].x != before.x || q[u].y != before.y || q[u].z != before.z || q[u].w != before.w)
+          vol[idx0 + (size_t)zz * plane_vec] = q[u];
+        if (neg) {
+          const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
+          // test first: after the first frames the bit is already set and no atomic is issued (a stale read only
+          // costs a redundant OR)
+          if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
+            __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
@@ -657,7 +666,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned nblk = grid.x * grid.y * grid.z;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
 #ifndef DETAIL_GX
-#define DETAIL_GX 4  // 4 x 256 queues x 4 waves = one resident round of the chip at 4 waves per SIMD
+#define DETAIL_GX 7  // 7 x 256 queues x 4 waves = one resident round of the chip at 7 waves per SIMD
 #endif
   const dim3 detail_grid(DETAIL_GX, HSK_NQUEUES);  // DETAIL_GX blocks stride over each queue
   if (count_only) {
