@@ -349,6 +349,7 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
 #ifndef ICP_BLOCK
 #define ICP_BLOCK 256
 #endif
+#define ICP_SH_ROWS ((ICP_BLOCK / 64) > 8 ? (ICP_BLOCK / 64) : 8)  // LDS rows: one per wave, at least the 8 slices of the shard reduction
 #ifndef ICP_PX_FINE
 #define ICP_PX_FINE 5  // pixels per lane at the finest level: 640x480 / (256 x 5) = 240 blocks, one per CU (with 4 the 300
 #endif                  // blocks gave 44 CUs a second one and every fine iteration waited for them: 178 -> 169 us of ICP)
@@ -645,7 +646,7 @@ static __device__ __forceinline__ void block_reduce27(const double* __restrict__
 
 __global__ __launch_bounds__(256) void k_icp_reduce(const double* __restrict__ partials, int nblocks,
                                                     double* __restrict__ out27) {
-  __shared__ double sh[8][32];
+  __shared__ double sh[ICP_SH_ROWS][32];
   __shared__ double tot[27];
   block_reduce27(partials, nblocks, sh, tot);
   if (threadIdx.x < 27) out27[threadIdx.x] = tot[threadIdx.x];
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
                                                         int W, int H, Intr in, TrackState* st, float dist_thresh,
                                                         float angle_thresh, const IcpPose* __restrict__ pose_in,
                                                         IcpPose* __restrict__ pose_out, double* __restrict__ slots, int iter) {
-  __shared__ double sh[8][32];
+  __shared__ double sh[ICP_SH_ROWS][32];
   __shared__ double tot[27];
   __shared__ IcpPose sp;
   IcpLaneIn<ICP_PX> L;
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
 // after the last iteration: final solve, pose and lost flag into the tracker state
 __global__ __launch_bounds__(256) void k_icp_final(const IcpPose* __restrict__ pose_in, double* __restrict__ slots, int iter,
                                                    TrackState* __restrict__ st) {
-  __shared__ double sh[8][32];
+  __shared__ double sh[ICP_SH_ROWS][32];
   __shared__ double tot[27];
   shard_reduce27(slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES, sh, tot);
   // slot 0 is where the next frame's first iteration adds: leave it empty (it may be the slot just read)
