@@ -40,6 +40,8 @@ struct VolParams {
   float tau, tau_inv;
   int bshift;      // log2 of the brick edge of the "has held a negative TSDF" bitfield (3 => 8^3 voxels)
   double icell[3]; // correctly rounded binary64 reciprocals of cell[] (hsk_div_by_cell)
+  int stream_nt;   // free-space updates stream the volume with non-temporal accesses (volumes >> Infinity Cache)
+  int pad_;
 };
 
 #ifndef HSK_FLAG_WORDS_MAX

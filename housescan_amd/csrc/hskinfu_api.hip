@@ -316,6 +316,8 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   vp.cell[1] = vp.size[1] / (float)vp.Y;
   vp.cell[2] = vp.size[2] / (float)vp.Z;
   for (int a = 0; a < 3; ++a) vp.icell[a] = 1.0 / (double)vp.cell[a];
+  vp.stream_nt = 0;  // decided below, once the stored plane count is known
+  vp.pad_ = 0;
   float m = vp.cell[0] > vp.cell[1] ? vp.cell[0] : vp.cell[1];
   m = m > vp.cell[2] ? m : vp.cell[2];
   const float lo = 2.1f * m;
@@ -330,6 +332,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   pose16_to_rt(c->init_pose, k->init_R, k->init_t);
   // memory
   k->vol_bytes = (size_t)vp.X * vp.Y * vp.nzs * 4;
+  vp.stream_nt = k->vol_bytes > ((size_t)1 << 30) ? 1 : 0;  // > 1 GiB: four times the Infinity Cache and more
   CK(hipMalloc(&k->d_vol, k->vol_bytes));
   const size_t P0 = (size_t)c->width * c->height;
   for (auto& b : k->ib) {

@@ -489,11 +489,29 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
           cnt += 16;
         } else {
           uint4 q4[4];
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          if (vp.stream_nt) {
+            // a volume far larger than the 256 MiB Infinity Cache gains nothing from caching these lines and loses
+            // what they evict: non-temporal loads and stores (1024^3: 838 -> 802 us; at 512^3, where half the volume
+            // stays cached from frame to frame, they cost 10 us, so the host decides by size)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) q4[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+            for (int u = 0; u < 4; ++u) {
+              const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zb + u) * plane_vec]);
+              q4[u] = make_uint4(t.x, t.y, t.z, t.w);
+            }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (update_vector_free4(q4[u])) vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
+            for (int u = 0; u < 4; ++u)
+              if (update_vector_free4(q4[u])) {
+                const v4u t = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+                __builtin_nontemporal_store(t, (v4u*)&vol[idx0 + (size_t)(zb + u) * plane_vec]);
+              }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q4[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (update_vector_free4(q4[u])) vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
+          }
         }
       }
       // wave-aggregated append of the uncertain lane-blocks
