@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
-    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
     ap.add_argument("--slab-graph", type=int, default=0, help="replay the z-slab frame front from a hipGraph (default: eager)")
     ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of the submit/wait pair")
     ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")

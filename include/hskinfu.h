@@ -56,7 +56,7 @@ typedef struct {
   /* z-slab sharding (multi-GPU): this context stores planes [own_z0 - halo, own_z1 + halo) clipped to the
    * volume and OWNS raycast steps whose far sample lies in [own_z0, own_z1).  Single device: 0, vol_z, 0. */
   int own_z0, own_z1, halo;
-  int use_graph;                /* 1 = replay the steady-state frame as one hipGraph (default 1)        */
+  int use_graph;                /* 1 = replay synchronous frames from one hipGraph; 0 (default) = eager  */
 } hsk_config;
 
 /* fills *c with the defaults above for an n^3 volume */

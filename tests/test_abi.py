@@ -83,7 +83,7 @@ def test_default_config_values(hsk):
     assert abs(c.icp_angle_thresh_sin - np.sin(np.radians(20))) < 1e-7
     pose = np.array(c.init_pose, np.float32).reshape(4, 4)
     assert np.allclose(pose[:3, :3], np.eye(3)) and np.allclose(pose[:3, 3], [1.5, 1.5, -0.3], atol=1e-6)
-    assert (c.own_z0, c.own_z1, c.halo, c.use_graph) == (0, 512, 0, 1)
+    assert (c.own_z0, c.own_z1, c.halo, c.use_graph) == (0, 512, 0, 0)
 
 
 def test_no_gpu_fails_loudly(hsk):
