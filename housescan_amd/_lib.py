@@ -50,6 +50,7 @@ SYMBOLS = {
     "hsk_process_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, _I]),
     "hsk_process_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, _I]),
     "hsk_submit_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "hsk_submit_frame": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "hsk_wait_frame": (C.c_int, [_P, _F, _I]),
     "hsk_integrate": (C.c_int, [_P, _P, C.c_int, C.c_int, _F]),
     "hsk_raycast": (C.c_int, [_P, _F, _P, _P, _P]),

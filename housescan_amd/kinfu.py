@@ -93,6 +93,11 @@ class KinfuTracker:
         """enqueue a frame (device pointer) without waiting; collect poses in order with wait_frame()"""
         self._ck(self.lib.hsk_submit_frame_dev(self.h, C.c_void_p(depth_dev_ptr), self.w, self.hgt))
 
+    def submit_frame(self, depth):
+        """enqueue a frame held in host memory (copied before this returns); collect poses in order with wait_frame()"""
+        d = self._depth(depth)
+        self._ck(self.lib.hsk_submit_frame(self.h, d.ctypes.data, d.shape[1], d.shape[0]))
+
     def wait_frame(self):
         pose = np.empty(16, np.float32)
         tracked = C.c_int()

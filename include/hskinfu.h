@@ -82,6 +82,7 @@ int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float
  * therefore stay valid until hsk_wait_frame has returned that frame. */
 #define HSK_MAX_IN_FLIGHT 3
 int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h);
+int hsk_submit_frame(hsk_ctx* k, const uint16_t* depth, int w, int h); /* host frame; copied before the call returns */
 int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked);
 
 /* Stage-level entry points: exist so parity tests and rocprof can isolate each kernel. */

@@ -551,8 +551,24 @@ def test_async_submit_wait_matches_sync(hsk, synth_frames):
         assert oks == oka, k
         assert_same_bits(pa, ps, f"async pose {k}")
     assert_same_bits(b.download_tsdf(), a.download_tsdf(), "async tsdf")
+    # the same with frames in host memory: copied at submission, so the caller may reuse its buffer at once
+    c = hsk.KinfuTracker(n=n)
+    scratch = np.empty_like(frames[0])
+    got = []
+    for i, f in enumerate(frames):
+        scratch[:] = f
+        c.submit_frame(scratch)
+        scratch[:] = 0                      # the library must not be reading this any more
+        if i >= 2:
+            got.append(c.wait_frame())
+    got += [c.wait_frame(), c.wait_frame()]
+    for k, ((ps, oks), (pc, okc)) in enumerate(zip(sync, got)):
+        assert oks == okc, k
+        assert_same_bits(pc, ps, f"host-frame async pose {k}")
+    assert_same_bits(c.download_tsdf(), a.download_tsdf(), "host-frame async tsdf")
     a.close()
     b.close()
+    c.close()
 
 
 def test_async_tracking_loss_drops_in_flight_frames(hsk, synth_frames):
