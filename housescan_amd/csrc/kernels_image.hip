@@ -372,36 +372,41 @@ static __device__ __forceinline__ double dpp_mov_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// gfx950 lane swaps of a 64-bit pair: v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31
+// of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second -- one VALU
+// instruction per 32-bit half moves BOTH directions of a butterfly step (no selects, no trip through the LDS crossbar).
+static __device__ __forceinline__ double swap32_add_f64(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+static __device__ __forceinline__ double swap16_add_f64(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
 // wave64 sums of 27 values at once by a halving butterfly: at every step the two partner lanes split the
 // remaining values between them, so 16 + 8 + 4 + 2 + 1 + 1 exchanges replace 27 x 6.  On return lane l holds the
 // wave total of value (l >> 1) & 31 for l < 64 (values 27..31 are padding); lanes 2k and 2k+1 both hold value k.
+// The first two steps (24 of the 32 exchanges) are lane swaps, the last four DPP moves inside a row of 16 lanes;
+// the step of distance 4 pairs lane l with l ^ 7 (row_half_mirror): any partner with the opposite bit 2 and the same
+// higher bits will do, because the sums are exact (multiples of 2^-26) and so independent of the order of addition.
 static __device__ __forceinline__ double wave_sum27(const double* acc, int lane) {
   double v[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) v[i] = i < 27 ? acc[i] : 0.0;
-  // step with partner lane ^ 32: lanes < 32 keep values 0..15, lanes >= 32 keep 16..31
-  {
-    const bool up = lane & 32;
+  // distance 32: lanes < 32 keep values 0..15, lanes >= 32 keep 16..31
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const double keep = up ? v[i + 16] : v[i], send = up ? v[i] : v[i + 16];
-      v[i] = keep + __shfl_xor(send, 32, 64);
-    }
-  }
-  {
-    const bool up = lane & 16;
+  for (int i = 0; i < 16; ++i) v[i] = swap32_add_f64(v[i], v[i + 16]);
+  // distance 16: even rows keep values i, odd rows i + 8
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const double keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
-      v[i] = keep + __shfl_xor(send, 16, 64);
-    }
-  }
+  for (int i = 0; i < 8; ++i) v[i] = swap16_add_f64(v[i], v[i + 8]);
   {
     const bool up = lane & 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const double keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
-      v[i] = keep + __shfl_xor(send, 8, 64);
+      v[i] = keep + dpp_mov_f64<0x128>(send);  // row_ror:8 == lane ^ 8
     }
   }
   {
@@ -409,15 +414,15 @@ static __device__ __forceinline__ double wave_sum27(const double* acc, int lane)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
-      v[i] = keep + __shfl_xor(send, 4, 64);
+      v[i] = keep + dpp_mov_f64<0x141>(send);  // row_half_mirror: lane ^ 7
     }
   }
   {
     const bool up = lane & 2;
     const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-    v[0] = keep + __shfl_xor(send, 2, 64);
+    v[0] = keep + dpp_mov_f64<0x4E>(send);  // quad_perm [2,3,0,1] == lane ^ 2
   }
-  v[0] += __shfl_xor(v[0], 1, 64);
+  v[0] += dpp_mov_f64<0xB1>(v[0]);  // quad_perm [1,0,3,2] == lane ^ 1
   return v[0];
 }
 // value index held by `lane` after wave_sum27: bit 5 -> +16, bit 4 -> +8, bit 3 -> +4, bit 2 -> +2, bit 1 -> +1
@@ -891,6 +896,17 @@ static __device__ __forceinline__ void icp_block_sums_atomic(const double* acc, 
   }
 }
 
+#ifdef HSK_ICP_TIMING
+// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration
+__device__ unsigned long long g_icp_times[20 * 256 * 6];
+extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
+}
+#define ICP_STAMP(k) do { if (threadIdx.x == 0 && iter < 20 && blockIdx.x < 256) g_icp_times[(iter * 256 + blockIdx.x) * 6 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ICP_STAMP(k) do { } while (0)
+#endif
+
 template <int ICP_PX>
 __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict__ vcur, const float* __restrict__ ncur,
                                                         const float* __restrict__ vprev, const float* __restrict__ nprev,
@@ -900,6 +916,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   __shared__ double sh[ICP_SH_ROWS][32];
   __shared__ double tot[27];
   __shared__ IcpPose sp;
+  ICP_STAMP(0);
   IcpLaneIn<ICP_PX> L;
   icp_load_current<ICP_PX>(vcur, ncur, W, H, 0, H, L);  // independent of the pose: in flight during the prologue
   // the previous pose estimate and the model pose come from other launches (L2 misses): fetch them now, not after
@@ -941,6 +958,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   for (int i = blockIdx.x * ICP_BLOCK + threadIdx.x; i < ICP_SLOT_DOUBLES; i += gridDim.x * ICP_BLOCK)
     __hip_atomic_store(slot_clear + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (iter > 0) shard_reduce27(slot_read, sh, tot);
+  ICP_STAMP(1);
   if (threadIdx.x < 64) {  // the first wave (icp_solve_step shares the work among its lanes)
     IcpPose p = p_in;
     if (iter > 0) icp_solve_step(tot, p);
@@ -950,13 +968,16 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
     }
   }
   __syncthreads();
+  ICP_STAMP(2);
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   if (!sp.lost)
     icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, sp.R, sp.t, Rp, tp, dist_thresh, angle_thresh, acc);
+  ICP_STAMP(3);
   __syncthreads();  // sh is reused by the block reduction below
   icp_block_sums_atomic(acc, (double (*)[32])sh, slot_add);
+  ICP_STAMP(4);
 }
 
 // after the last iteration: final solve, pose and lost flag into the tracker state
