@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
     ap.add_argument("--host-frames", action="store_true", help="also time hsk_process_frame with HOST depth buffers (PCIe-inclusive)")
     ap.add_argument("--force-sharded", action="store_true", help="use the z-slab host + collectives even at 1 GPU (plumbing check)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the check below)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (with --backend gloo: a logic check of the "
+                    "N > 1 path on a one-GPU box; its numbers mean nothing)")
     args = ap.parse_args()
 
     import torch
@@ -88,7 +91,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
@@ -101,7 +104,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     K, Wm = args.steps, args.warmup
     n = args.volume
@@ -184,11 +190,12 @@ def main():
                                "3 m cube, integrate + 19-iteration ICP + raycast per frame" % n,
                    "volume": n, "image": [640, 480], "icp_iters": [10, 5, 4],
                    "parallelism": ("1 gpu" if world == 1 else f"{args.mode}{world}" + (f"-icp-{args.icp}" if args.mode == "slab" else "")),
-                   "graph": bool(args.graph),
+                   "graph": bool(args.graph), **({"check_only": "all ranks share device 0 over %s" % args.backend} if args.share_gpu else {}),
                    "api": "submit/wait (1 frame in flight ahead)" if (use_async or ((world > 1 or args.force_sharded) and args.mode == "slab"
                                                                                     and args.icp == "replicated" and not args.sync_api))
                    else "process_frame (sync per frame)"},
-        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3)},
+        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3),
+                     "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
     }
 
     if rank == 0 and world == 1 and not args.force_sharded:

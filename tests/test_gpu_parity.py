@@ -664,3 +664,31 @@ def test_scan_two_rooms_and_stitch(tmp_path, hsk):
     H.write_ply_points(str(tmp_path / "house.ply"), np.concatenate(merged))
     assert len(H.read_ply_points(str(tmp_path / "house.ply"))) == sum(len(m) for m in merged)
     hs.close()
+
+
+def test_bench_two_ranks_match_one(tmp_path):
+    """bench.py's N > 1 flow end to end on the one GPU of the box: two ranks (torch.distributed.run) share device 0
+    and exchange over gloo -- the z-slab split, the key / bit-pattern collectives, the pipelined slab frames and the
+    max-over-ranks timing all run; the final pose must be bit-identical to the single-process run's"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    common = ["--steps", "24", "--warmup", "6", "--volume", "256", "--no-cpu-baseline"]
+
+    def last_json(cmd):
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one = last_json([sys.executable, "bench.py"] + common)
+    assert one["tracking"]["lost_frames"] == 0
+    for icp in ("replicated", "allreduce"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        two = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--share-gpu", "--icp", icp] + common)
+        assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["tracking"]["lost_frames"] == 0
+        assert two["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"], icp
+        assert two["independent_rooms"]["scaling"] == "weak"
