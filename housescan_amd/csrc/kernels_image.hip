@@ -826,10 +826,22 @@ struct IcpPose {
   int lost, n_iter, pad[2];
 };
 
+#ifdef HSK_ICP_TIMING
+// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration
+__device__ unsigned long long g_icp_times[20 * 256 * 10];
+extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
+}
+#define ICP_STAMP(k) do { if (threadIdx.x == 0 && g_icp_iter < 20 && blockIdx.x < 256) g_icp_times[(g_icp_iter * 256 + blockIdx.x) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ICP_STAMP(k) do { } while (0)
+#endif
+
 // Executed by the whole first wave: lane 0 solves, lanes 0..2 evaluate one sine/cosine pair each (the three
 // polynomial evaluations are the longest serial piece after the factorisation), lane 0 applies the increment.
 // Only lane 0's copy of p is meaningful afterwards.
-static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p) {
+static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p, int g_icp_iter = 99) {
+  (void)g_icp_iter;  // only the timing build's stamps use it
   const int lane = threadIdx.x & 63;
   float x6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   bool go = false;
@@ -837,8 +849,10 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
     double s[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) s[k] = tot[k];
+    ICP_STAMP(5);
     go = hsk_solve6(s, x6);
     if (!go) p.lost = 1;
+    ICP_STAMP(6);
   }
   const float a0 = __shfl(x6[0], 0, 64), a1 = __shfl(x6[1], 0, 64), a2 = __shfl(x6[2], 0, 64);
   double sd, cd;
@@ -847,10 +861,12 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
   const float sa = __shfl(sf, 0, 64), ca = __shfl(cf, 0, 64);
   const float sb = __shfl(sf, 1, 64), cb = __shfl(cf, 1, 64);
   const float sg = __shfl(sf, 2, 64), cg = __shfl(cf, 2, 64);
+  ICP_STAMP(7);
   if (go) {
     hsk_pose_update_sc(p.R, p.t, x6, sa, ca, sb, cb, sg, cg);
     p.n_iter += 1;
   }
+  ICP_STAMP(8);
 }
 
 // The 27 sums travel between launches through sharded accumulators instead of per-block partial rows: the
@@ -896,16 +912,6 @@ static __device__ __forceinline__ void icp_block_sums_atomic(const double* acc, 
   }
 }
 
-#ifdef HSK_ICP_TIMING
-// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration
-__device__ unsigned long long g_icp_times[20 * 256 * 6];
-extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
-}
-#define ICP_STAMP(k) do { if (threadIdx.x == 0 && iter < 20 && blockIdx.x < 256) g_icp_times[(iter * 256 + blockIdx.x) * 6 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ICP_STAMP(k) do { } while (0)
-#endif
 
 template <int ICP_PX>
 __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict__ vcur, const float* __restrict__ ncur,
@@ -916,6 +922,8 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   __shared__ double sh[ICP_SH_ROWS][32];
   __shared__ double tot[27];
   __shared__ IcpPose sp;
+  const int g_icp_iter = iter;
+  (void)g_icp_iter;
   ICP_STAMP(0);
   IcpLaneIn<ICP_PX> L;
   icp_load_current<ICP_PX>(vcur, ncur, W, H, 0, H, L);  // independent of the pose: in flight during the prologue
@@ -961,7 +969,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   ICP_STAMP(1);
   if (threadIdx.x < 64) {  // the first wave (icp_solve_step shares the work among its lanes)
     IcpPose p = p_in;
-    if (iter > 0) icp_solve_step(tot, p);
+    if (iter > 0) icp_solve_step(tot, p, iter);
     if (threadIdx.x == 0) {
       sp = p;
       if (blockIdx.x == 0) *pose_out = p;

@@ -543,6 +543,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
   }
 }
 
+#ifdef HSK_INT_TIMING
+// timing build (tools/int_timing.sh): s_memrealtime stamps (start, end, entries) of every wave of pass B
+__device__ unsigned long long g_detail_times[8192 * 3];
+extern "C" int hsk_debug_detail_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_detail_times), (size_t)n * 8);
+}
+#endif
 // Pass B of integrate: the queued (uncertain) lane-blocks, one per lane, four planes each, per-voxel path.
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(uint4* __restrict__ vol,
@@ -558,6 +565,10 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
                                                                          unsigned qcap) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
+#ifdef HSK_INT_TIMING
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  unsigned my_entries = 0;
+#endif
   // blockIdx.y = queue, blockIdx.x = one of gridDim.x blocks striding over it
   const unsigned n = qcount[blockIdx.y * HSK_QCOUNT_STRIDE];
   const unsigned* __restrict__ queue = queue_all + (size_t)blockIdx.y * qcap;
@@ -584,6 +595,9 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
   for (unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < n; e0 += stride) {  // wave-uniform trip count
     const unsigned e = e0 + lane;
     const bool have = e < n;
+#ifdef HSK_INT_TIMING
+    my_entries += (n - e0 < 64u ? n - e0 : 64u);
+#endif
     const unsigned id = have ? queue[e] : 0u;
     const int x0 = (int)(id % (unsigned)qx) * 4, y = (int)((id / (unsigned)qx) % (unsigned)vp.Y);
     const int zb = (int)(id / ((unsigned)qx * (unsigned)vp.Y)) * 4;
@@ -652,6 +666,16 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
     if (lane == 0 && cnt) atomicAdd(counter, cnt);
   }
+#ifdef HSK_INT_TIMING
+  if (!COUNT_ONLY && lane == 0) {
+    const unsigned w = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+    if (w < 8192) {
+      g_detail_times[w * 3] = t_start;
+      g_detail_times[w * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+      g_detail_times[w * 3 + 2] = my_entries;
+    }
+  }
+#endif
 }
 
 // fine (8-px) tile table: depends only on the depth frame, so it belongs to the preprocessing
