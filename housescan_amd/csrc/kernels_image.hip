@@ -837,33 +837,66 @@ extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
 #define ICP_STAMP(k) do { } while (0)
 #endif
 
-// Executed by the whole first wave: lane 0 solves, lanes 0..2 evaluate one sine/cosine pair each (the three
-// polynomial evaluations are the longest serial piece after the factorisation), lane 0 applies the increment.
-// Only lane 0's copy of p is meaningful afterwards.
+static __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+// Row `i` of hsk_pose_update_sc: the same expressions in the same order, element by element (the three 3x3 products
+// are row-separable), so three lanes produce the rows of the new rotation and translation with the bits one lane would.
+static __device__ __forceinline__ void hsk_pose_update_row(int i, const float* R, const float* t, const float* x6, float sa,
+                                                           float ca, float sb, float cb, float sg, float cg, float* rn,
+                                                           float* tn) {
+  const float z0 = i == 0 ? cg : (i == 1 ? sg : 0.0f), z1 = i == 0 ? -sg : (i == 1 ? cg : 0.0f), z2 = i == 2 ? 1.0f : 0.0f;
+  const float Ry[9] = {cb, 0.0f, sb, 0.0f, 1.0f, 0.0f, -sb, 0.0f, cb};
+  const float Rx[9] = {1.0f, 0.0f, 0.0f, 0.0f, ca, -sa, 0.0f, sa, ca};
+  float zy[3], inc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) zy[j] = (z0 * Ry[j] + z1 * Ry[3 + j]) + z2 * Ry[6 + j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) inc[j] = (zy[0] * Rx[j] + zy[1] * Rx[3 + j]) + zy[2] * Rx[6 + j];
+  const float xi = i == 0 ? x6[3] : (i == 1 ? x6[4] : x6[5]);
+  *tn = ((inc[0] * t[0] + inc[1] * t[1]) + inc[2] * t[2]) + xi;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) rn[j] = (inc[0] * R[j] + inc[1] * R[3 + j]) + inc[2] * R[6 + j];
+}
+
+// Executed by the whole first wave: lane 0 solves; lanes 0..2 evaluate one sine/cosine pair each (the three polynomial
+// evaluations are the longest serial piece after the factorisation) and then one row each of the pose update (three
+// 3x3 products on one lane were 150 dependent instructions); the rows are broadcast, so every lane of the wave
+// leaves with the whole new pose.
 static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p, int g_icp_iter = 99) {
   (void)g_icp_iter;  // only the timing build's stamps use it
   const int lane = threadIdx.x & 63;
   float x6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  bool go = false;
+  int go = 0;
   if (lane == 0 && !p.lost) {
     double s[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) s[k] = tot[k];
     ICP_STAMP(5);
-    go = hsk_solve6(s, x6);
+    go = hsk_solve6(s, x6) ? 1 : 0;
     if (!go) p.lost = 1;
     ICP_STAMP(6);
   }
-  const float a0 = __shfl(x6[0], 0, 64), a1 = __shfl(x6[1], 0, 64), a2 = __shfl(x6[2], 0, 64);
+  go = __builtin_amdgcn_readfirstlane(go);
+  p.lost = __builtin_amdgcn_readfirstlane(p.lost);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) x6[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x6[q])));
   double sd, cd;
-  hsk_sincos((double)(lane == 0 ? a0 : (lane == 1 ? a1 : a2)), &sd, &cd);
+  hsk_sincos((double)(lane == 0 ? x6[0] : (lane == 1 ? x6[1] : x6[2])), &sd, &cd);
   const float sf = (float)sd, cf = (float)cd;
-  const float sa = __shfl(sf, 0, 64), ca = __shfl(cf, 0, 64);
-  const float sb = __shfl(sf, 1, 64), cb = __shfl(cf, 1, 64);
-  const float sg = __shfl(sf, 2, 64), cg = __shfl(cf, 2, 64);
+  const float sa = lane_bcast(sf, 0), ca = lane_bcast(cf, 0);
+  const float sb = lane_bcast(sf, 1), cb = lane_bcast(cf, 1);
+  const float sg = lane_bcast(sf, 2), cg = lane_bcast(cf, 2);
   ICP_STAMP(7);
-  if (go) {
-    hsk_pose_update_sc(p.R, p.t, x6, sa, ca, sb, cb, sg, cg);
+  if (go) {  // wave-uniform
+    float rn[3], tn;
+    hsk_pose_update_row(lane < 3 ? lane : 2, p.R, p.t, x6, sa, ca, sb, cb, sg, cg, rn, &tn);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) p.R[r * 3 + j] = lane_bcast(rn[j], r);
+      p.t[r] = lane_bcast(tn, r);
+    }
     p.n_iter += 1;
   }
   ICP_STAMP(8);
