@@ -12,4 +12,6 @@ cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 grep -o '{"metric.*' $OUT/bench_profiled.log > $OUT/bench_profiled.json
 cd $ROOT && tools/pmc.sh gpurun_out/round/pmc > $OUT/pmc_summary.txt 2>&1
 cp $OUT/pmc/integrate_traffic.json $OUT/ 2>/dev/null
+# the raw per-dispatch CSVs exceed what gpurun copies back (64 MiB): only the summaries travel
+rm -rf $OUT/trace $OUT/pmc/p[0-9]*
 tail -5 $OUT/pmc_summary.txt
