@@ -48,10 +48,26 @@ struct VolParams {
 #define HSK_FLAG_WORDS_MAX 1024  // 4 KiB
 #endif
 // words of the brick bitfield; the brick edge is chosen (hsk_create) so that it fits HSK_FLAG_WORDS_MAX
-static inline int hsk_flag_words(const VolParams& vp) {
+__host__ __device__ static inline int hsk_flag_words(const VolParams& vp) {
   const long bits = (long)(vp.X >> vp.bshift) * (vp.Y >> vp.bshift) * ((vp.nzs + (1 << vp.bshift) - 1) >> vp.bshift);
   return (int)(((bits + 31) / 32 + 3) / 4 * 4);  // multiple of 4 words: staged into LDS with 16-B loads
 }
+// Behind the brick bitfield: one bit per SUPER-brick of (2^HSK_SUPER_SHIFT)^3 bricks ("one of my bricks has held a negative TSDF"),
+// the raycast's licence to cross such a block without looking at its steps.  Always HSK_SUPER_WORDS words (a multiple
+// of 4: staged with the same 16-B loads); a volume with more super-bricks than bits does not use it (hsk_super_ok).
+#ifndef HSK_SUPER_SHIFT
+#define HSK_SUPER_SHIFT 2  // log2 of the super-brick edge in bricks
+#endif
+#define HSK_SUPER_WORDS (HSK_SUPER_SHIFT == 2 ? 32 : 128)
+__host__ __device__ static inline int hsk_super_dim(int voxels, int bshift) {
+  return ((voxels >> bshift) + (1 << HSK_SUPER_SHIFT) - 1) >> HSK_SUPER_SHIFT;
+}
+__host__ __device__ static inline bool hsk_super_ok(const VolParams& vp) {
+  const int zb = (vp.nzs + (1 << vp.bshift) - 1) >> vp.bshift;
+  return (long)hsk_super_dim(vp.X, vp.bshift) * hsk_super_dim(vp.Y, vp.bshift) * ((zb + (1 << HSK_SUPER_SHIFT) - 1) >> HSK_SUPER_SHIFT) <=
+         HSK_SUPER_WORDS * 32;
+}
+__host__ __device__ static inline int hsk_flag_words_total(const VolParams& vp) { return hsk_flag_words(vp) + HSK_SUPER_WORDS; }
 
 // marching-tetrahedra lookup: per Kuhn tetrahedron and 4-bit inside mask, 0..2 triangles; each triangle corner is an
 // edge of the cube coded (low corner) | (high corner << 4)

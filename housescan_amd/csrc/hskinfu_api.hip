@@ -382,7 +382,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   while (hsk_flag_words(vp) > HSK_FLAG_WORDS_MAX && vp.bshift < 6 && ((vp.X >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.X &&
          ((vp.Y >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.Y)
     ++vp.bshift;
-  k->flags_bytes = (size_t)hsk_flag_words(vp) * 4;
+  k->flags_bytes = (size_t)hsk_flag_words_total(vp) * 4;  // brick bits + super-brick bits
   CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
   // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of the pass-A
   // blocks (64 x 16 voxels x 8 planes per block -> 512 lane-blocks); see launch_integrate

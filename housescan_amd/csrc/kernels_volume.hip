@@ -273,6 +273,21 @@ static __device__ __forceinline__ void classify_planes(int zz0, const bool* in_r
 
 static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]);
 
+// A voxel (x, y, stored plane zz) has just been given a negative TSDF: set its brick's bit and, the first time, its
+// super-brick's.  Test first: after the first frames the bits are already set and no atomic is issued (a stale read
+// only costs a redundant OR).
+static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict__ flags, const VolParams& vp, int x, int y, int zz) {
+  const int bs = vp.bshift, bxn = vp.X >> bs, byn = vp.Y >> bs;
+  const int bx = x >> bs, by = y >> bs, bz = zz >> bs;
+  const int bit = (bz * byn + by) * bxn + bx;
+  if ((flags[bit >> 5] >> (bit & 31)) & 1u) return;
+  __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (hsk_super_ok(vp)) {
+    const int sb = ((bz >> HSK_SUPER_SHIFT) * hsk_super_dim(vp.Y, bs) + (by >> HSK_SUPER_SHIFT)) * hsk_super_dim(vp.X, bs) + (bx >> HSK_SUPER_SHIFT);
+    __hip_atomic_fetch_or(&flags[hsk_flag_words(vp) + (sb >> 5)], 1u << (sb & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // All four voxels of the vector observed as free space (F == 1).  When all four already store +1 the running
 // mean leaves +1 ((1*W + 1) / (W + 1) == 1 exactly) and only the weights move: W <- min(W + 1, 128), done on the
 // packed words with one add and one min per voxel.  Otherwise the general update runs.
@@ -591,7 +606,6 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
   k.rk4 = k.zmin4 = k.cull_thr4 = k.free_thr4 = 0.0f;  // unused here
   const int qx = vp.X / 4;
   const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
-  const int bricks_x = vp.X >> vp.bshift, bricks_y = vp.Y >> vp.bshift;
   for (unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < n; e0 += stride) {  // wave-uniform trip count
     const unsigned e = e0 + lane;
     const bool have = e < n;
@@ -651,13 +665,7 @@ __global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(
         // saturated free space (+1 at the weight cap) comes back unchanged: no store
         if (q[u].x != before.x || q[u].y != before.y || q[u].z != before.z || q[u].w != before.w)
           vol[idx0 + (size_t)zz * plane_vec] = q[u];
-        if (neg) {
-          const int bit = (((zz >> vp.bshift) * bricks_y + (y >> vp.bshift)) * bricks_x + (x0 >> vp.bshift));
-          // test first: after the first frames the bit is already set and no atomic is issued (a stale read only
-          // costs a redundant OR)
-          if (!((flags[bit >> 5] >> (bit & 31)) & 1u))
-            __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (neg) mark_brick_negative(flags, vp, x0, y, zz);
       }
     }
   }
@@ -731,8 +739,7 @@ __global__ void k_rebuild_flags(const short2* __restrict__ vol, VolParams vp, un
   if (i >= n) return;
   if (vol[i].x < 0) {
     const int x = (int)(i % vp.X), y = (int)((i / vp.X) % vp.Y), zz = (int)(i / ((size_t)vp.X * vp.Y));
-    const int bit = ((zz >> vp.bshift) * (vp.Y >> vp.bshift) + (y >> vp.bshift)) * (vp.X >> vp.bshift) + (x >> vp.bshift);
-    __hip_atomic_fetch_or(&flags[bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mark_brick_negative(flags, vp, x, y, zz);
   }
 }
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags) {
@@ -847,11 +854,11 @@ static __device__ __forceinline__ void pyramid_step(const float* m, int dx, int 
 }
 
 #ifdef HSK_RC_TIMING
-__device__ unsigned long long g_rc_times[8192 * 4];
+__device__ unsigned long long g_rc_times[8192 * 6];  // per tile: 4 stamps, march trips, trips in which a lane gathered
 extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rc_times), (size_t)n * 8);
 }
-#define RC_STAMP(k) do { if (lane == 0 && tile_id < 8192) g_rc_times[tile_id * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RC_STAMP(k) do { if (lane == 0 && tile_id < 8192) g_rc_times[tile_id * 6 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RC_STAMP(k) do { } while (0)
 #endif
@@ -860,6 +867,12 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #endif                  // waves of a 640x480 frame spread evenly over the SIMDs.  Measured 512^3 / 1024^3 (us): 64 threads
                         // 99 / 124, 128: 107 / 126, 256: 99 / 131, 512: 107 / 142.  With 512-thread blocks and a 32 KiB
                         // bitfield 88 of the 256 CUs got a third block and the kernel waited for them (raycast_analysis.md).
+#ifndef RC_SKIP
+#define RC_SKIP 3      // fewest steps worth crossing at once inside a clear super-brick
+#endif
+#ifndef RC_GROUP
+#define RC_GROUP 4     // march steps located and gathered together (k_raycast)
+#endif
 #define RC_STAGE_MAX 4  // 16-B loads per thread: 4 KiB / (64 x 16 B); larger bitfields take the loop below
 template <bool SLAB>  // SLAB: this context stores / owns only part of the z range (multi-GPU)
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
@@ -878,7 +891,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   {
     // 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging loop cost 9 us per
     // block: profiles/r01/raycast_analysis.md)
-    const int nq = flag_words >> 2;  // flag_words is a multiple of 4 (hsk_flag_words)
+    const int nq = (flag_words + HSK_SUPER_WORDS) >> 2;  // brick bits + super-brick bits, both multiples of 4 words
     // (an indexed temporary array here was placed in scratch memory by the compiler: named registers instead)
     const uint4* __restrict__ src = (const uint4*)flags;
     uint4* dst = (uint4*)lflags;
@@ -991,37 +1004,150 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
       gz = (int)f2;
       return (unsigned)gx < (unsigned)vp.X && (unsigned)gy < (unsigned)vp.Y && (unsigned)gz < (unsigned)vp.Z;
     };
-    for (; time_curr < max_time; time_curr = time_curr + time_step, ++step) {
-      int gx, gy, gz;
-      if (!far_voxel(time_curr + time_step, gx, gy, gz)) break;
-      const int cxv = px, cyv = py, czv = pz;  // near sample of this step (inside the grid)
-      const bool was_first = first;
-      const unsigned fl_near = fl_prev;
-      const unsigned fl_far = flag_at(gx, gy, gz);
-      px = gx; py = gy; pz = gz;               // the far sample is the next step's near sample
-      first = false;
-      fl_prev = fl_far;
-      // an event needs a negative sample: skip the voxel gathers when neither brick ever held one, and (slab mode)
-      // when the step belongs to another slab
-      const bool owned = !SLAB || (gz >= vp.zo0 && gz < vp.zo1);
-      if (!(owned && (fl_near | fl_far))) continue;
-      const int raw_prev = raw_at(vol, vp, cxv, cyv, czv);
-      const int raw = raw_at(vol, vp, gx, gy, gz);
-      if (raw_prev < 0 && raw > 0) {  // back face
-        key = (step << 1) | 1;
-        break;
+#ifdef HSK_RC_TIMING
+    unsigned trips = 0, gtrips = 0;
+#endif
+    // The march advances RC_GROUP steps per trip.  A step that lies next to a flagged brick needs its two voxels, and a
+    // wave whose lanes reach such bricks at different steps used to stop for a memory round trip (~0.9 us under load) at
+    // every step in which ANY lane gathered (tools/rc_timing.sh: march time = 0.06 us x steps + 0.9 us x gather steps +
+    // 46 us of waiting for other lanes' gathers).  Here the far samples of the next RC_GROUP steps are located first
+    // (voxel + brick flag: arithmetic and LDS only), then every voxel any of those steps will compare is loaded in
+    // one batch -- the same voxels the step-by-step march reads, no others -- and the steps are then acted on in order
+    // with the values in registers: one round trip per RC_GROUP steps instead of up to RC_GROUP.  Same decisions, same
+    // ray parameters ((time_curr + time_step) + time_step ...), so the maps are bit-identical.
+    bool ended = false;
+    // Crossing clear super-bricks: when the near sample of EVERY marching lane of the wave sits in a super-brick (4^3
+    // bricks) none of whose bricks has held a negative TSDF, and every lane's ray stays inside its super-brick for the
+    // next RC_SKIP steps with two steps to spare, none of those steps can gather or end -- their only effect is to
+    // advance time_curr and step.  So the wave advances them by the same float additions and looks up the new near
+    // sample once.  The decision is wave-wide (the 64 rays of an 8x8 tile are a few centimetres apart, so they cross the
+    // same super-bricks together; per-lane skipping made every trip pay for both paths: raycast_analysis.md).
+    const bool can_skip = !SLAB && hsk_super_ok(vp);
+    const int ss = bs + HSK_SUPER_SHIFT, sxn = hsk_super_dim(vp.X, bs), syn = hsk_super_dim(vp.Y, bs);
+    const float s_edge0 = (float)(1 << ss) * vp.cell[0], s_edge1 = (float)(1 << ss) * vp.cell[1], s_edge2 = (float)(1 << ss) * vp.cell[2];
+    const float id0 = 1.0f / d0, id1 = 1.0f / d1, id2 = 1.0f / d2;
+    const float inv_step = 1.0f / time_step;
+    // (a wave-wide loop: lanes whose ray has ended idle inside it, so that the wave-wide minimum below can use shuffles)
+    while (__ballot(!ended && time_curr < max_time) != 0ull) {
+      const bool act = !ended && time_curr < max_time;
+      if (can_skip) {
+        const int s0 = px >> ss, s1 = py >> ss, s2 = pz >> ss;
+        const int sbit = (s2 * syn + s1) * sxn + s0;
+        const bool clear = !((lflags[flag_words + (sbit >> 5)] >> (sbit & 31)) & 1u);
+        // ray parameter at which the ray leaves the super-brick (approximate; two spare steps absorb the error)
+        const float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * s_edge0 - t0) * id0;
+        const float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * s_edge1 - t1) * id1;
+        const float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * s_edge2 - t2) * id2;
+        const float room = (fminf(fminf(e0, e1), e2) - time_curr) * inv_step - 2.0f;
+        int n = !act ? 0x7fffffff : ((clear && room >= 1.0f) ? (int)fminf(room, 64.0f) : 0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n = min(n, __shfl_xor(n, o, 64));
+        if (n >= RC_SKIP && n != 0x7fffffff) {  // wave-uniform
+          float tc = time_curr;
+          for (int i = 0; i < n; ++i) tc = tc + time_step;
+          int nx_, ny_, nz_;
+          const bool fine = !act || (far_voxel(tc, nx_, ny_, nz_) && tc < max_time);
+          if (__ballot(!fine) == 0ull) {
+            if (act) {
+              time_curr = tc;
+              step += n;
+              px = nx_; py = ny_; pz = nz_;
+              first = false;
+              fl_prev = flag_at(px, py, pz);
+            }
+            continue;
+          }
+        }
       }
-      if (raw_prev > 0 && raw < 0) {  // zero crossing: leave the loop, refine below with every lane of the wave
-        crossing = true;
-        nux = was_first ? qx : cxv;
-        nuy = was_first ? qy : cyv;
-        nuz = was_first ? qz : czv;
-        break;
+      if (!act) continue;
+      float tt[RC_GROUP];
+      int vx_[RC_GROUP], vy_[RC_GROUP], vz_[RC_GROUP];
+      bool okv[RC_GROUP], need[RC_GROUP];
+      unsigned fl[RC_GROUP];
+      {
+        float tc = time_curr;
+        bool alive = true;
+        unsigned fprev = fl_prev;
+#pragma unroll
+        for (int g = 0; g < RC_GROUP; ++g) {
+          alive = alive && (tc < max_time);
+          tt[g] = tc + time_step;
+          okv[g] = far_voxel(tt[g], vx_[g], vy_[g], vz_[g]);
+          alive = alive && okv[g];
+          fl[g] = alive ? flag_at(vx_[g], vy_[g], vz_[g]) : 0u;
+          const bool owned = !SLAB || (vz_[g] >= vp.zo0 && vz_[g] < vp.zo1);
+          need[g] = alive && owned && ((fprev | fl[g]) != 0u);
+          fprev = fl[g];
+          tc = tt[g];
+        }
+      }
+      int raw[RC_GROUP + 1];  // raw[0]: the near sample of the first step; raw[g + 1]: the far sample of step g
+#pragma unroll
+      for (int g = 0; g <= RC_GROUP; ++g) raw[g] = 0;
+      bool any_need = false;
+#pragma unroll
+      for (int g = 0; g < RC_GROUP; ++g) any_need = any_need || need[g];
+      if (any_need) {
+        if (need[0]) raw[0] = raw_at(vol, vp, px, py, pz);
+#pragma unroll
+        for (int g = 0; g < RC_GROUP; ++g)
+          if (need[g] || (g + 1 < RC_GROUP && need[g + 1])) raw[g + 1] = raw_at(vol, vp, vx_[g], vy_[g], vz_[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < RC_GROUP; ++g) {
+        if (ended || !(time_curr < max_time)) break;
+#ifdef HSK_RC_TIMING
+        ++trips;
+#endif
+        if (!okv[g]) {
+          ended = true;
+          break;
+        }
+        const int cxv = px, cyv = py, czv = pz;  // near sample of this step (inside the grid)
+        const bool was_first = first;
+        px = vx_[g]; py = vy_[g]; pz = vz_[g];   // the far sample is the next step's near sample
+        first = false;
+        fl_prev = fl[g];
+        if (need[g]) {
+#ifdef HSK_RC_TIMING
+          ++gtrips;
+#endif
+          const int raw_prev = raw[g], raw_far = raw[g + 1];
+          if (raw_prev < 0 && raw_far > 0) {  // back face
+            key = (step << 1) | 1;
+            ended = true;
+            break;
+          }
+          if (raw_prev > 0 && raw_far < 0) {  // zero crossing: refined below with every lane of the wave
+            crossing = true;
+            nux = was_first ? qx : cxv;
+            nuy = was_first ? qy : cyv;
+            nuz = was_first ? qz : czv;
+            ended = true;
+            break;
+          }
+        }
+        time_curr = tt[g];
+        ++step;
       }
     }
     // Deferred hit processing: lanes hit at different steps, and refining inside the loop would run these
     // (memory-latency-bound) taps once per distinct step.  Here the wave runs them once, loads batched.
     RC_STAMP(2);
+#ifdef HSK_RC_TIMING
+    {
+      // wave totals: the longest lane's trips, and the number of lanes-trips with gathers (max over lanes)
+      unsigned tmax = trips, gmax = gtrips;
+      for (int o = 32; o > 0; o >>= 1) {
+        tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o, 64));
+        gmax = max(gmax, (unsigned)__shfl_xor((int)gmax, o, 64));
+      }
+      if (lane == 0 && tile_id < 8192) {
+        g_rc_times[tile_id * 6 + 4] = tmax;
+        g_rc_times[tile_id * 6 + 5] = gmax;
+      }
+    }
+#endif
     if (crossing) {
       key = (step << 1) | 1;
       const float tn = time_curr + time_step;
@@ -1089,10 +1215,10 @@ void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const 
   const MapPyramid none = {nullptr, nullptr, nullptr, nullptr};
   const RingOut quiet = {nullptr, nullptr, nullptr};
   if (slab)
-    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
+    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
                        keys, flags, words, none, quiet);
   else
-    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)words * 4, s, (const short2*)vol, st, vp, W, H, in, vmap,
+    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, (const short2*)vol, st, vp, W, H, in, vmap,
                        nmap, keys, flags, words, pyramid ? *pyramid : none, ring ? *ring : quiet);
 }
 // the fused pyramid needs complete 8x8 tiles and a single-device volume

@@ -11,9 +11,10 @@ trk = hsk.KinfuTracker(n=int(sys.argv[1]) if len(sys.argv) > 1 else 512, use_gra
 for k in range(40):
     trk.process_frame(hsk.synth_depth(hsk.synth_pose(k)))
 lib = C.CDLL(_lib.LIB_PATH)
-t = np.zeros((4800, 4), np.uint64)
-rc = lib.hsk_debug_rc_times(C.c_void_p(t.ctypes.data), 4800 * 4)
-t = t.astype(np.float64) / 100.0   # s_memrealtime ticks at 100 MHz -> us
+t = np.zeros((4800, 6), np.uint64)
+rc = lib.hsk_debug_rc_times(C.c_void_p(t.ctypes.data), 4800 * 6)
+trips, gtrips = t[:, 4].astype(np.int64), t[:, 5].astype(np.int64)
+t = t[:, :4].astype(np.float64) / 100.0   # s_memrealtime ticks at 100 MHz -> us
 t0 = t[:, 0].min()
 stage, march, refine, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
 print("rc", rc, "span", t[:, 3].max() - t0, "first start spread", (t[:, 0] - t0).max())
@@ -21,4 +22,12 @@ for name, v in (("staging", stage), ("march", march), ("refine", refine), ("life
     print(f"{name:8s} mean {v.mean():6.1f}  p50 {np.percentile(v, 50):6.1f}  p90 {np.percentile(v, 90):6.1f}  p99 {np.percentile(v, 99):6.1f}  max {v.max():6.1f}")
 order = np.argsort(-(t[:, 3] - t0))[:12]
 for i in order:
-    print("tile", i, "xy", (i % 80) * 8, (i // 80) * 8, "start %.1f stage %.1f march %.1f refine %.1f end %.1f" % (t[i, 0] - t0, stage[i], march[i], refine[i], t[i, 3] - t0))
+    print("trips %4d gather-trips %4d us/trip %.3f |" % (trips[i], gtrips[i], march[i] / max(1, trips[i])), "tile", i, "xy", (i % 80) * 8, (i // 80) * 8, "start %.1f stage %.1f march %.1f refine %.1f end %.1f" % (t[i, 0] - t0, stage[i], march[i], refine[i], t[i, 3] - t0))
+
+print("trips: mean %.0f p50 %.0f p90 %.0f max %d; gather-trips mean %.0f max %d" % (trips.mean(), np.percentile(trips, 50), np.percentile(trips, 90), trips.max(), gtrips.mean(), gtrips.max()))
+# march time against trips: least squares us = a * trips + b * gather_trips
+A = np.stack([trips, gtrips, np.ones_like(trips)], axis=1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, march, rcond=None)
+print("march us ~ %.3f * trips + %.3f * gather_trips + %.1f" % tuple(coef))
+late = t[:, 2] - t0 > 70
+print("waves whose march ends after 70 us: %d, their trips mean %.0f gather-trips mean %.0f" % (late.sum(), trips[late].mean() if late.any() else 0, gtrips[late].mean() if late.any() else 0))
