@@ -929,6 +929,24 @@ static __device__ __forceinline__ void shard_reduce27(const double* __restrict__
   __syncthreads();
 }
 
+// The same totals gathered by ONE wave (the one that solves): lane l adds 16 of the 32 shards of sum l & 31, one lane
+// swap joins the halves, lanes 0..26 leave the totals in tot[].  No block barrier, no second LDS stage -- the other
+// waves of the block have nothing to do before the pose is known anyway.  (Any order of addition gives the same bits.)
+static __device__ __forceinline__ void shard_reduce27_wave(const double* __restrict__ slot, double* tot) {
+  const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5;
+  double a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = slot[(half * 16 + j) * 32 + k];
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int j = 0; j < w; ++j) a[j] = a[j] + a[j + w];
+  const double v = swap32_add_f64(a[0], a[0]);  // every lane: its half + the other half
+  if (lane < 27) tot[lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // block sums -> one f64 atomic add per sum into this block's shard
 static __device__ __forceinline__ void icp_block_sums_atomic(const double* acc, double (*sh)[32], double* __restrict__ slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -998,9 +1016,9 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   double* __restrict__ slot_clear = slots + (size_t)((iter + 1) % 3) * ICP_SLOT_DOUBLES;
   for (int i = blockIdx.x * ICP_BLOCK + threadIdx.x; i < ICP_SLOT_DOUBLES; i += gridDim.x * ICP_BLOCK)
     __hip_atomic_store(slot_clear + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (iter > 0) shard_reduce27(slot_read, sh, tot);
-  ICP_STAMP(1);
   if (threadIdx.x < 64) {  // the first wave (icp_solve_step shares the work among its lanes)
+    if (iter > 0) shard_reduce27_wave(slot_read, tot);
+    ICP_STAMP(1);
     IcpPose p = p_in;
     if (iter > 0) icp_solve_step(tot, p, iter);
     if (threadIdx.x == 0) {
