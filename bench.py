@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2; the API allows 3 in flight)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
     ap.add_argument("--slab-graph", type=int, default=0, help="replay the z-slab frame front from a hipGraph (default: eager)")
@@ -142,13 +143,16 @@ def main():
     t0 = time.perf_counter()
     if use_async:
         # hsk_submit_frame_dev / hsk_wait_frame: frame i+1 is enqueued before the pose of frame i is read back
-        trk.submit_frame_dev(dev_frames[1 + Wm].data_ptr())
-        for i in range(2 + Wm, total):
+        ahead = max(1, min(args.ahead, 2, K - 1))
+        for i in range(1 + Wm, 1 + Wm + ahead):
+            trk.submit_frame_dev(dev_frames[i].data_ptr())
+        for i in range(1 + Wm + ahead, total):
             trk.submit_frame_dev(dev_frames[i].data_ptr())
             pose, ok = trk.wait_frame()
             lost += (not ok)
-        pose, ok = trk.wait_frame()
-        lost += (not ok)
+        for _ in range(ahead):
+            pose, ok = trk.wait_frame()
+            lost += (not ok)
     elif (world > 1 or args.force_sharded) and args.mode == "slab" and args.icp == "replicated" and not args.sync_api:
         # pipelined slab frames: frame i + 1 (with its collectives) is enqueued before the pose of frame i is read;
         # the next frame is named so that its preprocessing overlaps on the second stream
@@ -190,7 +194,7 @@ def main():
                    "volume": n, "image": [640, 480], "icp_iters": [10, 5, 4],
                    "parallelism": ("1 gpu" if world == 1 else f"{args.mode}{world}" + (f"-icp-{args.icp}" if args.mode == "slab" else "")),
                    "graph": bool(args.graph), **({"check_only": "all ranks share device 0 over %s" % args.backend} if args.share_gpu else {}),
-                   "api": "submit/wait (1 frame in flight ahead)" if (use_async or ((world > 1 or args.force_sharded) and args.mode == "slab"
+                   "api": ("submit/wait (%d frame(s) in flight ahead)" % (max(1, min(args.ahead, 2)) if use_async else 1)) if (use_async or ((world > 1 or args.force_sharded) and args.mode == "slab"
                                                                                     and args.icp == "replicated" and not args.sync_api))
                    else "process_frame (sync per frame)"},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3),
