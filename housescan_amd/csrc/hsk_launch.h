@@ -1,11 +1,12 @@
 // hsk_launch.h -- launcher prototypes shared between the kernel translation units and the C-ABI layer.
 #pragma once
 #include "hsk_dev.h"
+#include "hsk_icp_dev.h"
 
 // volume
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax, int2* zint, unsigned* queue);
+                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr);
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);
@@ -42,7 +43,7 @@ void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf);
 size_t icp_pose_bytes();
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
-                      void* pose_buf, double* part_a, double* part_b);
+                      void* pose_buf, double* part_a, double* part_b, IcpFinal* defer_final = nullptr);
 bool host_solve6(const double* in27, float* x6);
 void host_pose_update(float* R, float* t, const float* x6);
 void hsk_build_tet_table(TetTable* tt);

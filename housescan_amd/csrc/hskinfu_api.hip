@@ -458,14 +458,17 @@ static void enqueue_preprocess(hsk_ctx* k, hipStream_t s) {
   launch_vmap_nmap_pyramid(s, k->B().d_dep, k->lv, k->B().d_vcur, k->B().d_ncur);
 }
 
-static void enqueue_icp(hsk_ctx* k) {
+// fin: leave the frame's last solve to the integrate that the caller enqueues next with the same descriptor (its first
+// kernel does it in its prologue: one launch less); only where that integrate always follows
+static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
+  if (fin) *fin = IcpFinal{nullptr, nullptr, 0};
   launch_icp_fused(k->stream, k->B().d_vcur, k->B().d_ncur, k->d_vmod, k->d_nmod, k->lv, k->cfg.icp_iters, k->d_st,
-                   k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2);
+                   k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2, fin);
 }
 
-static void enqueue_integrate(hsk_ctx* k) {
+static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr) {
   launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
-                   k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue);
+                   k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue, (fin && fin->slots) ? fin : nullptr);
 }
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys, bool report = false) {
@@ -517,8 +520,9 @@ static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
 
 // everything after the preprocessing of a tracked frame, on the main stream, for the buffer set k->cur
 static void enqueue_tracked_rest(hsk_ctx* k) {
-  enqueue_icp(k);  // its first iteration also starts the frame (previous pose <- pose, lost flag)
-  enqueue_integrate(k);
+  IcpFinal fin;
+  enqueue_icp(k, &fin);  // its first iteration also starts the frame (previous pose <- pose, lost flag)
+  enqueue_integrate(k, &fin);  // ... and its last solve happens in the first kernel of the integrate
   enqueue_raycast_and_resize(k, nullptr, true);  // pipelined frames report their state through the ring
 }
 

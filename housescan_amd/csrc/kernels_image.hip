@@ -347,6 +347,17 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
 // ------------------------------------------------------------------------------------------------------
 // ICP_PX pixels per lane (template): loads batched so that the dependent chain is 2 memory round trips
 #ifndef ICP_BLOCK
+#ifdef HSK_ICP_TIMING
+// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration
+__device__ unsigned long long g_icp_times[20 * 256 * 10];
+extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
+}
+#define ICP_STAMP(k) do { if (threadIdx.x == 0 && g_icp_iter < 20 && blockIdx.x < 256) g_icp_times[(g_icp_iter * 256 + blockIdx.x) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ICP_STAMP(k) do { } while (0)
+#endif
+#include "hsk_icp_dev.h"
 #define ICP_BLOCK 256
 #endif
 #define ICP_SH_ROWS ((ICP_BLOCK / 64) > 8 ? (ICP_BLOCK / 64) : 8)  // LDS rows: one per wave, at least the 8 slices of the shard reduction
@@ -371,14 +382,6 @@ static __device__ __forceinline__ double dpp_mov_f64(double v) {
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
-}
-// gfx950 lane swaps of a 64-bit pair: v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31
-// of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second -- one VALU
-// instruction per 32-bit half moves BOTH directions of a butterfly step (no selects, no trip through the LDS crossbar).
-static __device__ __forceinline__ double swap32_add_f64(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 static __device__ __forceinline__ double swap16_add_f64(double a, double b) {
   const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
@@ -660,136 +663,6 @@ void launch_icp_reduce(hipStream_t s, const double* partials, int nblocks, doubl
   hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(256), 0, s, partials, nblocks, out27);
 }
 
-// ---- 6x6 solve + pose update, shared by the device kernel and the host mirror (hsk_icp_solve) ----
-__host__ __device__ static inline void hsk_sincos(double x, double* s, double* c) {
-  if (!(fabs(x) < 1.0e5)) {
-    *s = 0.0;
-    *c = 1.0;
-    return;
-  }
-  const double two_over_pi = 0.63661977236758134308;
-  const double pio2_hi = 1.57079632673412561417e+00;
-  const double pio2_lo = 6.07710050650619224932e-11;
-  const double kf = rint(x * two_over_pi);
-  const double r = (x - kf * pio2_hi) - kf * pio2_lo;
-  const double r2 = r * r;
-  double S = -1.0 / 1307674368000.0;
-  S = S * r2 + 1.0 / 6227020800.0;
-  S = S * r2 - 1.0 / 39916800.0;
-  S = S * r2 + 1.0 / 362880.0;
-  S = S * r2 - 1.0 / 5040.0;
-  S = S * r2 + 1.0 / 120.0;
-  S = S * r2 - 1.0 / 6.0;
-  const double sr = r + (r * r2) * S;
-  double C = 1.0 / 20922789888000.0;
-  C = C * r2 - 1.0 / 87178291200.0;
-  C = C * r2 + 1.0 / 479001600.0;
-  C = C * r2 - 1.0 / 3628800.0;
-  C = C * r2 + 1.0 / 40320.0;
-  C = C * r2 - 1.0 / 720.0;
-  C = C * r2 + 1.0 / 24.0;
-  const double cr = (1.0 - 0.5 * r2) + (r2 * r2) * C;
-  const int q = ((int)kf) & 3;
-  if (q == 0) {
-    *s = sr;
-    *c = cr;
-  } else if (q == 1) {
-    *s = cr;
-    *c = -sr;
-  } else if (q == 2) {
-    *s = -sr;
-    *c = -cr;
-  } else {
-    *s = -cr;
-    *c = sr;
-  }
-}
-
-__host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6) {
-  double A[6][6], b[6], L[6][6], D[6];
-  int k = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 7; ++j) {
-      const double v = in27[k++];
-      if (j == 6)
-        b[i] = v;
-      else {
-        A[i][j] = v;
-        A[j][i] = v;
-      }
-    }
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
-  // LDL^T (unit lower L, diagonal D) with one reciprocal per pivot: no square roots on the dependent chain
-  double det = 1.0;
-  double dinv[6];
-  for (int j = 0; j < 6; ++j) {
-    double dj = A[j][j];
-    for (int q = 0; q < j; ++q) dj = dj - (L[j][q] * L[j][q]) * D[q];
-    if (!(dj > 0.0)) return false;
-    D[j] = dj;
-    dinv[j] = 1.0 / dj;
-    det = det * dj;
-    for (int i = j + 1; i < 6; ++i) {
-      double r = A[i][j];
-      for (int q = 0; q < j; ++q) r = r - (L[i][q] * L[j][q]) * D[q];
-      L[i][j] = r * dinv[j];
-    }
-  }
-  if (!(det >= 1e-15)) return false;
-  double yv[6], xv[6];
-  for (int i = 0; i < 6; ++i) {  // L y = b
-    double r = b[i];
-    for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
-    yv[i] = r;
-  }
-  for (int i = 5; i >= 0; --i) {  // L^T x = D^-1 y
-    double r = yv[i] * dinv[i];
-    for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
-    xv[i] = r;
-  }
-  for (int q = 0; q < 6; ++q) {
-    if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) return false;
-    x6[q] = (float)xv[q];
-  }
-  return true;
-}
-
-__host__ __device__ static inline void hsk_mat3mul(const float* A, const float* B, float* O) {
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) O[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
-}
-
-// pose refinement from the solved increment, given the sines and cosines of its three angles
-__host__ __device__ static inline void hsk_pose_update_sc(float* R, float* t, const float* x6, float sa, float ca, float sb,
-                                                          float cb, float sg, float cg) {
-  const float Rx[9] = {1.0f, 0.0f, 0.0f, 0.0f, ca, -sa, 0.0f, sa, ca};
-  const float Ry[9] = {cb, 0.0f, sb, 0.0f, 1.0f, 0.0f, -sb, 0.0f, cb};
-  const float Rz[9] = {cg, -sg, 0.0f, sg, cg, 0.0f, 0.0f, 0.0f, 1.0f};
-  float Rzy[9], Rinc[9], Rn[9];
-  hsk_mat3mul(Rz, Ry, Rzy);
-  hsk_mat3mul(Rzy, Rx, Rinc);
-  const float n0 = ((Rinc[0] * t[0] + Rinc[1] * t[1]) + Rinc[2] * t[2]) + x6[3];
-  const float n1 = ((Rinc[3] * t[0] + Rinc[4] * t[1]) + Rinc[5] * t[2]) + x6[4];
-  const float n2 = ((Rinc[6] * t[0] + Rinc[7] * t[1]) + Rinc[8] * t[2]) + x6[5];
-  t[0] = n0;
-  t[1] = n1;
-  t[2] = n2;
-  hsk_mat3mul(Rinc, R, Rn);
-  for (int i = 0; i < 9; ++i) R[i] = Rn[i];
-}
-
-__host__ __device__ static inline void hsk_pose_update(float* R, float* t, const float* x6) {
-  double sd, cd;
-  hsk_sincos((double)x6[0], &sd, &cd);
-  const float sa = (float)sd, ca = (float)cd;
-  hsk_sincos((double)x6[1], &sd, &cd);
-  const float sb = (float)sd, cb = (float)cd;
-  hsk_sincos((double)x6[2], &sd, &cd);
-  const float sg = (float)sd, cg = (float)cd;
-  hsk_pose_update_sc(R, t, x6, sa, ca, sb, cb, sg, cg);
-}
-
 // single-lane kernel: solve the reduced system and refine the pose held in TrackState
 __global__ void k_icp_update(const double* __restrict__ sums27, TrackState* __restrict__ st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -821,95 +694,7 @@ void launch_icp_update(hipStream_t s, const double* sums27, TrackState* st) {
 // same deterministic arithmetic in every block, so all blocks agree -- then accumulates its pixels with the new
 // pose.  One launch per iteration instead of two; the current-map loads are issued before the prologue so their
 // latency overlaps the solve.  Poses ping-pong through two IcpPose slots (block 0 publishes the new one).
-struct IcpPose {
-  float R[9], t[3];
-  int lost, n_iter, pad[2];
-};
 
-#ifdef HSK_ICP_TIMING
-// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration
-__device__ unsigned long long g_icp_times[20 * 256 * 10];
-extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
-}
-#define ICP_STAMP(k) do { if (threadIdx.x == 0 && g_icp_iter < 20 && blockIdx.x < 256) g_icp_times[(g_icp_iter * 256 + blockIdx.x) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ICP_STAMP(k) do { } while (0)
-#endif
-
-static __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
-}
-// Row `i` of hsk_pose_update_sc: the same expressions in the same order, element by element (the three 3x3 products
-// are row-separable), so three lanes produce the rows of the new rotation and translation with the bits one lane would.
-static __device__ __forceinline__ void hsk_pose_update_row(int i, const float* R, const float* t, const float* x6, float sa,
-                                                           float ca, float sb, float cb, float sg, float cg, float* rn,
-                                                           float* tn) {
-  const float z0 = i == 0 ? cg : (i == 1 ? sg : 0.0f), z1 = i == 0 ? -sg : (i == 1 ? cg : 0.0f), z2 = i == 2 ? 1.0f : 0.0f;
-  const float Ry[9] = {cb, 0.0f, sb, 0.0f, 1.0f, 0.0f, -sb, 0.0f, cb};
-  const float Rx[9] = {1.0f, 0.0f, 0.0f, 0.0f, ca, -sa, 0.0f, sa, ca};
-  float zy[3], inc[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) zy[j] = (z0 * Ry[j] + z1 * Ry[3 + j]) + z2 * Ry[6 + j];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) inc[j] = (zy[0] * Rx[j] + zy[1] * Rx[3 + j]) + zy[2] * Rx[6 + j];
-  const float xi = i == 0 ? x6[3] : (i == 1 ? x6[4] : x6[5]);
-  *tn = ((inc[0] * t[0] + inc[1] * t[1]) + inc[2] * t[2]) + xi;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) rn[j] = (inc[0] * R[j] + inc[1] * R[3 + j]) + inc[2] * R[6 + j];
-}
-
-// Executed by the whole first wave: lane 0 solves; lanes 0..2 evaluate one sine/cosine pair each (the three polynomial
-// evaluations are the longest serial piece after the factorisation) and then one row each of the pose update (three
-// 3x3 products on one lane were 150 dependent instructions); the rows are broadcast, so every lane of the wave
-// leaves with the whole new pose.
-static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p, int g_icp_iter = 99) {
-  (void)g_icp_iter;  // only the timing build's stamps use it
-  const int lane = threadIdx.x & 63;
-  float x6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  int go = 0;
-  if (lane == 0 && !p.lost) {
-    double s[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) s[k] = tot[k];
-    ICP_STAMP(5);
-    go = hsk_solve6(s, x6) ? 1 : 0;
-    if (!go) p.lost = 1;
-    ICP_STAMP(6);
-  }
-  go = __builtin_amdgcn_readfirstlane(go);
-  p.lost = __builtin_amdgcn_readfirstlane(p.lost);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) x6[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x6[q])));
-  double sd, cd;
-  hsk_sincos((double)(lane == 0 ? x6[0] : (lane == 1 ? x6[1] : x6[2])), &sd, &cd);
-  const float sf = (float)sd, cf = (float)cd;
-  const float sa = lane_bcast(sf, 0), ca = lane_bcast(cf, 0);
-  const float sb = lane_bcast(sf, 1), cb = lane_bcast(cf, 1);
-  const float sg = lane_bcast(sf, 2), cg = lane_bcast(cf, 2);
-  ICP_STAMP(7);
-  if (go) {  // wave-uniform
-    float rn[3], tn;
-    hsk_pose_update_row(lane < 3 ? lane : 2, p.R, p.t, x6, sa, ca, sb, cb, sg, cg, rn, &tn);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) p.R[r * 3 + j] = lane_bcast(rn[j], r);
-      p.t[r] = lane_bcast(tn, r);
-    }
-    p.n_iter += 1;
-  }
-  ICP_STAMP(8);
-}
-
-// The 27 sums travel between launches through sharded accumulators instead of per-block partial rows: the
-// products are integer multiples of 2^-26 (exact in binary64), so hardware f64 atomic adds give the same bits in
-// any arrival order, and the next launch reads ICP_SHARDS x 27 doubles instead of (blocks) x 27 (19 MB of L2 reads
-// per fine iteration before).  Three slots rotate: iteration i adds into slot i % 3, reads slot (i - 1) % 3 and
-// clears slot (i + 1) % 3 for its successor; slot 0 is empty at the start of a frame (cleared at creation and by
-// k_icp_final).
-#define ICP_SHARDS 32
-#define ICP_SLOT_DOUBLES (ICP_SHARDS * 32)
 static __device__ __forceinline__ void shard_reduce27(const double* __restrict__ slot, double (*sh)[32], double* tot) {
   const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 slices x 4 shards each
   double v = 0.0;
@@ -927,24 +712,6 @@ static __device__ __forceinline__ void shard_reduce27(const double* __restrict__
     tot[threadIdx.x] = r;
   }
   __syncthreads();
-}
-
-// The same totals gathered by ONE wave (the one that solves): lane l adds 16 of the 32 shards of sum l & 31, one lane
-// swap joins the halves, lanes 0..26 leave the totals in tot[].  No block barrier, no second LDS stage -- the other
-// waves of the block have nothing to do before the pose is known anyway.  (Any order of addition gives the same bits.)
-static __device__ __forceinline__ void shard_reduce27_wave(const double* __restrict__ slot, double* tot) {
-  const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5;
-  double a[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) a[j] = slot[(half * 16 + j) * 32 + k];
-#pragma unroll
-  for (int w = 8; w > 0; w >>= 1)
-#pragma unroll
-    for (int j = 0; j < w; ++j) a[j] = a[j] + a[j + w];
-  const double v = swap32_add_f64(a[0], a[0]);  // every lane: its half + the other half
-  if (lane < 27) tot[lane] = v;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
 }
 
 // block sums -> one f64 atomic add per sum into this block's shard
@@ -1071,7 +838,7 @@ static inline double* icp_slots(void* pose_buf) { return (double*)((char*)pose_b
 // enqueue the whole ICP of one frame: levels coarse -> fine, iters[l] iterations each
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
-                      void* pose_buf, double* part_a, double* part_b) {
+                      void* pose_buf, double* part_a, double* part_b, IcpFinal* defer_final) {
   (void)part_a;
   (void)part_b;
   static_assert(2 * sizeof(IcpPose) <= ICP_POSE_AREA, "pose ping-pong must fit its area");
@@ -1094,7 +861,13 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
                            lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
     }
   }
-  if (i > 0)
+  if (i > 0 && defer_final) {
+    // the caller's next launch (k_column_zrange, first kernel of integrate) does the last solve in its prologue: one
+    // launch and one kernel boundary less per frame
+    defer_final->pose_in = pb + (i & 1);
+    defer_final->slots = slots;
+    defer_final->iter = i;
+  } else if (i > 0)
     hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(256), 0, s, pb + (i & 1), slots, i, st);
   else
     launch_begin_frame(s, st, nullptr);  // no iteration configured: the frame still starts (previous pose, lost flag)

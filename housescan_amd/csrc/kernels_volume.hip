@@ -99,7 +99,35 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
                                 int2* __restrict__ zint, int dil_blocks, const float* __restrict__ tmax,
                                 const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th,
-                                unsigned* __restrict__ qcount) {
+                                unsigned* __restrict__ qcount, IcpFinal fin, TrackState* __restrict__ st_out) {
+  // fin.slots != null: the frame's ICP has left its last solve to this launch (launch_icp_fused).  The first wave of
+  // EVERY block reads the sharded sums of the last iteration and solves (deterministic: all blocks get the same pose),
+  // the block then works with that pose; block 0 also publishes it -- what k_icp_final does in a launch of its own.
+  // (Slot 0 of the accumulators, read here by all blocks, is emptied for the next frame by pass A's first block.)
+  __shared__ double fin_tot[27];
+  __shared__ IcpPose fin_pose;
+  if (fin.slots) {
+    if (threadIdx.x < 64) {
+      shard_reduce27_wave(fin.slots + (size_t)((fin.iter + 2) % 3) * ICP_SLOT_DOUBLES, fin_tot);
+      IcpPose p = *fin.pose_in;
+      icp_solve_step(fin_tot, p);
+      if (threadIdx.x == 0) {
+        fin_pose = p;
+        if (blockIdx.x == 0) {
+          for (int k = 0; k < 27; ++k) st_out->sums[k] = fin_tot[k];
+          if (p.lost) {
+            st_out->lost = 1;
+            st_out->need_reset = 1;
+          } else {
+            for (int i = 0; i < 9; ++i) st_out->R[i] = p.R[i];
+            for (int i = 0; i < 3; ++i) st_out->t[i] = p.t[i];
+          }
+          st_out->n_iter = p.n_iter;
+        }
+      }
+    }
+    __syncthreads();
+  }
   // The first blocks also dilate the tile table and clear the queue counters of pass A (no extra launch, memset node or
   // extra blocks: at 512^3 the column work alone is exactly one block per CU).
   {
@@ -122,10 +150,14 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
   const int ncol = vp.X / 4;
   if (c >= ncol * vp.Y) return;
   const int y = c / ncol, x0 = (c - y * ncol) * 4;
-  const float tx = st->t[0], ty = st->t[1], tz = st->t[2];
-  const float i00 = st->R[0], i01 = st->R[3], i02 = st->R[6];
-  const float i10 = st->R[1], i11 = st->R[4], i12 = st->R[7];
-  const float i20 = st->R[2], i21 = st->R[5], i22 = st->R[8];
+  // (a lost frame keeps the previous pose in st; the solve's own estimate is then meaningless, and nothing integrates)
+  const bool own = fin.slots != nullptr && !fin_pose.lost;
+  const float* __restrict__ Rm = own ? fin_pose.R : st->R;
+  const float* __restrict__ tm = own ? fin_pose.t : st->t;
+  const float tx = tm[0], ty = tm[1], tz = tm[2];
+  const float i00 = Rm[0], i01 = Rm[3], i02 = Rm[6];
+  const float i10 = Rm[1], i11 = Rm[4], i12 = Rm[7];
+  const float i20 = Rm[2], i21 = Rm[5], i22 = Rm[8];
   const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
   float glo = 1e30f, ghi = -1e30f;
 #pragma unroll
@@ -362,7 +394,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
                                                    unsigned* __restrict__ flags, const float2* __restrict__ dtab,
                                                    int tw, int th, const int2* __restrict__ zint,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
-                                                   unsigned qcap, const float2* __restrict__ ftab, int fw, int fh) {
+                                                   unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
+                                                   double* __restrict__ icp_slot0) {
+  // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
+  // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
+  if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.y * 64 + threadIdx.x; i < ICP_SLOT_DOUBLES; i += 256)
+      __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // dtab: per 16x16-pixel tile (max, min-if-all-valid) of the scaled depth, 3x3-dilated.  It is 9.6 KB and stays
   // hot in every CU's vector L1; staging it in LDS per workgroup cost ~2.5 us of each short-lived block's life.
   const int lane = threadIdx.x;
@@ -696,7 +734,7 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax, int2* zint, unsigned* queue) {
+                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final) {
   const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
   const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
@@ -705,8 +743,10 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const float2* ftab = (const float2*)(tmax + 4 * tw * th);  // behind the coarse tables (filled by launch_tile_fine)
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
   unsigned* qcount = queue;  // HSK_NQUEUES counters, one per 256-B line, cleared by k_column_zrange
+  const IcpFinal none = {nullptr, nullptr, 0};
+  const IcpFinal fin = (icp_final && !count_only) ? *icp_final : none;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, dil_blocks,
-                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount);
+                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount, fin, const_cast<TrackState*>(st));
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
@@ -721,12 +761,12 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const dim3 detail_grid(DETAIL_GX, HSK_NQUEUES);  // DETAIL_GX blocks stride over each queue
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, (double*)nullptr);
     hipLaunchKernelGGL(k_integrate_detail<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
   } else {
     hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, fin.slots);
     hipLaunchKernelGGL(k_integrate_detail<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
   }
