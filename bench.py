@@ -290,10 +290,19 @@ def main():
         out["independent_rooms"] = {"value": round(world * k2 / float(tt.item()), 2), "unit": "frames/s", "scaling": "weak",
                                     "steps": k2, "note": "one %d^3 volume per GPU, no collective (BASELINE configs[4])" % n}
         room.close()
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
