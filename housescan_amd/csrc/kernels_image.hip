@@ -513,7 +513,10 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
     const float c1 = ngz * np_[q][0] - ngx * np_[q][2];
     const float c2 = ngx * np_[q][1] - ngy * np_[q][0];
     valid = valid && (hsk_dot3(c0, c1, c2, c0, c1, c2) < angle_thresh);  // sqrtf(.) < angle_thresh, same conversion
-    if (valid) {
+    {
+      // Branch-free: a rejected pixel contributes a row of zeros (products exactly +-0, sums unchanged).  With the
+      // accumulation inside `if (valid)` the compiler copied the 27 accumulator pairs at every join of the divergent
+      // branch (416 v_mov in the 5-pixel kernel).
       float row[7];
       row[0] = g[q][1] * np_[q][2] - g[q][2] * np_[q][1];  // s x n
       row[1] = g[q][2] * np_[q][0] - g[q][0] * np_[q][2];
@@ -524,7 +527,7 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
       row[6] = hsk_dot3(np_[q][0], np_[q][1], np_[q][2], ex, ey, ez);
       double rs[6], rd[7];
 #pragma unroll
-      for (int a = 0; a < 7; ++a) rd[a] = (double)row[a];
+      for (int a = 0; a < 7; ++a) rd[a] = (double)(valid ? row[a] : 0.0f);
 #pragma unroll
       for (int a = 0; a < 6; ++a) rs[a] = rd[a] * ICP_SCALE;
       int k = 0;

@@ -24,7 +24,7 @@ for i in range(19):
     d = np.diff(b[:, :5], axis=1)
     end = b[:, 4].max()
     gap = (t[i + 1, :nb[i + 1], 0].min() - end) if i < 18 else float('nan')
-    if i > 0:
+    if i > 0 and b[:, 5:9].min() > 0:   # (the solve-step stamps exist only when hsk_icp_dev.h saw ICP_STAMP defined)
         inner = np.diff(np.concatenate([b[:, 1:2], b[:, 5:9], b[:, 2:3]], axis=1), axis=1).mean(axis=0)
         extra = "  || sums->regs %.2f solve6 %.2f shfl+sincos %.2f pose %.2f publish+barrier %.2f" % tuple(inner)
     else:
