@@ -471,123 +471,163 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     // (k_integrate_detail) walks with the per-voxel path on DENSE waves -- uncertain blocks hug the surfaces and
     // would otherwise drag their whole 64-lane wave through that path (profiles/r01/integrate_analysis.md).
     const int qx = vp.X / 4;
-    for (int zb = wl & ~3; zb <= wh; zb += 4) {
+    // The wave's (at most two) groups of 4 planes are taken through the stages TOGETHER: first-level tile lookups of
+    // both, second-level lookups of both, free-space loads of both, queue tickets of both.  A wave's life is a chain of
+    // dependent memory round trips (tile table -> fine tile table -> volume -> queue counter); stage by stage over both
+    // groups the chain is four trips long instead of eight, and pass A is bound by exactly that (its 65 k waves pass
+    // through 6 resident slots per SIMD in about eleven rounds).
+    static_assert(INTEGRATE_ZCHUNK <= 8, "pass A's staged loop handles at most two groups of 4 planes per wave");
+    constexpr int NS = 2;
+    int zbs[NS];
+    bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS];
+    float dc_s[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      zbs[sidx] = (wl & ~3) + 4 * sidx;
+      actv[sidx] = zbs[sidx] <= wh;  // wave-uniform
+      free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
+      dc_s[sidx] = 0.0f;
+    }
+    // ---- stage 1: first level (16-px dilated tile table)
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      if (!actv[sidx]) continue;
+      const int zb = zbs[sidx];
       const bool in_any = (zb + 3 >= zl) && (zb <= zh) && active;
       const bool in_all = (zb >= zl) && (zb + 3 <= zh) && active;
-      bool free44 = false, other = in_any;
-      {
-        const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - k.tz;  // centre of planes zb .. zb+3
-        const float czc = c.azc + k.i22 * gz;
-        const float rc = __builtin_amdgcn_rcpf(czc);
-        const float uc = (c.axfc + (k.i02 * gz) * in.fx) * rc + in.cx;
-        const float vc = (c.ayfc + (k.i12 * gz) * in.fy) * rc + in.cy;
-        const float r = k.rk4 * rc + 2.5f;
-        const bool ok = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
-        const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
-        const float2 Dt = dtab[tv * tw + tu];
-        const float dc = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
-        const bool dead4 = ok && (dc * 0.99999f - Dt.x > k.cull_thr4);
-        free44 = in_all && ok && (dc * 1.00001f + k.free_thr4 <= Dt.y);
-        other = in_any && !dead4 && !free44;
-        // ---- second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
-        //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
-        //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
-        //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
+      const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - k.tz;  // centre of planes zb .. zb+3
+      const float czc = c.azc + k.i22 * gz;
+      const float rc = __builtin_amdgcn_rcpf(czc);
+      const float uc = (c.axfc + (k.i02 * gz) * in.fx) * rc + in.cx;
+      const float vc = (c.ayfc + (k.i12 * gz) * in.fy) * rc + in.cy;
+      const float r = k.rk4 * rc + 2.5f;
+      const bool ok = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
+      const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
+      const float2 Dt = dtab[tv * tw + tu];
+      const float dc = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
+      const bool dead4 = ok && (dc * 0.99999f - Dt.x > k.cull_thr4);
+      const bool free44 = in_all && ok && (dc * 1.00001f + k.free_thr4 <= Dt.y);
+      in_all_s[sidx] = in_all;
+      dc_s[sidx] = dc;
+      free44_s[sidx] = free44;
+      other_s[sidx] = in_any && !dead4 && !free44;
+    }
+    // ---- stage 2: second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
+    //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
+    //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
+    //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
 #ifndef HSK_EXPA_NO_L2
-        if (__ballot(other) != 0ull) {
-          const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - k.tz;
-          const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - k.tz;
-          float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f, zmn = 1e30f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = (q & 1) ? 3 : 0;
-            const float gq = (q & 2) ? gzb : gza;
-            const float cz = c.az[j] + k.i22 * gq;
-            const float rq = __builtin_amdgcn_rcpf(cz);
-            const float uq = ((c.ax[j] + k.i02 * gq) * in.fx) * rq + in.cx;
-            const float vq = ((c.ay[j] + k.i12 * gq) * in.fy) * rq + in.cy;
-            zmn = fminf(zmn, cz);
-            umin = fminf(umin, uq);
-            umax = fmaxf(umax, uq);
-            vmin = fminf(vmin, vq);
-            vmax = fmaxf(vmax, vq);
-          }
-          umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
-          const int tu0 = (int)umin >> 3, tv0 = (int)vmin >> 3;
-          const bool ok2 = zmn > 0.05f && umin >= 0.0f && vmin >= 0.0f && umax <= (float)(W - 1) && vmax <= (float)(H - 1) &&
-                           ((int)umax >> 3) <= tu0 + 2 && ((int)vmax >> 3) <= tv0 + 2;
-          float Dx = 0.0f, Dn = 1e30f;
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      if (!actv[sidx] || __ballot(other_s[sidx]) == 0ull) continue;
+      const int zb = zbs[sidx];
+      const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - k.tz;
+      const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - k.tz;
+      float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f, zmn = 1e30f;
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-              const int tx = min(max(tu0 + b, 0), fw - 1), ty = min(max(tv0 + a, 0), fh - 1);
-              const float2 t = ftab[ty * fw + tx];
-              Dx = fmaxf(Dx, t.x);
-              Dn = fminf(Dn, t.y);
-            }
-          const bool dead2 = ok2 && (dc * 0.99999f - Dx > k.cull_thr4);
-          const bool free2 = in_all && ok2 && (dc * 1.00001f + k.free_thr4 <= Dn);
-          if (other && free2) free44 = true;
-          other = other && !dead2 && !free2;
-        }
-#endif
+      for (int q = 0; q < 4; ++q) {
+        const int j = (q & 1) ? 3 : 0;
+        const float gq = (q & 2) ? gzb : gza;
+        const float cz = c.az[j] + k.i22 * gq;
+        const float rq = __builtin_amdgcn_rcpf(cz);
+        const float uq = ((c.ax[j] + k.i02 * gq) * in.fx) * rq + in.cx;
+        const float vq = ((c.ay[j] + k.i12 * gq) * in.fy) * rq + in.cy;
+        zmn = fminf(zmn, cz);
+        umin = fminf(umin, uq);
+        umax = fmaxf(umax, uq);
+        vmin = fminf(vmin, vq);
+        vmax = fmaxf(vmax, vq);
       }
-#ifdef HSK_EXPA_NO_FREE
-      if (false) {
-#else
-      if (free44) {
+      umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
+      const int tu0 = (int)umin >> 3, tv0 = (int)vmin >> 3;
+      const bool ok2 = zmn > 0.05f && umin >= 0.0f && vmin >= 0.0f && umax <= (float)(W - 1) && vmax <= (float)(H - 1) &&
+                       ((int)umax >> 3) <= tu0 + 2 && ((int)vmax >> 3) <= tv0 + 2;
+      float Dx = 0.0f, Dn = 1e30f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int tx = min(max(tu0 + b, 0), fw - 1), ty = min(max(tv0 + a, 0), fh - 1);
+          const float2 t = ftab[ty * fw + tx];
+          Dx = fmaxf(Dx, t.x);
+          Dn = fminf(Dn, t.y);
+        }
+      const float dc = dc_s[sidx];
+      const bool dead2 = ok2 && (dc * 0.99999f - Dx > k.cull_thr4);
+      const bool free2 = in_all_s[sidx] && ok2 && (dc * 1.00001f + k.free_thr4 <= Dn);
+      if (other_s[sidx] && free2) free44_s[sidx] = true;
+      other_s[sidx] = other_s[sidx] && !dead2 && !free2;
+    }
 #endif
-        if (COUNT_ONLY) {
-          cnt += 16;
-        } else {
-          uint4 q4[4];
-          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    // ---- stage 3: deep free space -- four batched vector updates per group, the loads of both groups in flight together
+#ifndef HSK_EXPA_NO_FREE
+    if (COUNT_ONLY) {
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx)
+        if (actv[sidx] && free44_s[sidx]) cnt += 16;
+    } else {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      uint4 q4[NS][4];
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        if (!(actv[sidx] && free44_s[sidx])) continue;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
           if (vp.stream_nt) {
             // a volume far larger than the 256 MiB Infinity Cache gains nothing from caching these lines and loses
             // what they evict: non-temporal loads and stores (1024^3: 838 -> 802 us; at 512^3, where half the volume
             // stays cached from frame to frame, they cost 10 us, so the host decides by size)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zb + u) * plane_vec]);
-              q4[u] = make_uint4(t.x, t.y, t.z, t.w);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (update_vector_free4(q4[u])) {
-                const v4u t = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
-                __builtin_nontemporal_store(t, (v4u*)&vol[idx0 + (size_t)(zb + u) * plane_vec]);
-              }
+            const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
+            q4[sidx][u] = make_uint4(t.x, t.y, t.z, t.w);
           } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q4[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (update_vector_free4(q4[u])) vol[idx0 + (size_t)(zb + u) * plane_vec] = q4[u];
+            q4[sidx][u] = vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec];
           }
         }
       }
-      // wave-aggregated append of the uncertain lane-blocks
-#ifdef HSK_EXPA_NO_QUEUE
-      const unsigned long long bo = 0ull;
-#else
-      const unsigned long long bo = __ballot(other);
-#endif
-      if (bo != 0ull) {
-        // one of HSK_NQUEUES queues (a single counter saturates at ~88 atomics/us chip-wide).  The queue must NOT follow
-        // the block's x-y position: surfaces cluster in a few columns, and pass B's time is its longest queue.  Rotate
-        // the assignment by the row of HSK_NQUEUES blocks and by the wave: within a row it stays a bijection, so every
-        // queue still receives at most one wave-quarter of one block per row and wave index (the capacity bound).
-        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
-        unsigned base = 0;
-        if (lane == (int)__builtin_ctzll(bo)) base = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo));
-        base = __shfl(base, (int)__builtin_ctzll(bo), 64);
-        if (other)
-          queue[(size_t)qi * qcap + base + (unsigned)__popcll(bo & ((1ull << lane) - 1ull))] =
-              (unsigned)(((zb >> 2) * vp.Y + y) * qx + (x0 >> 2));
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        if (!(actv[sidx] && free44_s[sidx])) continue;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (update_vector_free4(q4[sidx][u])) {
+            if (vp.stream_nt) {
+              const v4u t = {q4[sidx][u].x, q4[sidx][u].y, q4[sidx][u].z, q4[sidx][u].w};
+              __builtin_nontemporal_store(t, (v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
+            } else {
+              vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec] = q4[sidx][u];
+            }
+          }
       }
     }
+#endif
+    // ---- stage 4: wave-aggregated append of the uncertain lane-blocks: one of HSK_NQUEUES queues (a single counter
+    // saturates at ~88 atomics/us chip-wide).  The queue must NOT follow the block's x-y position: surfaces cluster in a
+    // few columns, and pass B's time is its longest queue.  Rotate the assignment by the row of HSK_NQUEUES blocks and by
+    // the wave: within a row it stays a bijection, so every queue still receives at most one wave-quarter of one block
+    // per row and wave index (the capacity bound).  Both groups' tickets are requested before either is used.
+#ifndef HSK_EXPA_NO_QUEUE
+    {
+      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
+      unsigned long long bo[NS];
+      unsigned base[NS];
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        bo[sidx] = actv[sidx] ? __ballot(other_s[sidx]) : 0ull;
+        base[sidx] = 0;
+        if (bo[sidx] != 0ull && lane == (int)__builtin_ctzll(bo[sidx]))
+          base[sidx] = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo[sidx]));
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        if (bo[sidx] == 0ull) continue;
+        const unsigned b0 = (unsigned)__shfl((int)base[sidx], (int)__builtin_ctzll(bo[sidx]), 64);
+        if (other_s[sidx])
+          queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] =
+              (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
+      }
+    }
+#endif
   }
   if (COUNT_ONLY) {
 #pragma unroll
