@@ -1114,14 +1114,19 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
         const int s0 = px >> ss, s1 = py >> ss, s2 = pz >> ss;
         const int sbit = (s2 * syn + s1) * sxn + s0;
         const bool clear = !((lflags[flag_words + (sbit >> 5)] >> (sbit & 31)) & 1u);
-        // ray parameter at which the ray leaves the super-brick (approximate; two spare steps absorb the error)
-        const float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * s_edge0 - t0) * id0;
-        const float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * s_edge1 - t1) * id1;
-        const float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * s_edge2 - t2) * id2;
-        const float room = (fminf(fminf(e0, e1), e2) - time_curr) * inv_step - 2.0f;
-        int n = !act ? 0x7fffffff : ((clear && room >= 1.0f) ? (int)fminf(room, 64.0f) : 0);
+        // (one ballot settles the common "no": the waves that graze a surface for a hundred steps -- the ones the launch
+        // ends with -- must not pay for exit distances and a wave-wide minimum at every trip)
+        int n = 0;
+        if (__ballot(act && !clear) == 0ull) {
+          // ray parameter at which the ray leaves the super-brick (approximate; two spare steps absorb the error)
+          const float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * s_edge0 - t0) * id0;
+          const float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * s_edge1 - t1) * id1;
+          const float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * s_edge2 - t2) * id2;
+          const float room = (fminf(fminf(e0, e1), e2) - time_curr) * inv_step - 2.0f;
+          n = !act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, 64.0f) : 0);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n = min(n, __shfl_xor(n, o, 64));
+          for (int o = 32; o > 0; o >>= 1) n = min(n, __shfl_xor(n, o, 64));
+        }
         if (n >= RC_SKIP && n != 0x7fffffff) {  // wave-uniform
           float tc = time_curr;
           for (int i = 0; i < n; ++i) tc = tc + time_step;
