@@ -994,9 +994,15 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
 #endif
   RC_STAMP(1);
   const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int tiles_x = (W + 7) >> 3;
+  const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+  // Tile rows are dispatched from the top and bottom edges of the image inwards (0, last, 1, last - 1, ...): the rays of
+  // the border rows meet floor and ceiling at grazing angles and march longest, and a wave dispatched last onto a SIMD
+  // that already holds its share of waves finishes last -- with the rows in image order the launch ended with exactly
+  // those tiles (tools/rc_timing.sh).  Scheduling only.  Measured 512^3 / 1024^3: 90.6 / 117.9 -> 86.8 / 110.8 us.
+  const int ty_lin = tile / tiles_x;
+  const int ty = (ty_lin & 1) ? (tiles_y - 1 - (ty_lin >> 1)) : (ty_lin >> 1);
   const int x = (tile % tiles_x) * 8 + (lane & 7);
-  const int y = (tile / tiles_x) * 8 + (lane >> 3);
+  const int y = ty * 8 + (lane >> 3);
   if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0) {
     // the tracker state is final once the ICP has ended (nothing after it writes it): report it to the host now, also
     // for a lost or dropped frame, which returns just below

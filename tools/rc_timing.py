@@ -22,7 +22,9 @@ for name, v in (("staging", stage), ("march", march), ("refine", refine), ("life
     print(f"{name:8s} mean {v.mean():6.1f}  p50 {np.percentile(v, 50):6.1f}  p90 {np.percentile(v, 90):6.1f}  p99 {np.percentile(v, 99):6.1f}  max {v.max():6.1f}")
 order = np.argsort(-(t[:, 3] - t0))[:12]
 for i in order:
-    print("trips %4d gather-trips %4d us/trip %.3f |" % (trips[i], gtrips[i], march[i] / max(1, trips[i])), "tile", i, "xy", (i % 80) * 8, (i // 80) * 8, "start %.1f stage %.1f march %.1f refine %.1f end %.1f" % (t[i, 0] - t0, stage[i], march[i], refine[i], t[i, 3] - t0))
+    row = i // 80
+    row = (60 - 1 - (row >> 1)) if (row & 1) else (row >> 1)   # k_raycast dispatches tile rows from the edges inwards
+    print("trips %4d gather-trips %4d us/trip %.3f |" % (trips[i], gtrips[i], march[i] / max(1, trips[i])), "tile", i, "xy", (i % 80) * 8, row * 8, "start %.1f stage %.1f march %.1f refine %.1f end %.1f" % (t[i, 0] - t0, stage[i], march[i], refine[i], t[i, 3] - t0))
 
 print("trips: mean %.0f p50 %.0f p90 %.0f max %d; gather-trips mean %.0f max %d" % (trips.mean(), np.percentile(trips, 50), np.percentile(trips, 90), trips.max(), gtrips.mean(), gtrips.max()))
 # march time against trips: least squares us = a * trips + b * gather_trips
