@@ -33,7 +33,7 @@ def assert_same_bits(a, b, what):
                              f"{a[tuple(idx[0])]} vs {b[tuple(idx[0])]}")
 
 
-@pytest.mark.parametrize("n", [64, 128])
+@pytest.mark.parametrize("n", [64, 128, 256, 512])   # 512: the headline size, every voxel compared
 def test_integrate_bit_exact(hsk, oracle, synth_frames, n):
     cfg_o = oracle.default_config(n)
     trk = hsk.KinfuTracker(n=n)
@@ -128,7 +128,7 @@ def _fused_volume(hsk, oracle, synth_frames, n, frames):
     return cfg_o, vol
 
 
-@pytest.mark.parametrize("n", [64, 128])
+@pytest.mark.parametrize("n", [64, 128, 256, 512])   # 256 / 512: long wave-wide crossings of clear super-bricks, step keys included
 def test_raycast_bit_exact(hsk, oracle, synth_frames, n):
     cfg_o, vol = _fused_volume(hsk, oracle, synth_frames, n, (0, 5, 10))
     trk = hsk.KinfuTracker(n=n)
@@ -464,6 +464,32 @@ def test_config2_256_tracker_vs_oracle_and_truth(hsk, oracle, synth_frames):
         assert dt < 3.0 and ang < 0.1, (k, dt, ang)
     assert_same_bits(trk.download_tsdf(), ot.volume(), "256^3 tsdf after 8 frames")
     trk.close()
+
+
+def test_headline_512_tracker_vs_oracle(hsk, oracle, synth_frames):
+    """BASELINE's metric configuration itself: 640x480 into 512^3 through the pipelined pair the benchmark times
+    (submit ahead, wait behind); every pose, the whole TSDF and the model maps bit-identical to the oracle"""
+    n = 512
+    ot = oracle.Tracker(oracle.default_config(n), omp=True)
+    trk = hsk.KinfuTracker(n=n)
+    frames = [synth_frames(k) for k in range(7)]
+    want = [ot.process(d) for _, d in frames]
+    trk.process_frame(frames[0][1])
+    trk.submit_frame(frames[1][1])
+    got = []
+    for _, d in frames[2:]:
+        trk.submit_frame(d)
+        got.append(trk.wait_frame())
+    got.append(trk.wait_frame())
+    for k, ((ph, ok), (po, oko)) in enumerate(zip(got, want[1:]), start=1):
+        assert ok and oko
+        assert_same_bits(ph, po, f"512^3 pose frame {k}")
+    assert_same_bits(trk.download_tsdf(), ot.volume(), "512^3 tsdf after 7 frames")
+    for level in range(3):
+        assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"512^3 model vmap {level}")
+        assert_same_bits(trk.download_map(3, level), ot.model_map(3, level), f"512^3 model nmap {level}")
+    trk.close()
+    ot.close()
 
 
 def test_noisy_stream_trajectory(hsk):
