@@ -83,6 +83,7 @@ struct hsk_ctx {
   // overlapped preprocessing: stream, per-set events (preprocess done / set free again), per-set graphs of the rest
   hipStream_t pstream = nullptr;
   hipEvent_t ev_pre[2] = {}, ev_free[2] = {};
+  hipEvent_t ev_src = nullptr;  // orders the second stream behind the caller's (adopted) stream before a depth copy
 
   bool set_used[2] = {false, false};
   int async_set = 1;
@@ -193,6 +194,7 @@ static void free_all(hsk_ctx* k) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : k->ev_free)
     if (e) (void)hipEventDestroy(e);
+  if (k->ev_src) (void)hipEventDestroy(k->ev_src);
   if (k->pstream) (void)hipStreamDestroy(k->pstream);
   auto F = [](void* p) {
     if (p) (void)hipFree(p);
@@ -356,6 +358,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipStreamCreateWithFlags(&k->pstream, hipStreamNonBlocking));
   for (auto& e : k->ev_pre) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : k->ev_free) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&k->ev_src, hipEventDisableTiming));
 
   CK(hipMalloc((void**)&k->d_st, sizeof(TrackState)));
   CK(hipHostMalloc((void**)&k->h_st, sizeof(TrackState), hipHostMallocDefault));
@@ -383,6 +386,13 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
          ((vp.Y >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.Y)
     ++vp.bshift;
   k->flags_bytes = (size_t)hsk_flag_words_total(vp) * 4;  // brick bits + super-brick bits
+  // k_raycast stages the whole bitfield in dynamic LDS; a launch may ask for at most 64 KiB of it.  Volumes whose
+  // dimensions stop the brick edge from growing (e.g. 1000^3: 125 = 5^3 bricks of 8) would be created fine and then
+  // fail at the first raycast: refuse them here, with the reason.
+  if (k->flags_bytes > 64u * 1024u) {
+    k->err = "hsk_create: the brick bitfield of this volume does not fit the raycast's LDS (64 KiB): choose vol_x, vol_y divisible by a larger power of two";
+    return bail(HSK_ERR_ARG);
+  }
   CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
   // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of the pass-A
   // blocks (64 x 16 voxels x 8 planes per block -> 512 lane-blocks); see launch_integrate
@@ -490,18 +500,24 @@ static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys, bool report = fals
                       k->d_nmod[2], k->d_st);
 }
 
-// integration gate (A.2 step 5); evaluated on the host, only when the threshold is positive
+// Integration gate (specification in oracle/kinfu_oracle.c and DESIGN.md): the frame integrates
+// iff (angle(R^T Rp) + |t - tp|) / 2 >= thr.  Host side, only when the threshold is positive; the pose pair comes from
+// the tracker state the frame has just downloaded.  trace(R^T Rp) is taken column by column: column i of R against
+// column i of Rp, the three column products added left to right.
 static bool gate_passes(const TrackState* st, float thr) {
   if (!(thr > 0.0f)) return true;
-  float tr = 0.0f;
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) tr += st->R[j * 3 + i] * st->Rp[j * 3 + i];
-  float cs = (tr - 1.0f) / 2.0f;
-  cs = cs > 1.0f ? 1.0f : (cs < -1.0f ? -1.0f : cs);
-  const float rnorm = acosf(cs);
-  const float d0 = st->t[0] - st->tp[0], d1 = st->t[1] - st->tp[1], d2 = st->t[2] - st->tp[2];
-  const float tnorm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
-  return (rnorm + tnorm) / 2.0f >= thr;
+  const float* a = st->R;
+  const float* b = st->Rp;
+  const float c0 = (a[0] * b[0] + a[3] * b[3]) + a[6] * b[6];
+  const float c1 = (a[1] * b[1] + a[4] * b[4]) + a[7] * b[7];
+  const float c2 = (a[2] * b[2] + a[5] * b[5]) + a[8] * b[8];
+  float cs = (((c0 + c1) + c2) - 1.0f) / 2.0f;
+  if (cs > 1.0f) cs = 1.0f;
+  if (cs < -1.0f) cs = -1.0f;
+  const float turn = acosf(cs);
+  const float ex = st->t[0] - st->tp[0], ey = st->t[1] - st->tp[1], ez = st->t[2] - st->tp[2];
+  const float shift = sqrtf((ex * ex + ey * ey) + ez * ez);
+  return (turn + shift) / 2.0f >= thr;
 }
 
 // the steady-state frame: everything between the depth copy and the pose read-back
@@ -760,6 +776,14 @@ static int submit_frame(hsk_ctx* k, const void* depth_dev, hipMemcpyKind kind, i
   }
   k->set_expect[set] = k->ring_seq | 0x80000000u;
   k->set_slot[set] = slot;
+  // A device frame may still be in the making on the context's stream (an upload or a conversion kernel the caller
+  // enqueued on the stream it handed over with hsk_set_stream): the second stream is ordered behind it.  The record
+  // costs the main queue nothing, the wait sits on the second stream only.  (Host frames come from the context's own
+  // pinned staging ring, already complete.)
+  if (e == hipSuccess && kind == hipMemcpyDeviceToDevice && !k->own_stream) {
+    e = hipEventRecord(k->ev_src, k->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(k->pstream, k->ev_src, 0);
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, kind, k->pstream);
   if (e == hipSuccess) {
     enqueue_preprocess(k, k->pstream);
@@ -1106,6 +1130,11 @@ extern "C" int hsk_mgpu_prefetch(hsk_ctx* k, const void* depth_dev, int w, int h
   if (k->set_used[set]) HIPCHK(k, hipStreamWaitEvent(k->pstream, k->ev_free[set], 0));  // its previous frame has finished
   const int keep = k->cur;
   k->cur = set;
+  // the frame may still be in the making on the context's (adopted) stream: order the second stream behind it
+  if (!k->own_stream) {
+    HIPCHK(k, hipEventRecord(k->ev_src, k->stream));
+    HIPCHK(k, hipStreamWaitEvent(k->pstream, k->ev_src, 0));
+  }
   hipError_t e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->pstream);
   if (e == hipSuccess) {
     enqueue_preprocess(k, k->pstream);

@@ -42,7 +42,7 @@ extern "C" {
 typedef struct hsk_ctx hsk_ctx; /* opaque; one per volume / room */
 
 typedef struct {
-  int vol_x, vol_y, vol_z;      /* voxels, e.g. 256 / 512 / 1024; vol_x must be a multiple of 4         */
+  int vol_x, vol_y, vol_z;      /* voxels, e.g. 256 / 512 / 1024; vol_x and vol_y multiples of 8        */
   float vol_size_m[3];          /* metric extent, default 3 x 3 x 3                                    */
   float trunc_dist_m;           /* default 0.03; clamped to >= 2.1 * max cell                           */
   int width, height;            /* depth image, default 640 x 480 (the shape HoniHelper.hs:34-36 returns) */
@@ -79,7 +79,10 @@ int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float
  * outstanding, so the GPU runs frame k+1 while the host reads frame k's pose.  After a tracking loss the frames
  * already in flight are dropped (tracked = 0) and the volume is reset before the next submission.  The depth copy
  * and preprocessing of a submitted frame run on a second stream, overlapped with the previous frame; depth_dev must
- * therefore stay valid until hsk_wait_frame has returned that frame. */
+ * therefore stay valid until hsk_wait_frame has returned that frame.  Its CONTENTS may still be in the making on a
+ * stream the context has adopted through hsk_set_stream (an upload or a conversion kernel enqueued there): the second
+ * stream is ordered behind everything enqueued on the adopted stream at the time of the call.  Work on any other
+ * stream (and any work when the context runs on its own stream) must have completed before the call. */
 #define HSK_MAX_IN_FLIGHT 3
 int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h);
 int hsk_submit_frame(hsk_ctx* k, const uint16_t* depth, int w, int h); /* host frame; copied before the call returns */

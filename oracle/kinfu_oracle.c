@@ -3,7 +3,8 @@
  * header of kinfu_oracle.h ("PARITY UNPINNED").  Every stage cites the SURVEY.md Appendix A paragraph it
  * follows (the reference repository itself holds no KinFu source: /root/reference/README.md:13-14).
  *
- * Numerical contract (shared with the HIP kernels, which are written independently against it):
+ * Numerical contract (shared with the HIP kernels; the 6x6 solve, sin/cos and the integration gate exist as two
+ * separately written texts, here and in housescan_amd/csrc, that must agree bit for bit):
  *   - IEEE-754 binary32/binary64, round-to-nearest-even, one rounding per written operator;
  *     no fused multiply-add anywhere (build with -ffp-contract=off), no fast-math;
  *   - sqrtf and '/' are the correctly rounded operations;
@@ -403,131 +404,118 @@ uint64_t ora_icp_accumulate(const float* vcur, const float* ncur, const float* v
   return n_valid;
 }
 
-/* A.5 host side: symmetric fill, Cholesky (LL^T), |det| < 1e-15 or NaN => lost */
+/* A.5 host side.  The 27 sums are the rows of the upper triangle of the augmented system [A | b], packed:
+ * (i, j), i <= j <= 6, sits at 7 i - i (i - 1) / 2 + (j - i).  A.5 names a Cholesky solve; this build's specification
+ *  is the square-root-free form A = L D L^T, L unit lower triangular, with ONE reciprocal per pivot:
+ *   d_c   = A_cc - sum_{q<c} (L_cq L_cq) d_q                      (q ascending)
+ *   L_rc  = (A_rc - sum_{q<c} (L_rq L_cq) d_q) * (1 / d_c)
+ *   det   = d_0 d_1 ... d_5                                        (left to right)
+ *   L y = b forwards, then x_r = y_r (1 / d_r) - sum_{q>r} L_qr x_q backwards (q ascending).
+ * Lost (return 0) when a pivot is not positive, det < 1e-15 or NaN, or a component is NaN / not below 1e30.
+ * Written here from that specification; the device solve in housescan_amd/csrc is a separate text. */
+static int tri_at(int i, int j) { return 7 * i - (i * (i - 1)) / 2 + (j - i); }
+
+static int solve_lost(float x6[6]) {
+  for (int q = 0; q < 6; ++q) x6[q] = 0.0f;
+  return 0;
+}
+
 int ora_icp_solve(const double in27[27], float x6[6]) {
-  double A[6][6], b[6], L[6][6];
-  int k = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 7; ++j) {
-      const double v = in27[k++];
-      if (j == 6)
-        b[i] = v;
-      else {
-        A[i][j] = v;
-        A[j][i] = v;
-      }
-    }
-  memset(L, 0, sizeof(L));
-  /* LDL^T (unit lower L, diagonal D), one reciprocal per pivot; numerically equivalent to the Cholesky (LL^T) of
-   * A.5, without square roots on the dependent chain */
+  double low[6][6]; /* strictly lower part of L; only [r][c] with c < r is ever read */
+  double piv[6], rpiv[6];
   double det = 1.0;
-  double D[6], dinv[6];
-  for (int j = 0; j < 6; ++j) {
-    double dj = A[j][j];
-    for (int q = 0; q < j; ++q) dj = dj - (L[j][q] * L[j][q]) * D[q];
-    if (!(dj > 0.0)) {
-      for (int q = 0; q < 6; ++q) x6[q] = 0.0f;
-      return 0;
-    }
-    D[j] = dj;
-    dinv[j] = 1.0 / dj;
-    det = det * dj;
-    for (int i = j + 1; i < 6; ++i) {
-      double r = A[i][j];
-      for (int q = 0; q < j; ++q) r = r - (L[i][q] * L[j][q]) * D[q];
-      L[i][j] = r * dinv[j];
+  for (int c = 0; c < 6; ++c) {
+    double d = in27[tri_at(c, c)];
+    for (int q = 0; q < c; ++q) d -= (low[c][q] * low[c][q]) * piv[q];
+    if (!(d > 0.0)) return solve_lost(x6);
+    piv[c] = d;
+    rpiv[c] = 1.0 / d;
+    det *= d;
+    for (int r = c + 1; r < 6; ++r) {
+      double a = in27[tri_at(c, r)]; /* A_rc = A_cr */
+      for (int q = 0; q < c; ++q) a -= (low[r][q] * low[c][q]) * piv[q];
+      low[r][c] = a * rpiv[c];
     }
   }
-  if (!(det >= 1e-15)) { /* also catches NaN */
-    for (int q = 0; q < 6; ++q) x6[q] = 0.0f;
-    return 0;
+  if (!(det >= 1e-15)) return solve_lost(x6); /* NaN fails the comparison too */
+  double y[6], x[6];
+  for (int r = 0; r < 6; ++r) {
+    double acc = in27[tri_at(r, 6)];
+    for (int q = 0; q < r; ++q) acc -= low[r][q] * y[q];
+    y[r] = acc;
   }
-  double yv[6], xv[6];
-  for (int i = 0; i < 6; ++i) { /* L y = b */
-    double r = b[i];
-    for (int q = 0; q < i; ++q) r = r - L[i][q] * yv[q];
-    yv[i] = r;
+  for (int r = 5; r >= 0; --r) {
+    double acc = y[r] * rpiv[r];
+    for (int q = r + 1; q < 6; ++q) acc -= low[q][r] * x[q];
+    x[r] = acc;
   }
-  for (int i = 5; i >= 0; --i) { /* L^T x = D^-1 y */
-    double r = yv[i] * dinv[i];
-    for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
-    xv[i] = r;
-  }
-  for (int q = 0; q < 6; ++q) {
-    if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) {
-      for (int w = 0; w < 6; ++w) x6[w] = 0.0f;
-      return 0;
-    }
-    x6[q] = (float)xv[q];
-  }
+  for (int q = 0; q < 6; ++q)
+    if (isnan(x[q]) || !(fabs(x[q]) < 1e30)) return solve_lost(x6);
+  for (int q = 0; q < 6; ++q) x6[q] = (float)x[q];
   return 1;
 }
 
-/* sin/cos by Cody-Waite reduction + fixed Taylor/Horner polynomials in binary64 (bit-reproducible) */
+/* sin and cos of the ICP increment, bit-reproducible on every machine: Cody-Waite reduction by pi/2 in two pieces
+ * (k = rint(x 2/pi), r = (x - k hi) - k lo), then the Taylor polynomials to r^15 / r^16 in Horner form, binary64:
+ *   sin r = r + (r r^2) S(r^2),  S = ((((((-1/15! r2 + 1/13!) r2 - 1/11!) r2 + 1/9!) r2 - 1/7!) r2 + 1/5!) r2 - 1/3!)
+ *   cos r = (1 - r^2 / 2) + (r^2 r^2) C(r^2),  C likewise from 1/16! down to 1/4!
+ * and the quadrant k mod 4 picks (s, c) from the cycle sr, cr, -sr, -cr.  |x| >= 1e5 or NaN gives (0, 1). */
+static const double kSinTail[7] = {-(1.0 / 1307674368000.0), 1.0 / 6227020800.0, -(1.0 / 39916800.0), 1.0 / 362880.0,
+                                   -(1.0 / 5040.0),          1.0 / 120.0,        -(1.0 / 6.0)};
+static const double kCosTail[7] = {1.0 / 20922789888000.0, -(1.0 / 87178291200.0), 1.0 / 479001600.0, -(1.0 / 3628800.0),
+                                   1.0 / 40320.0,          -(1.0 / 720.0),         1.0 / 24.0};
+
 void ora_sincos(double x, double* s, double* c) {
-  if (!(fabs(x) < 1.0e5)) {
-    *s = 0.0;
-    *c = 1.0;
-    return;
-  }
-  const double two_over_pi = 0.63661977236758134308;
-  const double pio2_hi = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
-  const double pio2_lo = 6.07710050650619224932e-11;
-  const double kf = rint(x * two_over_pi);
-  const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+  *s = 0.0;
+  *c = 1.0;
+  if (!(fabs(x) < 1.0e5)) return;
+  const double k = rint(x * 0.63661977236758134308);
+  double r = x - k * 1.57079632673412561417e+00; /* the first 33 bits of pi/2: k times it is exact */
+  r = r - k * 6.07710050650619224932e-11;
   const double r2 = r * r;
-  /* sin r = r + r^3 * S(r2), cos r = 1 - r2/2 + r2^2 * C(r2) */
-  double S = -1.0 / 1307674368000.0; /* -1/15! */
-  S = S * r2 + 1.0 / 6227020800.0;   /* 1/13! */
-  S = S * r2 - 1.0 / 39916800.0;     /* 1/11! */
-  S = S * r2 + 1.0 / 362880.0;       /* 1/9! */
-  S = S * r2 - 1.0 / 5040.0;         /* 1/7! */
-  S = S * r2 + 1.0 / 120.0;          /* 1/5! */
-  S = S * r2 - 1.0 / 6.0;            /* 1/3! */
-  const double sr = r + (r * r2) * S;
-  double C = 1.0 / 20922789888000.0; /* 1/16! */
-  C = C * r2 - 1.0 / 87178291200.0;  /* 1/14! */
-  C = C * r2 + 1.0 / 479001600.0;    /* 1/12! */
-  C = C * r2 - 1.0 / 3628800.0;      /* 1/10! */
-  C = C * r2 + 1.0 / 40320.0;        /* 1/8! */
-  C = C * r2 - 1.0 / 720.0;          /* 1/6! */
-  C = C * r2 + 1.0 / 24.0;           /* 1/4! */
-  const double cr = (1.0 - 0.5 * r2) + (r2 * r2) * C;
-  const int q = ((int)kf) & 3;
-  switch (q) {
-    case 0: *s = sr; *c = cr; break;
-    case 1: *s = cr; *c = -sr; break;
-    case 2: *s = -sr; *c = -cr; break;
-    default: *s = -cr; *c = sr; break;
+  double ps = kSinTail[0], pc = kCosTail[0];
+  for (int i = 1; i < 7; ++i) {
+    ps = ps * r2 + kSinTail[i];
+    pc = pc * r2 + kCosTail[i];
+  }
+  const double sr = r + (r * r2) * ps;
+  const double cr = (1.0 - 0.5 * r2) + (r2 * r2) * pc;
+  const double cycle[4] = {sr, cr, -sr, -cr};
+  const int quad = ((int)k) & 3;
+  *s = cycle[quad];
+  *c = cycle[(quad + 1) & 3];
+}
+
+/* C = A B for row-major 3x3 matrices, each element (a0 b0 + a1 b1) + a2 b2 */
+static void mul33(const float A[9], const float B[9], float C[9]) {
+  for (int e = 0; e < 9; ++e) {
+    const float* a = A + 3 * (e / 3);
+    const float* b = B + (e % 3);
+    C[e] = (a[0] * b[0] + a[1] * b[3]) + a[2] * b[6];
   }
 }
 
-static void mat3mul(const float A[9], const float B[9], float O[9]) {
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) O[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
-}
-
-/* A.2 step (3): R_inc = Rz(gamma) Ry(beta) Rx(alpha); t <- R_inc t + t_inc; R <- R_inc R */
+/* A.2 step (3): R_inc = Rz(gamma) Ry(beta) Rx(alpha) from x6 = (alpha, beta, gamma, tx, ty, tz);
+ * t <- R_inc t + t_inc; R <- R_inc R.  The sines and cosines are ora_sincos's, rounded to binary32. */
 void ora_pose_update(float R[9], float t[3], const float x6[6]) {
-  double sd, cd;
-  ora_sincos((double)x6[0], &sd, &cd);
-  const float sa = (float)sd, ca = (float)cd;
-  ora_sincos((double)x6[1], &sd, &cd);
-  const float sb = (float)sd, cb = (float)cd;
-  ora_sincos((double)x6[2], &sd, &cd);
-  const float sg = (float)sd, cg = (float)cd;
-  const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca};
-  const float Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb};
-  const float Rz[9] = {cg, -sg, 0, sg, cg, 0, 0, 0, 1};
-  float Rzy[9], Rinc[9], Rn[9], tn[3];
-  mat3mul(Rz, Ry, Rzy);
-  mat3mul(Rzy, Rx, Rinc);
-  rot3(Rinc, t, tn);
-  t[0] = tn[0] + x6[3];
-  t[1] = tn[1] + x6[4];
-  t[2] = tn[2] + x6[5];
-  mat3mul(Rinc, R, Rn);
-  memcpy(R, Rn, sizeof(Rn));
+  float sn[3], cs[3];
+  for (int a = 0; a < 3; ++a) {
+    double sd, cd;
+    ora_sincos((double)x6[a], &sd, &cd);
+    sn[a] = (float)sd;
+    cs[a] = (float)cd;
+  }
+  const float about_x[9] = {1.0f, 0.0f, 0.0f, 0.0f, cs[0], -sn[0], 0.0f, sn[0], cs[0]};
+  const float about_y[9] = {cs[1], 0.0f, sn[1], 0.0f, 1.0f, 0.0f, -sn[1], 0.0f, cs[1]};
+  const float about_z[9] = {cs[2], -sn[2], 0.0f, sn[2], cs[2], 0.0f, 0.0f, 0.0f, 1.0f};
+  float zy[9], inc[9], turned[9];
+  mul33(about_z, about_y, zy);
+  mul33(zy, about_x, inc);
+  float moved[3];
+  for (int r = 0; r < 3; ++r) moved[r] = ((inc[3 * r] * t[0] + inc[3 * r + 1] * t[1]) + inc[3 * r + 2] * t[2]) + x6[3 + r];
+  mul33(inc, R, turned);
+  memcpy(t, moved, sizeof(moved));
+  memcpy(R, turned, sizeof(turned));
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -880,19 +868,22 @@ static void pose_to16(const float R[9], const float t[3], float m[16]) {
   m[15] = 1.0f;
 }
 
-/* integration gate (A.2 step 5); only evaluated when move_thresh > 0 */
+/* integration gate (A.2 step 5); only evaluated when move_thresh > 0.  M = R^-1 R_prev = R^T R_prev; the norm of its
+ * Rodrigues vector is the rotation angle acos((trace M - 1) / 2), clamped into [-1, 1]; the frame integrates iff
+ * (angle + |t - t_prev|) / 2 >= threshold.  Only the diagonal of M is formed:
+ * M_ii = (R_0i Rp_0i + R_1i Rp_1i) + R_2i Rp_2i, trace = (M_00 + M_11) + M_22; acosf is the C library's. */
 static int gate_passes(const float R[9], const float t[3], const float Rp[9], const float tp[3], float thr) {
   if (!(thr > 0.0f)) return 1;
-  /* R^-1 R_prev = R^T R_prev; rotation angle = acos((trace-1)/2) */
-  float tr = 0.0f;
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) tr += R[j * 3 + i] * Rp[j * 3 + i];
-  float cs = (tr - 1.0f) / 2.0f;
-  cs = cs > 1.0f ? 1.0f : (cs < -1.0f ? -1.0f : cs);
-  const float rnorm = acosf(cs);
+  float diag[3];
+  for (int i = 0; i < 3; ++i) diag[i] = (R[i] * Rp[i] + R[3 + i] * Rp[3 + i]) + R[6 + i] * Rp[6 + i];
+  const float trace = (diag[0] + diag[1]) + diag[2];
+  float cosine = (trace - 1.0f) / 2.0f;
+  if (cosine > 1.0f) cosine = 1.0f;
+  if (cosine < -1.0f) cosine = -1.0f;
+  const float angle = acosf(cosine);
   const float d[3] = {t[0] - tp[0], t[1] - tp[1], t[2] - tp[2]};
-  const float tnorm = sqrtf(dot3(d, d));
-  return (rnorm + tnorm) / 2.0f >= thr;
+  const float moved = sqrtf(dot3(d, d));
+  return (angle + moved) / 2.0f >= thr;
 }
 
 int ora_tracker_process(ora_tracker* k, const uint16_t* depth, float pose16[16]) {
