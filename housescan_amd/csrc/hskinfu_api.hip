@@ -500,7 +500,7 @@ static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys, bool report = fals
                       k->d_nmod[2], k->d_st);
 }
 
-// Integration gate (specification in oracle/kinfu_oracle.c and DESIGN.md): the frame integrates
+// Integration gate (this build's specification of it: DESIGN.md section 4): the frame integrates
 // iff (angle(R^T Rp) + |t - tp|) / 2 >= thr.  Host side, only when the threshold is positive; the pose pair comes from
 // the tracker state the frame has just downloaded.  trace(R^T Rp) is taken column by column: column i of R against
 // column i of Rp, the three column products added left to right.
