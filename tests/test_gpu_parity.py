@@ -335,6 +335,24 @@ def test_golden_vectors_gpu(hsk):
     assert_same_bits(trk.download_map(3, 0)[:, 40:70, 60:100], g["nmap_crop"], "golden nmap crop")
     trk.preprocess(hsk.synth_depth(hsk.synth_pose(4), W, H, FX, FX, CX, CY))
     assert_same_bits(trk.icp_accumulate(0, poses[-1]), g["icp27"], "golden ICP sums")
+    # vectors added in round 2 (generated by the numpy twin)
+    x6, ok = trk.icp_solve(g["icp27"])
+    assert ok
+    assert_same_bits(x6, g["solve6"], "golden 6x6 solve (host mirror of the device solve)")
+    pts, total = trk.extract_cloud()
+    assert total == int(g["cloud_count"])
+    assert_same_bits(pts[:256], g["cloud_head"], "golden cloud head")
+    trk.close()
+    # a second tracker stops exactly where the golden run stopped: model maps of the coarsest level and the step keys
+    trk = hsk.KinfuTracker(hsk.default_config(n, width=W, height=H, fx=FX, fy=FX, cx=CX, cy=CY))
+    for k in g["frames"]:
+        trk.process_frame(hsk.synth_depth(hsk.synth_pose(int(k)), W, H, FX, FX, CX, CY))
+    assert_same_bits(trk.download_map(2, 2), g["vmap2"], "golden model vmap level 2")
+    assert_same_bits(trk.download_map(3, 2), g["nmap2"], "golden model nmap level 2")
+    _, _, keys = trk.raycast(poses[-1], want_keys=True)
+    assert np.array_equal(keys[40:70, 60:100], g["keys_crop"])
+    trk.preprocess(hsk.synth_depth(hsk.synth_pose(int(g["frames"][1])), W, H, FX, FX, CX, CY))
+    assert np.array_equal(trk.download_depth_level(0), g["bilateral1"])
     trk.close()
 
 

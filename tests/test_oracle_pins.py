@@ -2,7 +2,7 @@
 KinFu source or golden vectors.  What pins the oracle instead:
   (i)   an independent numpy restatement (tests/np_twin.py) -- bit-exact,
   (ii)  the analytic ground truth of the synthetic scene (known planes, known poses),
-  (iii) committed golden vectors generated by tests/golden/make_golden.py (regression / cross-machine pin)."""
+  (iii) committed golden vectors generated FROM THE TWIN by tests/golden/make_golden.py (regression / cross-machine pin)."""
 import os
 
 import numpy as np
@@ -167,3 +167,183 @@ def test_golden_vectors(oracle, hsk):
     vm = oracle.vmap(cfg, oracle.bilateral(cfg, d))
     s, _ = oracle.icp_accumulate(cfg, 0, vm, oracle.nmap(vm), trk.model_map(2, 0), trk.model_map(3, 0), poses[-1], poses[-1])
     assert np.array_equal(s.view(np.uint64), g["icp27"].view(np.uint64))
+    # vectors added in round 2 (the file is generated by the numpy twin: tests/golden/make_golden.py)
+    assert same_bits(trk.model_map(2, 2), g["vmap2"]) and same_bits(trk.model_map(3, 2), g["nmap2"])
+    assert np.array_equal(oracle.bilateral(cfg, small_depth(hsk, int(g["frames"][1]))), g["bilateral1"])
+    x6, ok = oracle.icp_solve(g["icp27"])
+    assert ok and np.array_equal(x6.view(np.uint32), g["solve6"].view(np.uint32))
+    assert np.array_equal(oracle.pose_update(poses[-1], x6).view(np.uint32), g["pose_after_solve"].view(np.uint32))
+    _, _, keys, _ = oracle.raycast(cfg, trk.volume(), poses[-1])
+    assert np.array_equal(keys[40:70, 60:100], g["keys_crop"])
+    pts, total = oracle.extract_cloud(cfg, trk.volume())
+    assert total == int(g["cloud_count"]) and same_bits(pts[:256], g["cloud_head"])
+
+
+# ---- round 2: every remaining stage has a second, independently written restatement (tests/np_twin.py) ----
+def _libm_acosf():
+    import ctypes
+    m = ctypes.CDLL("libm.so.6")
+    m.acosf.restype = ctypes.c_float
+    m.acosf.argtypes = [ctypes.c_float]
+    return lambda c: m.acosf(float(c))
+
+
+def test_twin_bilateral(oracle, hsk):
+    cfg = small_cfg(oracle)
+    rng = np.random.default_rng(21)
+    d = small_depth(hsk, 3).copy()
+    d = (d.astype(np.int32) + rng.integers(-12, 13, d.shape)).clip(0, 65535).astype(np.uint16)
+    d[rng.random(d.shape) < 0.03] = 0
+    d[30:44, 60:90] = 0
+    d[0:5, 0:7] = 40000          # beyond the 32767 clamp of the result, at a clipped corner window
+    assert same_bits(oracle.bilateral(cfg, d), T.bilateral(d))
+    ws, wc = hsk.bilateral_tables()
+    tws, twc = T.bilateral_tables()
+    assert np.array_equal(ws.reshape(13, 13), tws) and np.array_equal(wc, twc)
+
+
+def test_twin_resize_and_transform(oracle, hsk):
+    cfg = small_cfg(oracle)
+    d = small_depth(hsk, 6).copy()
+    d[50:60, 20:40] = 0
+    vm = oracle.vmap(cfg, d)
+    nm = oracle.nmap(vm)
+    pose = hsk.synth_pose(6)
+    vo, no = oracle.transform_maps(vm, nm, pose)
+    tv, tn = T.transform_maps(vm, nm, pose)
+    assert same_bits(vo, tv) and same_bits(no, tn)
+    assert same_bits(oracle.resize_vmap(vo), T.resize_vmap(vo))
+    assert same_bits(oracle.resize_nmap(no), T.resize_nmap(no))
+    assert same_bits(oracle.resize_nmap(oracle.resize_nmap(no)), T.resize_nmap(T.resize_nmap(no)))
+
+
+def test_twin_sincos_solve_pose_update_gate(oracle, hsk):
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.normal(scale=0.02, size=200), rng.uniform(-7, 7, 200), [0.0, -0.0, 1e-12, 1.0e5, -3.0e7, np.nan, 99999.5]])
+    for x in xs:
+        so, co = oracle.sincos(float(x))
+        st, ct = T.sincos(x)
+        assert np.float64(so).tobytes() == np.float64(st).tobytes() and np.float64(co).tobytes() == np.float64(ct).tobytes(), x
+    for trial in range(60):
+        J = rng.normal(size=(40, 6)) * rng.uniform(0.01, 30, size=6)
+        if trial % 5 == 0:
+            J[:, 5] = J[:, 4] * (1 + 1e-7 * rng.normal(size=40))      # nearly dependent columns
+        A, b = J.T @ J, J.T @ rng.normal(size=40)
+        s27 = np.array(sum([list(A[i, i:]) + [b[i]] for i in range(6)], []))
+        xo, oko = oracle.icp_solve(s27)
+        xt, okt = T.icp_solve(s27)
+        assert oko == okt and np.array_equal(xo.view(np.uint32), xt.view(np.uint32)), trial
+    for bad in (np.zeros(27), np.full(27, np.nan), -np.ones(27)):
+        assert not oracle.icp_solve(bad)[1] and not T.icp_solve(bad)[1]
+    acosf = _libm_acosf()
+    pose = hsk.synth_pose(4)
+    for _ in range(40):
+        x6 = (rng.normal(size=6) * [0.01, 0.01, 0.01, 0.005, 0.005, 0.005]).astype(np.float32)
+        po = oracle.pose_update(pose, x6)
+        pt = T.pose_update(pose, x6)
+        assert np.array_equal(po.view(np.uint32), pt.view(np.uint32))
+        pose = po
+
+
+def test_solve_and_sincos_against_exact_rational_arithmetic(oracle):
+    """an anchor that shares no arithmetic with either restatement: the 6x6 system solved in exact rationals, sin / cos
+    from their Taylor series in exact rationals"""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(8)
+    for trial in range(25):
+        J = rng.normal(size=(30, 6))
+        if trial % 4 == 0:
+            J[:, 3] = J[:, 2] + 1e-4 * rng.normal(size=30)             # condition number ~1e8
+        A, b = J.T @ J, J.T @ rng.normal(size=30)
+        s27 = np.array(sum([list(A[i, i:]) + [b[i]] for i in range(6)], []))
+        x, ok = oracle.icp_solve(s27)
+        assert ok
+        M = [[Fr(float(A[min(i, j), max(i, j)])) for j in range(6)] + [Fr(float(b[i]))] for i in range(6)]
+        for c in range(6):                                             # Gauss-Jordan in exact arithmetic
+            p = next(r for r in range(c, 6) if M[r][c] != 0)
+            M[c], M[p] = M[p], M[c]
+            M[c] = [v / M[c][c] for v in M[c]]
+            for r in range(6):
+                if r != c:
+                    M[r] = [vr - M[r][c] * vc for vr, vc in zip(M[r], M[c])]
+        exact = np.array([float(M[i][6]) for i in range(6)])
+        cond = np.linalg.cond(A)
+        assert np.abs(x - exact).max() <= (8 * cond * 2.0 ** -53 + 2.0 ** -24) * np.abs(exact).max(), (trial, cond)
+    for x in list(np.linspace(-0.3, 0.3, 31)) + [1.0, -2.5, 3.0, 6.0]:
+        fx = Fr(float(x))
+        s = sum((-1) ** k * fx ** (2 * k + 1) / Fr(int(np.prod(np.arange(1, 2 * k + 2, dtype=object)))) for k in range(30))
+        c = sum((-1) ** k * fx ** (2 * k) / Fr(int(np.prod(np.arange(1, 2 * k + 1, dtype=object)))) for k in range(30))
+        so, co = oracle.sincos(float(x))
+        assert abs(Fr(so) - s) <= Fr(3, 2 ** 54) and abs(Fr(co) - c) <= Fr(3, 2 ** 54), x
+
+
+def test_twin_gate(oracle, hsk):
+    """the gate's own arithmetic (twin vs the oracle tracker's decisions): repeated frames gate off, moving frames on"""
+    acosf = _libm_acosf()
+    p0, p1 = hsk.synth_pose(0), hsk.synth_pose(1)
+    assert T.gate_passes(p1, p0, 0.004, acosf) and not T.gate_passes(p0, p0, 0.004, acosf) and T.gate_passes(p0, p0, 0.0, acosf)
+    thr = 0.004
+    cfg = small_cfg(oracle, 32)
+    cfg.move_thresh = thr
+    ot = oracle.Tracker(cfg)
+    tt = T.Tracker(32, W, H, FX, FX, CX, CY, move_thresh=thr, acosf=acosf)
+    for k in (0, 1, 1, 2, 3, 3):
+        d = small_depth(hsk, k)
+        po, oko = ot.process(d)
+        pt, okt = tt.process(d)
+        assert oko == okt and np.array_equal(po.view(np.uint32), pt.view(np.uint32)), k
+    assert np.array_equal(ot.volume(), tt.vol)
+    assert 1 < int(tt.vol[..., 1].max()) < 6       # six frames: some integrated, at least one repeat gated off
+
+
+@pytest.mark.parametrize("n,slab", [(32, None), (48, (10, 30, 14, 24))])
+def test_twin_raycast(oracle, hsk, n, slab):
+    cfg = small_cfg(oracle, n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    for k in (0, 4, 8):
+        d = small_depth(hsk, k)
+        oracle.integrate(cfg, vol, oracle.scale_depth(cfg, d), hsk.synth_pose(k))
+    inside = np.array([[0.94, 0, 0.34, 1.2], [0, 1, 0, 1.4], [-0.34, 0, 0.94, 0.6], [0, 0, 0, 1]], np.float32)
+    for pose in (hsk.synth_pose(8), hsk.synth_pose(40), inside):
+        if slab is None:
+            o = oracle.raycast(cfg, vol, pose)
+            t = T.raycast(vol, (3.0, 3.0, 3.0), 0.03, W, H, FX, FX, CX, CY, pose)
+        else:
+            zs0, zs1, zo0, zo1 = slab
+            part = np.ascontiguousarray(vol[zs0:zs1])
+            o = oracle.raycast(cfg, part, pose, zs0=zs0, zo0=zo0, zo1=zo1)
+            t = T.raycast(part, (3.0, 3.0, 3.0), 0.03, W, H, FX, FX, CX, CY, pose, Z=n, zs0=zs0, zo0=zo0, zo1=zo1)
+        assert np.array_equal(o[2], t[2]), "step keys"
+        assert same_bits(o[0], t[0]) and same_bits(o[1], t[1])
+        assert o[3] == t[3] and o[3] > 1000
+        assert (o[2] != 0x7FFFFFFF).mean() > (0.2 if slab is None else 0.01)   # a slab ends only the rays that end in it
+
+
+def test_twin_extract_cloud(oracle, hsk):
+    n = 40
+    cfg = small_cfg(oracle, n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    for k in (0, 5, 10):
+        d = small_depth(hsk, k)
+        oracle.integrate(cfg, vol, oracle.scale_depth(cfg, d), hsk.synth_pose(k))
+    pts, total = oracle.extract_cloud(cfg, vol)
+    tp = T.extract_cloud(vol, (3.0, 3.0, 3.0))
+    assert total == len(tp) > 500 and same_bits(pts, tp)
+
+
+def test_twin_tracker_equals_oracle_tracker(oracle, hsk):
+    """the whole A.2 state machine, twin vs oracle, poses / TSDF / model maps bit for bit (and a lost frame)"""
+    cfg = small_cfg(oracle, 32)
+    ot = oracle.Tracker(cfg)
+    tt = T.Tracker(32, W, H, FX, FX, CX, CY)
+    for k in (0, 2, 4):
+        d = small_depth(hsk, k)
+        po, oko = ot.process(d)
+        pt, okt = tt.process(d)
+        assert oko == okt and np.array_equal(po.view(np.uint32), pt.view(np.uint32)), k
+    assert np.array_equal(ot.volume(), tt.vol)
+    for l in range(3):
+        assert same_bits(ot.model_map(2, l), tt.vmod[l]) and same_bits(ot.model_map(3, l), tt.nmod[l])
+    po, oko = ot.process(np.zeros((H, W), np.uint16))
+    pt, okt = tt.process(np.zeros((H, W), np.uint16))
+    assert not oko and not okt and np.array_equal(po, pt) and not tt.vol.any()
