@@ -88,6 +88,7 @@ SYMBOLS = {
     "hsk_set_profiling": (C.c_int, [_P, C.c_int]),
     "hsk_stage_ms": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
     "hsk_bilateral_tables": (C.c_int, [_F, _F]),
+    "hsk_selftest_exact_ops": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "hsk_synth_pose": (C.c_int, [C.c_int, _F]),
     "hsk_synth_render": (C.c_int, [_F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hsk_synth_room_extents": (C.c_int, [C.c_int, _F]),

@@ -124,6 +124,35 @@ static __device__ __forceinline__ float hsk_div_small_int(float x, int n) {
 // rounding boundary (ties need c to be a power of two, where rc is exact), and the product is within 2^-52 of it.
 static __device__ __forceinline__ float hsk_div_by_const(float x, double rc) { return (float)((double)x * rc); }
 
+// ---- correctly rounded 1/x, sqrt(x) and a/n in a handful of instructions -------------------------------------------
+// The specification asks for the IEEE-754 correctly rounded results; the compiler's sequences for them cost 10-14
+// instructions.  On gfx950 the one-ulp hardware approximations corrected by ONE fused multiply-add step give the same
+// bits -- not by a theorem but by exhaustive comparison on the hardware itself: every binary32 value for 1/x and
+// sqrt(x), every (a, n) pair of the domain for a/n (hsk_selftest_exact_ops; tests/test_gpu_exact_ops.py runs it on
+// the GPU under test, tools/exact/rcp_sqrt_check.hip is the stand-alone form).  The FMAs below are explicit builtins:
+// the translation units are compiled with -ffp-contract=off, nothing else is ever fused.
+//   hsk_rcp_exact : exact for every normal x whose reciprocal is normal              (2^-126 <= |x| <= 2^126)
+//   hsk_sqrt_exact: exact for every x >= 2^-102 (below that the residual underflows)
+//   hsk_div_small_exact: exact for 2^-100 <= |a| < 512 or a = +0, and an integer 1 <= n <= 129 held in a float
+//                        (a = -0 gives +0: immaterial, the quotient is only ever converted to an integer)
+static __device__ __forceinline__ float hsk_rcp_exact(float x) {
+  const float r0 = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, r0, 1.0f);
+  return __builtin_fmaf(r0, e, r0);
+}
+static __device__ __forceinline__ float hsk_sqrt_exact(float x) {
+  const float s0 = __builtin_amdgcn_sqrtf(x);
+  const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+  const float d = __builtin_fmaf(-s0, s0, x);  // exact: s0 is within one ulp of the root
+  return __builtin_fmaf(d, h, s0);
+}
+static __device__ __forceinline__ float hsk_div_small_exact(float a, float n) {
+  const float y = hsk_rcp_exact(n);
+  const float q0 = a * y;
+  const float r = __builtin_fmaf(-q0, n, a);
+  return __builtin_fmaf(r, y, q0);
+}
+
 static __device__ __forceinline__ float hsk_dot3(float ax, float ay, float az, float bx, float by, float bz) {
   return (ax * bx + ay * by) + az * bz;
 }

@@ -150,6 +150,11 @@ int hsk_synchronize(hsk_ctx* k);
 int hsk_set_profiling(hsk_ctx* k, int on);    /* record HIP events around each stage of process_frame */
 int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int reset);
 int hsk_bilateral_tables(float ws[169], float wc[512]);
+/* Exhaustive self-test, on the GPU itself, of the exact-arithmetic shortcuts the kernels use for the specification's
+ * correctly rounded 1/x, sqrt(x) and a/n (hardware approximation + one fused correction step; hsk_dev.h): every binary32
+ * value, every (a, n) pair of the domain.  counts: [0] 1/x values checked, [1] wrong, [2] wrong without the correction
+ * (shows that the comparison bites), [3..5] the same for sqrt, [6] a/n pairs checked, [7] wrong.  About 0.3 s. */
+int hsk_selftest_exact_ops(int device_id, uint64_t counts[8]);
 
 /* Deterministic synthetic depth stream; host-only, no GPU needed. */
 int hsk_synth_pose(int frame, float pose[16]);
