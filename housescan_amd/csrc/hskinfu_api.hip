@@ -385,6 +385,11 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   while (hsk_flag_words(vp) > HSK_FLAG_WORDS_MAX && vp.bshift < 6 && ((vp.X >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.X &&
          ((vp.Y >> (vp.bshift + 1)) << (vp.bshift + 1)) == vp.Y)
     ++vp.bshift;
+  // integrate's queue entries are 28-bit lane-block ids (4 x-voxels x 4 planes) with 4 plane bits on top
+  if ((size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4) >= ((size_t)1 << 28)) {
+    k->err = "hsk_create: volume too large for the 28-bit lane-block ids of integrate (more than 2^32 stored voxels)";
+    return bail(HSK_ERR_ARG);
+  }
   k->flags_bytes = (size_t)hsk_flag_words_total(vp) * 4;  // brick bits + super-brick bits
   // k_raycast stages the whole bitfield in dynamic LDS; a launch may ask for at most 64 KiB of it.  Volumes whose
   // dimensions stop the brick edge from growing (e.g. 1000^3: 125 = 5^3 bricks of 8) would be created fine and then

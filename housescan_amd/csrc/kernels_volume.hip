@@ -24,9 +24,6 @@
 #ifndef INTEGRATE_WPE
 #define INTEGRATE_WPE 6  // waves per SIMD the register allocator must leave room for (79 VGPRs, no spills)
 #endif
-#ifndef INTEGRATE_DETAIL_WPE
-#define INTEGRATE_DETAIL_WPE 7  // pass B works one plane (4 voxels per lane) at a time: <= 72 VGPRs, 7 waves per SIMD
-#endif
 #ifndef INTEGRATE_ZCHUNK
 #define INTEGRATE_ZCHUNK 8
 #endif
@@ -202,107 +199,6 @@ struct IntegrateConst {
   float rk4, zmin4, cull_thr4, free_thr4;  // the same for a 4-plane block (voxels within 2.2 cells of its centre)
 };
 
-// Per-voxel classification of U consecutive planes of one lane column: which of the lane's 4 voxels per plane are
-// rewritten (mask), which of those with F == 1 (one), and F for the others.  Phase by phase, so that the U tile
-// lookups, then the 4U depth gathers, are in flight together; branch-free inside, guarded by wave-uniform ballots;
-// the correctly rounded division / square root of the spec run only for voxels flagged as sitting on a decision
-// boundary (v_rcp_f32 moves a pixel coordinate by < 1.6e-4 px, v_sqrt_f32 moves sdf by < 1e-6 m).
-template <int U>
-static __device__ __forceinline__ void classify_planes(int zz0, const bool* in_range, const ColumnTerms& c,
-                                                       const IntegrateConst& k, const VolParams& vp, int W, int H,
-                                                       const Intr& in, const float2* __restrict__ dtab, int tw, int th,
-                                                       const float* __restrict__ scaled, unsigned* mask, unsigned* one,
-                                                       float (*F)[4]) {
-  // (No per-plane tile test here: the entries of pass B's queues are lane-blocks that two levels of tile tests could
-  // not decide, so a third one on their planes almost never does -- measured: dropping it took 6 us off the stage at
-  // 512^3 and 27 us at 1024^3.  Every in-range plane goes through the exact per-voxel path, which decides the same.)
-  float gz2[U], gzv[U];
-  unsigned detail = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const float gz = ((float)(vp.zs0 + zz0 + u) + 0.5f) * vp.cell[2] - k.tz;
-    gzv[u] = gz;
-    gz2[u] = gz * gz;
-    mask[u] = one[u] = 0u;
-    detail |= (in_range[u] ? 1u : 0u) << u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) F[u][j] = 0.0f;
-  }
-  if (__ballot(detail != 0) == 0ull) return;
-  int pix[U][4];
-  unsigned nearb = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {  // phase 1
-    const bool lv = (detail >> u) & 1u;
-    const float bx = k.i02 * gzv[u], by = k.i12 * gzv[u], bz = k.i22 * gzv[u];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float camz = c.az[j] + bz;
-      const float inv_a = __builtin_amdgcn_rcpf(camz);
-      const float fu = ((c.ax[j] + bx) * in.fx) * inv_a + in.cx;
-      const float fv = ((c.ay[j] + by) * in.fy) * inv_a + in.cy;
-      const float ru = rintf(fu), rv = rintf(fv);
-      const int uu = (int)ru, vv = (int)rv;
-      const bool front = lv && camz > 0.0f && fabsf(fu) < 1.0e5f && fabsf(fv) < 1.0e5f;
-      const bool inb = front && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
-      const bool nb = front && fmaxf(fabsf(fu - ru), fabsf(fv - rv)) > 0.5f - 3.0e-4f;
-      pix[u][j] = inb ? vv * W + uu : -1;
-      nearb |= (nb ? 1u : 0u) << (u * 4 + j);
-    }
-  }
-  if (nearb) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float bx = k.i02 * gzv[u], by = k.i12 * gzv[u], bz = k.i22 * gzv[u];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (nearb & (1u << (u * 4 + j))) {
-          const float inv_z = 1.0f / (c.az[j] + bz);
-          const float fu = ((c.ax[j] + bx) * in.fx) * inv_z + in.cx;
-          const float fv = ((c.ay[j] + by) * in.fy) * inv_z + in.cy;
-          int uu, vv;
-          pix[u][j] = (hsk_rint_guard(fu, uu) && hsk_rint_guard(fv, vv) && uu >= 0 && vv >= 0 && uu < W && vv < H) ? vv * W + uu
-                                                                                                                : -1;
-        }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u)  // phase 2: all gathers in flight
-#pragma unroll
-    for (int j = 0; j < 4; ++j) F[u][j] = scaled[max(pix[u][j], 0)];
-  unsigned unsure = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u)  // phase 2b
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float Ds = F[u][j];
-      const float sdf_a = Ds - __builtin_amdgcn_sqrtf(gz2[u] + c.pn[j]);
-      const bool val = pix[u][j] >= 0 && Ds != 0.0f;
-      const bool sure = val && sdf_a * vp.tau_inv > 1.0001f;
-      const bool maybe = val && !sure && sdf_a >= -vp.tau - 2.0e-6f;
-      mask[u] |= (sure ? 1u : 0u) << j;
-      one[u] |= (sure ? 1u : 0u) << j;
-      unsure |= (maybe ? 1u : 0u) << (u * 4 + j);
-    }
-  if (unsure) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (unsure & (1u << (u * 4 + j))) {
-          const float sdf = F[u][j] - sqrtf(gz2[u] + c.pn[j]);
-          if (sdf >= -vp.tau) {
-            const float f = sdf * vp.tau_inv;
-            mask[u] |= 1u << j;
-            if (f < 1.0f)
-              F[u][j] = f;
-            else
-              one[u] |= 1u << j;
-          }
-        }
-  }
-}
-
 static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]);
 
 // A voxel (x, y, stored plane zz) has just been given a negative TSDF: set its brick's bit and, the first time, its
@@ -384,6 +280,157 @@ static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, un
   }
   q = make_uint4(w4[0], w4[1], w4[2], w4[3]);
   return neg;
+}
+
+// wave-uniform constants of the per-voxel path: the pose (world -> camera rows) of the frame
+struct DetailPose {
+  float tx, ty, tz;
+  float i00, i01, i02, i10, i11, i12, i20, i21, i22;
+};
+static __device__ __forceinline__ DetailPose detail_pose(const TrackState* __restrict__ st) {
+  DetailPose p;
+  p.tx = st->t[0]; p.ty = st->t[1]; p.tz = st->t[2];
+  p.i00 = st->R[0]; p.i01 = st->R[3]; p.i02 = st->R[6];
+  p.i10 = st->R[1]; p.i11 = st->R[4]; p.i12 = st->R[7];
+  p.i20 = st->R[2]; p.i21 = st->R[5]; p.i22 = st->R[8];
+  return p;
+}
+
+// One lane-block (4 x-voxels at x0, row y, stored planes zb .. zb + 3) through the per-voxel path, U planes per trip.
+// `planes`: bit u set = plane zb + u lies in the lane's z range (0: the lane holds no entry and idles inside the
+// wave-uniform branches).  Returns the voxels rewritten.
+template <bool COUNT_ONLY, int U>
+static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0, int y, int zb, uint4* __restrict__ vol,
+                                                        const float* __restrict__ scaled, const DetailPose& P,
+                                                        const VolParams& vp, int W, int H, const Intr& in,
+                                                        unsigned* __restrict__ flags) {
+  static_assert(U == 1 || U == 2 || U == 4, "planes per trip");
+  const int lane = threadIdx.x & 63;
+  (void)lane;
+  const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
+  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
+  unsigned cnt = 0;
+  float ax[4], ay[4], az[4], pn[4];
+  const float gy = ((float)y + 0.5f) * vp.cell[1] - P.ty;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - P.tx;
+    ax[j] = P.i00 * gx + P.i01 * gy;
+    ay[j] = P.i10 * gx + P.i11 * gy;
+    az[j] = P.i20 * gx + P.i21 * gy;
+    pn[j] = gx * gx + gy * gy;
+  }
+  const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
+#pragma unroll
+  for (int h0 = 0; h0 < 4; h0 += U) {
+    bool inr[U];
+    bool any_in = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      inr[u] = ((planes >> (h0 + u)) & 1u) != 0u;
+      any_in = any_in || inr[u];
+    }
+    if (__ballot(any_in) == 0ull) continue;
+    // 1. the volume vectors of the trip: in flight while the projections run
+    uint4 q[U];
+    if (!COUNT_ONLY) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        q[u] = make_uint4(0u, 0u, 0u, 0u);
+#ifndef HSK_EXPB_NOVOL  // timing experiment: no volume traffic (results wrong)
+        if (inr[u]) q[u] = vol[idx0 + (size_t)(zb + h0 + u) * plane_vec];
+#endif
+      }
+    }
+    // 2. projection of the 4U voxel centres (A.4, exact), then their depth gathers
+    float D[U][4];  // scaled depth at the voxel's pixel, 0 when it has none; afterwards the observation F
+    float gz2[U];
+    int pix[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float gz = ((float)(vp.zs0 + zb + h0 + u) + 0.5f) * vp.cell[2] - P.tz;
+      const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
+      gz2[u] = gz * gz;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float camz = az[j] + bz;
+        const float inv_z = hsk_rcp_exact(camz);
+        const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
+        const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
+        // (|f| >= 1e6 of the specification's guard: the conversion saturates far beyond W and H, the bound test rejects it)
+        const int uu = (int)rintf(fu), vv = (int)rintf(fv);
+        const bool ok = inr[u] && camz >= 1.17549435e-38f && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
+        pix[u][j] = ok ? vv * W + uu : -1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+#ifdef HSK_EXPB_NOGATHER  // timing experiment: coalesced loads instead of the gathers (results wrong)
+      for (int j = 0; j < 4; ++j) D[u][j] = scaled[(u * 4 + j) * 64 + lane];
+#else
+      for (int j = 0; j < 4; ++j) D[u][j] = scaled[max(pix[u][j], 0)];
+#endif
+    // 3. the observation: F in [-1, 1] for a voxel the rule rewrites, -4 for one it leaves alone
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float Ds = pix[u][j] >= 0 ? D[u][j] : 0.0f;
+        const float sdf = Ds - hsk_sqrt_exact(gz2[u] + pn[j]);
+        const float f = sdf * vp.tau_inv;
+        D[u][j] = (Ds != 0.0f && sdf >= -vp.tau) ? (f < 1.0f ? f : 1.0f) : -4.0f;
+      }
+    if (COUNT_ONLY) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cnt += D[u][j] > -2.0f ? 1u : 0u;
+      continue;
+    }
+    // 4. running mean, repack, store
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+      unsigned nw[4];
+      bool gen[4], gen_any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool upd = D[u][j] > -2.0f;
+        const bool unseen = (w4[j] >> 16) == 0u;
+        // free space (F == 1) onto a stored +1, or onto an unseen voxel: the mean is +1 exactly, only the weight moves
+        const bool simple = D[u][j] == 1.0f && (unseen || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR);
+        const unsigned ws = unseen ? (0x10000u | (unsigned)HSK_DIVISOR) : min(w4[j] + 0x10000u, cap);
+        nw[j] = (upd && simple) ? ws : w4[j];
+        gen[j] = upd && !simple;
+        gen_any = gen_any || gen[j];
+      }
+      bool neg = false;
+      if (__ballot(gen_any) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int tp = (int)(short)(w4[j] & 0xffffu);
+          const unsigned wp = w4[j] >> 16;
+          const float Wp = (float)wp;
+          const float Fn = hsk_div_small_exact(hsk_tsdf_unpack(tp) * Wp + D[u][j], Wp + 1.0f);
+          int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
+          fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
+          const unsigned wg = ((unsigned)fixed & 0xffffu) | (min(wp + 1u, (unsigned)HSK_MAX_WEIGHT) << 16);
+          nw[j] = gen[j] ? wg : nw[j];
+          neg = neg || (gen[j] && fixed < 0);
+        }
+      }
+#ifndef HSK_EXPB_NOVOL
+      // (saturated free space -- +1 at the weight cap -- comes back unchanged: no store)
+      if (nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3])
+        vol[idx0 + (size_t)(zb + h0 + u) * plane_vec] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+      if (neg) mark_brick_negative(flags, vp, x0, y, zb + h0 + u);
+#else
+      if ((nw[0] ^ nw[1] ^ nw[2] ^ nw[3]) == 0x12345u || neg) vol[idx0] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+#endif
+    }
+  }
+  return cnt;
 }
 
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
@@ -478,12 +525,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     // through 6 resident slots per SIMD in about eleven rounds).
     static_assert(INTEGRATE_ZCHUNK <= 8, "pass A's staged loop handles at most two groups of 4 planes per wave");
     constexpr int NS = 2;
+    const int zb0 = wl & ~3;
     int zbs[NS];
     bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS];
     float dc_s[NS];
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
-      zbs[sidx] = (wl & ~3) + 4 * sidx;
+      zbs[sidx] = zb0 + 4 * sidx;
       actv[sidx] = zbs[sidx] <= wh;  // wave-uniform
       free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
       dc_s[sidx] = 0.0f;
@@ -559,6 +607,26 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       other_s[sidx] = other_s[sidx] && !dead2 && !free2;
     }
 #endif
+    // ---- stage 4: wave-aggregated append of the uncertain lane-blocks: one of HSK_NQUEUES queues (a single counter
+    // saturates at ~88 atomics/us chip-wide).  The queue must NOT follow the block's x-y position: surfaces cluster in a
+    // few columns, and pass B's time is its longest queue.  Rotate the assignment by the row of HSK_NQUEUES blocks and by
+    // the wave: within a row it stays a bijection, so every queue still receives at most one wave-quarter of one block
+    // per row and wave index (the capacity bound).  Both groups' tickets are requested before either is used.
+#ifndef HSK_EXPA_NO_QUEUE
+    // (the tickets are REQUESTED here, before the free-space loads, and used after the stores: the counters' round trip
+    // runs under the volume's -- one dependent round trip less in a wave's life)
+    const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
+    unsigned long long bo[NS];
+    unsigned base[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      bo[sidx] = actv[sidx] ? __ballot(other_s[sidx]) : 0ull;
+      base[sidx] = 0;
+      if (bo[sidx] != 0ull && lane == (int)__builtin_ctzll(bo[sidx]))
+        base[sidx] = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo[sidx]));
+    }
+#endif
     // ---- stage 3: deep free space -- four batched vector updates per group, the loads of both groups in flight together
 #ifndef HSK_EXPA_NO_FREE
     if (COUNT_ONLY) {
@@ -600,31 +668,18 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       }
     }
 #endif
-    // ---- stage 4: wave-aggregated append of the uncertain lane-blocks: one of HSK_NQUEUES queues (a single counter
-    // saturates at ~88 atomics/us chip-wide).  The queue must NOT follow the block's x-y position: surfaces cluster in a
-    // few columns, and pass B's time is its longest queue.  Rotate the assignment by the row of HSK_NQUEUES blocks and by
-    // the wave: within a row it stays a bijection, so every queue still receives at most one wave-quarter of one block
-    // per row and wave index (the capacity bound).  Both groups' tickets are requested before either is used.
 #ifndef HSK_EXPA_NO_QUEUE
-    {
-      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
-      unsigned long long bo[NS];
-      unsigned base[NS];
 #pragma unroll
-      for (int sidx = 0; sidx < NS; ++sidx) {
-        bo[sidx] = actv[sidx] ? __ballot(other_s[sidx]) : 0ull;
-        base[sidx] = 0;
-        if (bo[sidx] != 0ull && lane == (int)__builtin_ctzll(bo[sidx]))
-          base[sidx] = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo[sidx]));
-      }
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      if (bo[sidx] == 0ull) continue;
+      const unsigned b0 = (unsigned)__shfl((int)base[sidx], (int)__builtin_ctzll(bo[sidx]), 64);
+      if (other_s[sidx]) {
+        // the entry: lane-block id, and (when it fits: id_mask_shift != 0) which of its 4 planes lie in the lane's z range
+        unsigned pm = 0u;
 #pragma unroll
-      for (int sidx = 0; sidx < NS; ++sidx) {
-        if (bo[sidx] == 0ull) continue;
-        const unsigned b0 = (unsigned)__shfl((int)base[sidx], (int)__builtin_ctzll(bo[sidx]), 64);
-        if (other_s[sidx])
-          queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] =
-              (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
+        for (int u = 0; u < 4; ++u) pm |= ((zbs[sidx] + u >= zl && zbs[sidx] + u <= zh) ? 1u : 0u) << u;
+        const unsigned id = (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
+        queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] = id | (pm << 28);
       }
     }
 #endif
@@ -636,132 +691,65 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
   }
 }
 
-#ifdef HSK_INT_TIMING
-// timing build (tools/int_timing.sh): s_memrealtime stamps (start, end, entries) of every wave of pass B
-__device__ unsigned long long g_detail_times[8192 * 3];
-extern "C" int hsk_debug_detail_times(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_detail_times), (size_t)n * 8);
-}
+// ------------------------------------------------------------------------------------------------------
+// Pass B (second form, round 2): the queued lane-blocks, per-voxel path -- built round three facts measured on round 1's
+// form (profiles/r01/final_pmc_summary.txt, profiles/r02/integrate_analysis.md):
+// it spent half its wave cycles parked on memory and a quarter of its instructions on branches and lane-mask
+// bookkeeping (171 basic blocks, 535 s_and/s_or, 37 spilled SGPRs), all of it in service of "approximate first, exact
+// where a decision is close".  With hsk_rcp_exact / hsk_sqrt_exact / hsk_div_small_exact the specification's correctly
+// rounded operations cost 3 / 5 / 6 instructions, so every voxel simply takes the exact path: no decision-boundary
+// tests, no fallback loops.  The U planes of a trip issue their volume vectors FIRST (their addresses need only the
+// queue entry), then the 4U depth gathers, so both round trips overlap the projection arithmetic.  Two wave-uniform
+// branches remain per plane: the general running mean (skipped when every rewritten voxel of the wave is free space
+// onto a stored +1 or an unseen voxel: saturating add on the packed word) and the store (skipped when nothing changed).
+// Domain of the shortcuts: hsk_rcp_exact needs a normal camz -- the specification itself asks for camz >= FLT_MIN
+// (deviation D6: a voxel whose camera-space depth is a denormal number counts as not in front of the camera); a huge
+// reciprocal makes the pixel coordinate overflow the image bounds, as the specification's 1e6 guard does.  The root
+// of a value below 2^-102 is inexact but finite and far below half an ulp of any non-zero depth, so sdf is unaffected;
+// the root of 0 (voxel centre ON the camera centre: NaN from the shortcut) belongs to a voxel with camz = 0.
+// ------------------------------------------------------------------------------------------------------
+#ifndef DETAIL2_U
+#define DETAIL2_U 4
 #endif
-// Pass B of integrate: the queued (uncertain) lane-blocks, one per lane, four planes each, per-voxel path.
+#ifndef DETAIL2_WPE
+#define DETAIL2_WPE 5
+#endif
+#ifndef DETAIL2_GX
+#define DETAIL2_GX 5  // DETAIL2_GX x 256 queues x 4 waves: one resident round of the chip at 8 waves per SIMD
+#endif
+
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256, INTEGRATE_DETAIL_WPE) void k_integrate_detail(uint4* __restrict__ vol,
-                                                                         const float* __restrict__ scaled,
-                                                                         const TrackState* __restrict__ st, VolParams vp,
-                                                                         int W, int H, Intr in,
-                                                                         unsigned long long* __restrict__ counter,
-                                                                         unsigned* __restrict__ flags,
-                                                                         const float2* __restrict__ dtab, int tw, int th,
-                                                                         const int2* __restrict__ zint,
-                                                                         const unsigned* __restrict__ queue_all,
-                                                                         const unsigned* __restrict__ qcount,
-                                                                         unsigned qcap) {
+__global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* __restrict__ vol, const float* __restrict__ scaled,
+                                                                        const TrackState* __restrict__ st, VolParams vp, int W,
+                                                                        int H, Intr in, unsigned long long* __restrict__ counter,
+                                                                        unsigned* __restrict__ flags,
+                                                                        const int2* __restrict__ zint,
+                                                                        const unsigned* __restrict__ queue_all,
+                                                                        const unsigned* __restrict__ qcount, unsigned qcap) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
-#ifdef HSK_INT_TIMING
-  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-  unsigned my_entries = 0;
-#endif
-  // blockIdx.y = queue, blockIdx.x = one of gridDim.x blocks striding over it
   const unsigned n = qcount[blockIdx.y * HSK_QCOUNT_STRIDE];
   const unsigned* __restrict__ queue = queue_all + (size_t)blockIdx.y * qcap;
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned long long cnt = 0;
-  const float tx = st->t[0], ty = st->t[1];
-  const float i00 = st->R[0], i01 = st->R[3], i10 = st->R[1], i11 = st->R[4], i20 = st->R[2], i21 = st->R[5];
-  IntegrateConst k;
-  k.i02 = st->R[6];
-  k.i12 = st->R[7];
-  k.i22 = st->R[8];
-  k.tz = st->t[2];
-  const float cellm = fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2]));
-  k.rk = 1.06f * 2.75f * cellm * fmaxf(in.fx, in.fy);
-  k.zmin = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk / ((float)HSK_TILE - 2.5f));
-  k.cull_thr = vp.tau * 1.001f + 1e-4f + 2.0f * vp.cell[0];
-  k.free_thr = vp.tau * 1.0002f + 1e-4f + 2.0f * vp.cell[0];
-  k.hw = 0.5f * (float)(W - 1);
-  k.hh = 0.5f * (float)(H - 1);
-  k.rk4 = k.zmin4 = k.cull_thr4 = k.free_thr4 = 0.0f;  // unused here
+  const DetailPose P = detail_pose(st);
   const int qx = vp.X / 4;
-  const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
-  for (unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < n; e0 += stride) {  // wave-uniform trip count
-    const unsigned e = e0 + lane;
-    const bool have = e < n;
-#ifdef HSK_INT_TIMING
-    my_entries += (n - e0 < 64u ? n - e0 : 64u);
-#endif
-    const unsigned id = have ? queue[e] : 0u;
-    const int x0 = (int)(id % (unsigned)qx) * 4, y = (int)((id / (unsigned)qx) % (unsigned)vp.Y);
-    const int zb = (int)(id / ((unsigned)qx * (unsigned)vp.Y)) * 4;
-    const int2 zr = zint[(size_t)y * qx + (x0 >> 2)];
-    ColumnTerms c;
-    {
-      const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
-        c.ax[j] = i00 * gx + i01 * gy;
-        c.ay[j] = i10 * gx + i11 * gy;
-        c.az[j] = i20 * gx + i21 * gy;
-        c.pn[j] = gx * gx + gy * gy;
-      }
-      c.axfc = 0.5f * (c.ax[1] + c.ax[2]) * in.fx;
-      c.ayfc = 0.5f * (c.ay[1] + c.ay[2]) * in.fy;
-      c.azc = 0.5f * (c.az[1] + c.az[2]);
-      c.pnc = 0.5f * (c.pn[1] + c.pn[2]);
-    }
-    const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
-#ifndef DETAIL_U
-#define DETAIL_U 1  // planes of an entry classified and updated together.  Measured 512^3 / 1024^3 (us, with the matching
-                    // occupancy and one resident round of blocks): U = 4 at 4 waves per SIMD 141 / 945, U = 2 at 5: 126 / 876,
-                    // U = 1 at 6: 120 / 858, U = 1 at 7: 119 / 838 -- resident waves hide the gathers better than batching
-#endif
-#pragma unroll
-    for (int h0 = 0; h0 < 4; h0 += DETAIL_U) {
-      bool in_range[DETAIL_U];
-      unsigned mask[DETAIL_U], one[DETAIL_U];
-      float F[DETAIL_U][4];
-#pragma unroll
-      for (int u = 0; u < DETAIL_U; ++u)
-        in_range[u] = have && (zb + h0 + u) >= zr.x && (zb + h0 + u) <= zr.y && (zb + h0 + u) < vp.nzs;
-      classify_planes<DETAIL_U>(zb + h0, in_range, c, k, vp, W, H, in, dtab, tw, th, scaled, mask, one, F);
-      if (COUNT_ONLY) {
-#pragma unroll
-        for (int u = 0; u < DETAIL_U; ++u) cnt += __popc(mask[u]);
-        continue;
-      }
-      uint4 q[DETAIL_U];
-#pragma unroll
-      for (int u = 0; u < DETAIL_U; ++u)
-        if (mask[u]) q[u] = vol[idx0 + (size_t)(zb + h0 + u) * plane_vec];
-#pragma unroll
-      for (int u = 0; u < DETAIL_U; ++u) {
-        if (!mask[u]) continue;
-        const int zz = zb + h0 + u;
-        const uint4 before = q[u];
-        const bool neg = update_vector(q[u], mask[u], one[u], F[u]);
-        // saturated free space (+1 at the weight cap) comes back unchanged: no store
-        if (q[u].x != before.x || q[u].y != before.y || q[u].z != before.z || q[u].w != before.w)
-          vol[idx0 + (size_t)zz * plane_vec] = q[u];
-        if (neg) mark_brick_negative(flags, vp, x0, y, zz);
-      }
-    }
+  // the entry of the NEXT trip is fetched while the current one is worked on (its address needs nothing but the trip index)
+  unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+  unsigned id_next = (e0 + lane < n) ? queue[e0 + lane] : 0u;
+  for (; e0 < n; e0 += stride) {  // wave-uniform trip count
+    const unsigned id = id_next;
+    id_next = (e0 + stride + lane < n) ? queue[e0 + stride + lane] : 0u;
+    const unsigned lb = id & 0x0fffffffu;
+    const int x0 = (int)(lb % (unsigned)qx) * 4, y = (int)((lb / (unsigned)qx) % (unsigned)vp.Y);
+    const int zb = (int)(lb / ((unsigned)qx * (unsigned)vp.Y)) * 4;
+    cnt += detail_entry<COUNT_ONLY, DETAIL2_U>(id >> 28, x0, y, zb, vol, scaled, P, vp, W, H, in, flags);
   }
   if (COUNT_ONLY) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
     if (lane == 0 && cnt) atomicAdd(counter, cnt);
   }
-#ifdef HSK_INT_TIMING
-  if (!COUNT_ONLY && lane == 0) {
-    const unsigned w = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
-    if (w < 8192) {
-      g_detail_times[w * 3] = t_start;
-      g_detail_times[w * 3 + 1] = __builtin_amdgcn_s_memrealtime();
-      g_detail_times[w * 3 + 2] = my_entries;
-    }
-  }
-#endif
 }
 
 // fine (8-px) tile table: depends only on the depth frame, so it belongs to the preprocessing
@@ -795,20 +783,17 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
   const unsigned nblk = grid.x * grid.y * grid.z;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
-#ifndef DETAIL_GX
-#define DETAIL_GX 7  // 7 x 256 queues x 4 waves = one resident round of the chip at 7 waves per SIMD
-#endif
-  const dim3 detail_grid(DETAIL_GX, HSK_NQUEUES);  // DETAIL_GX blocks stride over each queue
+  const dim3 detail_grid(DETAIL2_GX, HSK_NQUEUES);  // DETAIL2_GX blocks stride over each queue
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, (double*)nullptr);
-    hipLaunchKernelGGL(k_integrate_detail<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
+    hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
+                       flags, zint, qdata, qcount, qcap);
   } else {
     hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, fin.slots);
-    hipLaunchKernelGGL(k_integrate_detail<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       counter, flags, dil, tw, th, zint, qdata, qcount, qcap);
+    hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
+                       flags, zint, qdata, qcount, qcap);
   }
 }
 

@@ -117,7 +117,7 @@ uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], flo
         const float camx = (i00 * gx + i01 * gy) + i02 * gz;
         const float camy = (i10 * gx + i11 * gy) + i12 * gz;
         const float camz = (i20 * gx + i21 * gy) + i22 * gz;
-        if (!(camz > 0.0f)) continue;
+        if (!(camz >= 1.17549435e-38f)) continue; /* in front of the camera (D6: a denormal depth counts as not in front) */
         const float inv_z = 1.0f / camz;
         const float fu = (camx * fx) * inv_z + cx;
         const float fv = (camy * fy) * inv_z + cy;

@@ -41,7 +41,7 @@ def _integrate(vol, size, trunc, scaled, fx, fy, cx, cy, pose, zs0, Z=None):
     gz = (z + f32(0.5)) * cell[2] - t[2]
     cam = [(Ri[i, 0] * gx + Ri[i, 1] * gy) + Ri[i, 2] * gz for i in range(3)]
     with np.errstate(all="ignore"):
-        front = cam[2] > 0
+        front = cam[2] >= f32(1.17549435e-38)       # D6: a denormal camera-space depth counts as not in front
         inv_z = f32(1) / cam[2]
         fu = (cam[0] * f32(fx)) * inv_z + f32(cx)
         fv = (cam[1] * f32(fy)) * inv_z + f32(cy)
