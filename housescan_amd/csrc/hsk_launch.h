@@ -7,6 +7,7 @@
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
                       const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr);
+size_t integrate_queue_words(const VolParams& vp);
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);

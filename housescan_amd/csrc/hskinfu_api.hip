@@ -342,7 +342,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     CK(hipMalloc((void**)&b.d_raw, P0 * 2));
     CK(hipMalloc((void**)&b.d_scaled, P0 * 4));
     CK(hipMalloc((void**)&b.d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4 +
-                                    (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8));
+                                    (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8 * 5));  // 8-px table + 4-px table (4x)
     for (int l = 0; l < HSK_NLEVELS; ++l) {
       const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
       CK(hipMalloc((void**)&b.d_dep[l], P * 2));
@@ -399,13 +399,8 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     return bail(HSK_ERR_ARG);
   }
   CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
-  // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of the pass-A
-  // blocks (64 x 16 voxels x 8 planes per block -> 512 lane-blocks); see launch_integrate
-  {
-    const size_t nblk = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16) * ((vp.nzs + 7) / 8);
-    const size_t qcap = ((nblk + 255) / 256) * 512;
-    CK(hipMalloc((void**)&k->d_queue, (256 * 64 + 256 * qcap) * sizeof(unsigned)));
-  }
+  // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of pass A's tiles
+  CK(hipMalloc((void**)&k->d_queue, integrate_queue_words(vp) * sizeof(unsigned)));
   CK(hipMalloc((void**)&k->d_zint, (size_t)(vp.X / 4) * vp.Y * sizeof(int2)));
   CK(hipMalloc((void**)&k->d_counter, 16));
   {

@@ -59,20 +59,32 @@ void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* ti
   hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tiles, tiles + n, tw);
 }
 
-// Fine tile table for the second classification level: per 8x8-pixel tile (max, min-if-all-valid) of the scaled
-// depth, NOT dilated (the lookup covers the exact pixel box of a voxel block).  One thread per tile.
+// Fine tile tables for the second classification level: per 8x8-pixel tile and per 4x4-pixel tile the (max,
+// min-if-all-valid) of the scaled depth, NOT dilated (the lookup covers the exact pixel box of a voxel block; the finer
+// table serves the blocks whose box spans at most 3 x 3 of its tiles -- most of them from about a metre on).  One thread
+// per 8-px tile; it writes its four 4-px quadrants too (qtab: 2 fw x 2 fh tiles).
 #define HSK_FTILE 8
-__global__ void k_tile_fine(const float* __restrict__ scaled, int W, int H, float2* __restrict__ ftab, int fw, int fh) {
+__global__ void k_tile_fine(const float* __restrict__ scaled, int W, int H, float2* __restrict__ ftab, int fw, int fh,
+                            float2* __restrict__ qtab) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= fw * fh) return;
   const int ty = t / fw, tx = t - ty * fw;
   float mx = 0.0f, mn = 1e30f;
-  for (int dy = 0; dy < HSK_FTILE; ++dy)
-    for (int dx = 0; dx < HSK_FTILE; ++dx) {
-      const int x = tx * HSK_FTILE + dx, y = ty * HSK_FTILE + dy;
-      const float v = (x < W && y < H) ? scaled[(size_t)y * W + x] : 0.0f;  // outside the image: never "all valid"
-      mx = fmaxf(mx, v);
-      mn = fminf(mn, v);
+#pragma unroll
+  for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+    for (int qx = 0; qx < 2; ++qx) {
+      float qmx = 0.0f, qmn = 1e30f;
+      for (int dy = 0; dy < 4; ++dy)
+        for (int dx = 0; dx < 4; ++dx) {
+          const int x = tx * HSK_FTILE + qx * 4 + dx, y = ty * HSK_FTILE + qy * 4 + dy;
+          const float v = (x < W && y < H) ? scaled[(size_t)y * W + x] : 0.0f;  // outside the image: never "all valid"
+          qmx = fmaxf(qmx, v);
+          qmn = fminf(qmn, v);
+        }
+      qtab[(size_t)(2 * ty + qy) * (2 * fw) + (2 * tx + qx)] = make_float2(qmx, qmn);
+      mx = fmaxf(mx, qmx);
+      mn = fminf(mn, qmn);
     }
   ftab[t] = make_float2(mx, mn);
 }
@@ -191,12 +203,14 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
 struct ColumnTerms {
   float ax[4], ay[4], az[4], pn[4];  // (R^T (gx, gy, 0)) per voxel and gx^2 + gy^2
   float axfc, ayfc, azc, pnc;        // group centre: x/y terms pre-multiplied by fx/fy
+  float pn_lo, pn_hi;                // smallest / largest gx^2 + gy^2 over the lane's x range (not only at its 4 centres)
 };
 // wave-uniform constants of the launch
 struct IntegrateConst {
   float i02, i12, i22, tz;
   float rk, zmin, cull_thr, free_thr, hw, hh;
   float rk4, zmin4, cull_thr4, free_thr4;  // the same for a 4-plane block (voxels within 2.2 cells of its centre)
+  float cull_thr2, free_thr2;              // second level: against the block's exact distance range (no cell margin)
 };
 
 static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]);
@@ -433,6 +447,19 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
   return cnt;
 }
 
+#ifdef HSK_PA_TIMING
+// timing build (tools/pa_timing.sh): per wave of pass A, s_memrealtime stamps (100 MHz) at the phase boundaries, the
+// hardware slot it ran in and what it had to do
+__device__ unsigned long long g_pa_times[65536 * 8];
+extern "C" int hsk_debug_pa_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pa_times), (size_t)n * 8);
+}
+#define PA_STAMP(k) do { if (!COUNT_ONLY && lane == 0 && pa_wave < 65536u) g_pa_times[pa_wave * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#elif defined(HSK_PA_MARKS)
+#define PA_STAMP(k) asm volatile("s_nop 0 ; PA_MARK_" #k ::: "memory")  // static instruction census (tools/pa_census.sh)
+#else
+#define PA_STAMP(k) do { } while (0)
+#endif
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
                                                    int tw, int th, const int2* __restrict__ zint,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
-                                                   double* __restrict__ icp_slot0) {
+                                                   const float2* __restrict__ qtab, double* __restrict__ icp_slot0) {
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
   // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
   if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -450,8 +477,19 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // dtab: per 16x16-pixel tile (max, min-if-all-valid) of the scaled depth, 3x3-dilated.  It is 9.6 KB and stays
   // hot in every CU's vector L1; staging it in LDS per workgroup cost ~2.5 us of each short-lived block's life.
+#ifdef HSK_EXPA_EXTRA_IDLE  // timing experiment: as many extra waves again that exit at once (what does a launch cost?)
+  if ((int)blockIdx.z * zchunk >= vp.nzs) return;
+#endif
   const int lane = threadIdx.x;
   if (!COUNT_ONLY && st->lost) return;
+#ifdef HSK_PA_TIMING
+  const unsigned pa_wave = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4u + threadIdx.y);
+  if (!COUNT_ONLY && lane == 0 && pa_wave < 65536u) {
+    for (int q = 0; q < 8; ++q) g_pa_times[pa_wave * 8 + q] = 0ull;
+    g_pa_times[pa_wave * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
+#endif
+  PA_STAMP(0);
   // wave footprint: 64 voxels in x (16 lanes x 16 B = 256 contiguous bytes) by 4 rows in y -- compact, so
   // that the wave-uniform z range and the group classification reject whole planes, not just lanes
   const int x0 = (blockIdx.x * 16 + (lane & 15)) * 4;
@@ -472,6 +510,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     wl = min(wl, __shfl_xor(wl, o, 64));
     wh = max(wh, __shfl_xor(wh, o, 64));
   }
+  PA_STAMP(1);
   if (wl <= wh) {
     const float tx = st->t[0], ty = st->t[1];
     // Rinv = R^T
@@ -494,6 +533,8 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     k.zmin4 = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk4 / ((float)HSK_TILE - 2.5f));
     k.cull_thr4 = vp.tau * 1.001f + 1e-4f + 2.3f * cellm;
     k.free_thr4 = vp.tau * 1.0002f + 1e-4f + 2.3f * cellm;
+    k.cull_thr2 = vp.tau * 1.001f + 1e-4f;
+    k.free_thr2 = vp.tau * 1.0002f + 1e-4f;
     ColumnTerms c;
     {
       const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
@@ -509,6 +550,11 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       c.ayfc = 0.5f * (c.ay[1] + c.ay[2]) * in.fy;
       c.azc = 0.5f * (c.az[1] + c.az[2]);
       c.pnc = 0.5f * (c.pn[1] + c.pn[2]);
+      {
+        const float gx0 = ((float)x0 + 0.5f) * vp.cell[0] - tx, gx3 = ((float)(x0 + 3) + 0.5f) * vp.cell[0] - tx;
+        c.pn_hi = fmaxf(c.pn[0], c.pn[3]);
+        c.pn_lo = (gx0 <= 0.0f && gx3 >= 0.0f) ? gy * gy : fminf(c.pn[0], c.pn[3]);
+      }
     }
     const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
     const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
@@ -523,8 +569,8 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     // dependent memory round trips (tile table -> fine tile table -> volume -> queue counter); stage by stage over both
     // groups the chain is four trips long instead of eight, and pass A is bound by exactly that (its 65 k waves pass
     // through 6 resident slots per SIMD in about eleven rounds).
-    static_assert(INTEGRATE_ZCHUNK <= 8, "pass A's staged loop handles at most two groups of 4 planes per wave");
-    constexpr int NS = 2;
+    static_assert(INTEGRATE_ZCHUNK % 4 == 0 && INTEGRATE_ZCHUNK <= 16, "pass A stages the chunk's groups of 4 planes together");
+    constexpr int NS = INTEGRATE_ZCHUNK / 4;
     const int zb0 = wl & ~3;
     int zbs[NS];
     bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS];
@@ -536,6 +582,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
       dc_s[sidx] = 0.0f;
     }
+    PA_STAMP(6);
     // ---- stage 1: first level (16-px dilated tile table)
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
@@ -560,6 +607,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       free44_s[sidx] = free44;
       other_s[sidx] = in_any && !dead4 && !free44;
     }
+    PA_STAMP(2);
     // ---- stage 2: second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
     //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
     //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
@@ -587,24 +635,47 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         vmax = fmaxf(vmax, vq);
       }
       umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
-      const int tu0 = (int)umin >> 3, tv0 = (int)vmin >> 3;
-      const bool ok2 = zmn > 0.05f && umin >= 0.0f && vmin >= 0.0f && umax <= (float)(W - 1) && vmax <= (float)(H - 1) &&
-                       ((int)umax >> 3) <= tu0 + 2 && ((int)vmax >> 3) <= tv0 + 2;
+      // the 4-px table when the box spans at most 3 x 3 of its tiles, else the 8-px one (at most 3 x 3 again, else undecided)
+      const bool in_img = zmn > 0.05f && umin >= 0.0f && vmin >= 0.0f && umax <= (float)(W - 1) && vmax <= (float)(H - 1);
+      const int iu0 = (int)umin, iv0 = (int)vmin, iu1 = (int)umax, iv1 = (int)vmax;
+      const bool fine = (iu1 >> 2) <= (iu0 >> 2) + 2 && (iv1 >> 2) <= (iv0 >> 2) + 2;
+      const int sh = fine ? 2 : 3;
+      const int tu0 = iu0 >> sh, tv0 = iv0 >> sh;
+      const bool ok2 = in_img && (iu1 >> sh) <= tu0 + 2 && (iv1 >> sh) <= tv0 + 2;
+      const float2* __restrict__ tab = fine ? qtab : ftab;
+      const int tbw = fine ? 2 * fw : fw, tbh = fine ? 2 * fh : fh;
+      int txs[3], tys[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        txs[a] = min(max(tu0 + a, 0), tbw - 1);
+        tys[a] = min(max(tv0 + a, 0), tbh - 1) * tbw;
+      }
       float Dx = 0.0f, Dn = 1e30f;
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          const int tx = min(max(tu0 + b, 0), fw - 1), ty = min(max(tv0 + a, 0), fh - 1);
-          const float2 t = ftab[ty * fw + tx];
+          const float2 t = tab[tys[a] + txs[b]];
           Dx = fmaxf(Dx, t.x);
           Dn = fminf(Dn, t.y);
         }
-      const float dc = dc_s[sidx];
-      const bool dead2 = ok2 && (dc * 0.99999f - Dx > k.cull_thr4);
-      const bool free2 = in_all_s[sidx] && ok2 && (dc * 1.00001f + k.free_thr4 <= Dn);
+      // exact distance range of the block: its 16 voxel centres lie in the rectangle [gx0, gx3] x {gy} x [gza, gzb], over
+      // which the distance to the camera centre is largest at a corner and smallest where each coordinate is nearest 0
+      const float gz2_hi = fmaxf(gza * gza, gzb * gzb);
+      const float gz2_lo = (gza <= 0.0f && gzb >= 0.0f) ? 0.0f : fminf(gza * gza, gzb * gzb);
+      const float d_hi = __builtin_amdgcn_sqrtf(c.pn_hi + gz2_hi), d_lo = __builtin_amdgcn_sqrtf(c.pn_lo + gz2_lo);
+      const bool dead2 = ok2 && (d_lo * 0.99999f - Dx > k.cull_thr2);
+      const bool free2 = in_all_s[sidx] && ok2 && (d_hi * 1.00001f + k.free_thr2 <= Dn);
       if (other_s[sidx] && free2) free44_s[sidx] = true;
       other_s[sidx] = other_s[sidx] && !dead2 && !free2;
+    }
+#endif
+    PA_STAMP(3);
+#ifdef HSK_PA_TIMING
+    if (!COUNT_ONLY && pa_wave < 65536u) {
+      const unsigned nf = (unsigned)__popcll(__ballot(free44_s[0] && actv[0])) + (unsigned)__popcll(__ballot(free44_s[1] && actv[1]));
+      const unsigned no = (unsigned)__popcll(__ballot(other_s[0] && actv[0])) + (unsigned)__popcll(__ballot(other_s[1] && actv[1]));
+      if (lane == 0) g_pa_times[pa_wave * 8 + 7] = nf | ((unsigned long long)no << 32);
     }
 #endif
     // ---- stage 4: wave-aggregated append of the uncertain lane-blocks: one of HSK_NQUEUES queues (a single counter
@@ -668,6 +739,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       }
     }
 #endif
+#ifdef HSK_PA_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp below sees the loads back and the stores acknowledged
+#endif
+    PA_STAMP(4);
 #ifndef HSK_EXPA_NO_QUEUE
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
@@ -684,6 +759,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     }
 #endif
   }
+  PA_STAMP(5);
   if (COUNT_ONLY) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
@@ -756,8 +832,16 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* _
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles) {
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
-  hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, (float2*)(tiles + 4 * tw * th), fw,
-                     fh);
+  float2* ftab = (float2*)(tiles + 4 * tw * th);
+  hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, ftab, fw, fh, ftab + (size_t)fw * fh);
+}
+
+// words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
+size_t integrate_queue_words(const VolParams& vp) {
+  const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
+  const size_t nblk = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16) * ((vp.nzs + zchunk - 1) / zchunk);
+  const size_t qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (size_t)((zchunk + 3) / 4);
+  return (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE + (size_t)HSK_NQUEUES * qcap;
 }
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
@@ -769,6 +853,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const int ncols = (vp.X / 4) * vp.Y;
   const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
   const float2* ftab = (const float2*)(tmax + 4 * tw * th);  // behind the coarse tables (filled by launch_tile_fine)
+  const float2* qtab = ftab + (size_t)fw * fh;                // ... and the 4-px table behind the 8-px one
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
   unsigned* qcount = queue;  // HSK_NQUEUES counters, one per 256-B line, cleared by k_column_zrange
   const IcpFinal none = {nullptr, nullptr, 0};
@@ -776,22 +861,26 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, dil_blocks,
                      tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount, fin, const_cast<TrackState*>(st));
   dim3 block(64, 4, 1);
+#ifdef HSK_EXPA_EXTRA_IDLE
+  dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks * HSK_EXPA_EXTRA_IDLE);
+#else
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
+#endif
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
   // behind the counters: HSK_NQUEUES queues of qcap entries each; a block of pass A holds at most 4 waves x 64 lanes
   // x (zchunk / 4) blocks and every HSK_NQUEUES-th block shares a queue
   unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
-  const unsigned nblk = grid.x * grid.y * grid.z;
+  const unsigned nblk = grid.x * grid.y * (unsigned)zchunks;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
   const dim3 detail_grid(DETAIL2_GX, HSK_NQUEUES);  // DETAIL2_GX blocks stride over each queue
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, (double*)nullptr);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   } else {
     hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, fin.slots);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   }
