@@ -6,8 +6,9 @@ from . import _lib
 
 _lib.load()
 
-from .kinfu import (KinfuError, KinfuTracker, bilateral_tables, default_config,  # noqa: E402
-                    synth_depth, synth_pose, synth_room_depth, synth_room_extents, synth_room_pose)
+from .kinfu import (GROUP_FORCE_RCCL, GROUP_ICP_ALLREDUCE, KinfuError, KinfuGroup, KinfuTracker,  # noqa: E402
+                    bilateral_tables, default_config, synth_depth, synth_pose, synth_room_depth, synth_room_extents,
+                    synth_room_pose)
 
-__all__ = ["KinfuError", "KinfuTracker", "default_config", "synth_depth", "synth_pose", "bilateral_tables",
-           "synth_room_depth", "synth_room_extents", "synth_room_pose"]
+__all__ = ["KinfuError", "KinfuTracker", "KinfuGroup", "GROUP_FORCE_RCCL", "GROUP_ICP_ALLREDUCE", "default_config",
+           "synth_depth", "synth_pose", "bilateral_tables", "synth_room_depth", "synth_room_extents", "synth_room_pose"]

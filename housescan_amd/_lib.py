@@ -89,6 +89,19 @@ SYMBOLS = {
     "hsk_stage_ms": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
     "hsk_bilateral_tables": (C.c_int, [_F, _F]),
     "hsk_selftest_exact_ops": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    "hsk_group_create": (C.c_int, [C.POINTER(HskConfig), C.c_int, _I, C.c_int, C.POINTER(_P)]),
+    "hsk_group_unique_id": (C.c_int, [_P]),
+    "hsk_group_create_rank": (C.c_int, [C.POINTER(HskConfig), C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "hsk_group_destroy": (None, [_P]),
+    "hsk_group_last_error": (C.c_char_p, [_P]),
+    "hsk_group_reset": (C.c_int, [_P]),
+    "hsk_group_process_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, _I]),
+    "hsk_group_submit_frame": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "hsk_group_submit_frame_dev": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
+    "hsk_group_wait_frame": (C.c_int, [_P, _F, _I]),
+    "hsk_group_n_slabs": (C.c_int, [_P]),
+    "hsk_group_slab": (_P, [_P, C.c_int]),
+    "hsk_group_download_tsdf": (C.c_int, [_P, _P]),
     "hsk_synth_pose": (C.c_int, [C.c_int, _F]),
     "hsk_synth_render": (C.c_int, [_F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "hsk_synth_room_extents": (C.c_int, [C.c_int, _F]),

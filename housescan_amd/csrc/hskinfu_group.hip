@@ -1,0 +1,572 @@
+// hskinfu_group.hip -- ONE TSDF volume sharded as z-slabs over several GPUs, behind the C ABI (SURVEY.md 8(b), 8(e);
+// BASELINE.json configs[3]).  The caller -- HouseScan's frame loop, Main.hs:1282-1313 -- keeps feeding whole depth frames
+// (HoniHelper.hs:20); the slab frame loop and its collectives live here, against RCCL's C API directly:
+//
+//   per frame   every slab: preprocess + 19 ICP iterations + integrate + slab-local raycast   (hsk_mgpu_frame_front)
+//               MIN of the per-pixel step keys over all slabs     -> which slab saw each ray end first
+//               the winner contributes the bit patterns of its vertex / normal, SUM over all slabs (exact, keeps NaN)
+//               every slab adopts the composite, rebuilds the model pyramid, reports the pose     (hsk_mgpu_frame_end*)
+//
+// Slabs that share a device are combined by a small kernel; across devices ncclAllReduce does it (one communicator rank
+// per distinct device of this process, ncclCommInitAll, or one rank per process, ncclCommInitRank).  RCCL is loaded at
+// run time (dlopen): a process that already holds a copy -- torch does -- must get that one, and a single-device group
+// needs none.  One stream per device carries its slabs' kernels and its collectives, so stream order is the only
+// synchronisation on the frame path.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hskinfu.h"
+
+namespace {
+
+struct Rccl {
+  void* so = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+// the process-wide RCCL entry points; an error string when the library or a symbol is missing
+Rccl* rccl(std::string* err) {
+  static Rccl R;
+  static bool tried = false;
+  static std::string why;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      R.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (R.so) break;
+    }
+    if (!R.so) {
+      why = std::string("RCCL is not loadable: ") + dlerror();
+    } else {
+#define SYM(f)                                                              \
+  R.f = (decltype(R.f))dlsym(R.so, "nccl" #f);                              \
+  if (!R.f && why.empty()) why = "RCCL lacks the symbol nccl" #f;
+      SYM(GetUniqueId) SYM(CommInitRank) SYM(CommInitAll) SYM(CommDestroy) SYM(AllReduce) SYM(GroupStart) SYM(GroupEnd)
+      SYM(GetErrorString)
+#undef SYM
+    }
+  }
+  if (!why.empty()) {
+    if (err) *err = why;
+    return nullptr;
+  }
+  return &R;
+}
+
+__global__ void k_min_into(int* __restrict__ acc, const int* __restrict__ x, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] = min(acc[i], x[i]);
+}
+__global__ void k_add_into(int* __restrict__ acc, const int* __restrict__ x, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] = acc[i] + x[i];  // bit patterns: at most one slab contributes a non-zero word per pixel
+}
+__global__ void k_add_into_f64(double* __restrict__ acc, const double* __restrict__ x, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] = acc[i] + x[i];  // exact: the ICP products are multiples of 2^-26
+}
+
+struct Slab {
+  hsk_ctx* k = nullptr;
+  int dev_slot = 0;       // index into Group::devs
+  int index = 0;          // global slab number (row shard of the all-reduced ICP)
+  int* keys = nullptr;    // int32[P]   this slab's step keys
+  int* bits = nullptr;    // int32[6P]  this slab's contribution to the composite
+  double* sums = nullptr; // double[27] this slab's share of an ICP iteration (all-reduce mode)
+};
+
+struct Dev {
+  int id = 0;
+  hipStream_t stream = nullptr;
+  uint16_t* depth = nullptr;  // the frame, uploaded once per device
+  int* kmin = nullptr;        // MIN of the keys over all slabs (after the collective: over all devices)
+  int* bsum = nullptr;        // SUM of the bit patterns
+  double* sums = nullptr;     // double[27]
+  ncclComm_t comm = nullptr;
+  std::vector<int> slabs;     // indices into Group::slabs
+};
+
+}  // namespace
+
+struct hsk_group {
+  hsk_config cfg;
+  int flags = 0;
+  int world = 1, rank0 = 0;  // communicator size and the rank of this process's first device
+  int n_slabs_total = 1;
+  bool use_rccl = false;
+  std::vector<Slab> slabs;
+  std::vector<Dev> devs;
+  uint16_t* h_stage = nullptr;  // pinned ring for host frames
+  unsigned stage_turn = 0;
+  int in_flight = 0;
+  std::vector<int> fifo_sync;   // per submitted frame: 1 = finished synchronously (first frame of a scan)
+  float sync_pose[16] = {};
+  int sync_tracked = 0;
+  std::string err;
+};
+
+static thread_local std::string g_group_err;
+
+#define GFAIL(g, code, msg) \
+  do {                      \
+    (g)->err = (msg);       \
+    return (code);          \
+  } while (0)
+#define GHIP(g, call)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      (g)->err = std::string(#call " failed: ") + hipGetErrorString(e_);                               \
+      return HSK_ERR_HIP;                                                                              \
+    }                                                                                                  \
+  } while (0)
+#define GSLAB(g, s, call)                                                                              \
+  do {                                                                                                 \
+    int r_ = (call);                                                                                   \
+    if (r_ != HSK_OK) {                                                                                \
+      (g)->err = std::string("slab ") + std::to_string((s).index) + ": " + hsk_last_error((s).k);     \
+      return r_;                                                                                       \
+    }                                                                                                  \
+  } while (0)
+#define GNCCL(g, R, call)                                                                              \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      (g)->err = std::string(#call " failed: ") + (R)->GetErrorString(r_);                             \
+      return HSK_ERR_HIP;                                                                              \
+    }                                                                                                  \
+  } while (0)
+
+// owned planes of slab i of n: contiguous, cover [0, Z) exactly, differ by at most one plane
+static void slab_range(int i, int n, int Z, int* z0, int* z1) {
+  const int base = Z / n, rem = Z % n;
+  *z0 = i * base + (i < rem ? i : rem);
+  *z1 = *z0 + base + (i < rem ? 1 : 0);
+}
+// planes a slab stores beyond what it owns: an owned raycast step reads its near sample (one step back) and the refined
+// vertex within [t - step/2, t + 3 step/2] (deviation D3), +-1 cell for the normal taps, +-1 voxel for the trilinear taps
+static int slab_halo(const hsk_config* c) {
+  float m = c->vol_size_m[0] / (float)c->vol_x;
+  const float cy = c->vol_size_m[1] / (float)c->vol_y, cz = c->vol_size_m[2] / (float)c->vol_z;
+  m = m > cy ? m : cy;
+  m = m > cz ? m : cz;
+  const float tau = c->trunc_dist_m > 2.1f * m ? c->trunc_dist_m : 2.1f * m;
+  const float steps = 1.5f * (0.8f * tau) / cz;
+  int h = (int)steps;
+  if ((float)h < steps) ++h;
+  return h + 3;
+}
+
+static void group_free(hsk_group* g) {
+  if (!g) return;
+  Rccl* R = rccl(nullptr);
+  for (auto& s : g->slabs) {
+    if (s.k) {
+      (void)hipSetDevice(g->devs[s.dev_slot].id);
+      (void)hsk_synchronize(s.k);
+      if (s.keys) (void)hipFree(s.keys);
+      if (s.bits) (void)hipFree(s.bits);
+      if (s.sums) (void)hipFree(s.sums);
+      hsk_destroy(s.k);
+    }
+  }
+  for (auto& d : g->devs) {
+    (void)hipSetDevice(d.id);
+    if (d.comm && R) (void)R->CommDestroy(d.comm);
+    if (d.depth) (void)hipFree(d.depth);
+    if (d.kmin) (void)hipFree(d.kmin);
+    if (d.bsum) (void)hipFree(d.bsum);
+    if (d.sums) (void)hipFree(d.sums);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+  }
+  if (g->h_stage) (void)hipHostFree(g->h_stage);
+  delete g;
+}
+
+// slabs [first, first + n_local) of n_total on device_ids[]; communicator of `world` ranks, this process's devices being
+// ranks rank0, rank0 + 1, ... (one per distinct device); comm_id null: single process (ncclCommInitAll)
+static int group_build(const hsk_config* c, int n_total, int first, int n_local, const int* device_ids, int world, int rank0,
+                       const void* comm_id, int flags, hsk_group** out) {
+  if (!c || !out || n_total <= 0 || n_local <= 0 || first < 0 || first + n_local > n_total || !device_ids) {
+    g_group_err = "hsk_group_create: invalid argument";
+    return HSK_ERR_ARG;
+  }
+  *out = nullptr;
+  if (n_total > c->vol_z) {
+    g_group_err = "hsk_group_create: more slabs than planes";
+    return HSK_ERR_ARG;
+  }
+  hsk_group* g = new hsk_group();
+  g->cfg = *c;
+  g->flags = flags;
+  g->n_slabs_total = n_total;
+  g->world = world;
+  g->rank0 = rank0;
+  auto bail = [&](int code) {
+    g_group_err = g->err;
+    group_free(g);
+    return code;
+  };
+  const size_t P = (size_t)c->width * c->height;
+  const int halo = slab_halo(c);
+  for (int i = 0; i < n_local; ++i) {
+    const int dev = device_ids[i];
+    int slot = -1;
+    for (size_t d = 0; d < g->devs.size(); ++d)
+      if (g->devs[d].id == dev) slot = (int)d;
+    if (slot < 0) {
+      Dev d;
+      d.id = dev;
+      g->devs.push_back(d);
+      slot = (int)g->devs.size() - 1;
+    }
+    Slab s;
+    s.dev_slot = slot;
+    s.index = first + i;
+    g->slabs.push_back(s);
+    g->devs[slot].slabs.push_back((int)g->slabs.size() - 1);
+  }
+  for (auto& d : g->devs) {
+    if (hipSetDevice(d.id) != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&d.depth, P * 2) != hipSuccess || hipMalloc((void**)&d.kmin, P * 4) != hipSuccess ||
+        hipMalloc((void**)&d.bsum, P * 24) != hipSuccess || hipMalloc((void**)&d.sums, 27 * sizeof(double)) != hipSuccess) {
+      g->err = "hsk_group_create: device setup failed (device id out of range, or out of memory)";
+      return bail(HSK_ERR_HIP);
+    }
+  }
+  for (auto& s : g->slabs) {
+    hsk_config sc = *c;
+    sc.device_id = g->devs[s.dev_slot].id;
+    slab_range(s.index, n_total, c->vol_z, &sc.own_z0, &sc.own_z1);
+    sc.halo = n_total > 1 ? halo : 0;
+    sc.use_graph = 0;
+    int r = hsk_create(&sc, &s.k);
+    if (r != HSK_OK) {
+      g->err = std::string("hsk_group_create: slab ") + std::to_string(s.index) + ": " + hsk_last_error(nullptr);
+      return bail(r);
+    }
+    (void)hipSetDevice(sc.device_id);
+    if (hsk_set_stream(s.k, g->devs[s.dev_slot].stream) != HSK_OK || hipMalloc((void**)&s.keys, P * 4) != hipSuccess ||
+        hipMalloc((void**)&s.bits, P * 24) != hipSuccess || hipMalloc((void**)&s.sums, 27 * sizeof(double)) != hipSuccess) {
+      g->err = "hsk_group_create: slab buffers";
+      return bail(HSK_ERR_HIP);
+    }
+  }
+  if (hipHostMalloc((void**)&g->h_stage, P * 2 * (HSK_MAX_IN_FLIGHT + 1), hipHostMallocDefault) != hipSuccess) {
+    g->err = "hsk_group_create: pinned staging";
+    return bail(HSK_ERR_HIP);
+  }
+  g->use_rccl = world > 1 || (flags & HSK_GROUP_FORCE_RCCL);
+  if (g->use_rccl) {
+    std::string why;
+    Rccl* R = rccl(&why);
+    if (!R) {
+      g->err = why;
+      return bail(HSK_ERR_STATE);
+    }
+    ncclResult_t r = ncclSuccess;
+    if (comm_id) {
+      if (g->devs.size() != 1) {
+        g->err = "hsk_group_create_rank: one device per process";
+        return bail(HSK_ERR_ARG);
+      }
+      ncclUniqueId id;
+      memcpy(&id, comm_id, sizeof(id));
+      (void)hipSetDevice(g->devs[0].id);
+      r = R->CommInitRank(&g->devs[0].comm, world, id, rank0);
+    } else {
+      std::vector<int> ids;
+      std::vector<ncclComm_t> comms(g->devs.size());
+      for (auto& d : g->devs) ids.push_back(d.id);
+      r = R->CommInitAll(comms.data(), (int)ids.size(), ids.data());
+      if (r == ncclSuccess)
+        for (size_t d = 0; d < g->devs.size(); ++d) g->devs[d].comm = comms[d];
+    }
+    if (r != ncclSuccess) {
+      g->err = std::string("RCCL communicator: ") + R->GetErrorString(r);
+      return bail(HSK_ERR_HIP);
+    }
+  }
+  *out = g;
+  return HSK_OK;
+}
+
+extern "C" int hsk_group_create(const hsk_config* c, int n_slabs, const int* device_ids, int flags, hsk_group** out) {
+  if (!device_ids || n_slabs <= 0) {
+    g_group_err = "hsk_group_create: invalid argument";
+    return HSK_ERR_ARG;
+  }
+  int distinct = 0;
+  for (int i = 0; i < n_slabs; ++i) {
+    bool seen = false;
+    for (int j = 0; j < i; ++j) seen = seen || device_ids[j] == device_ids[i];
+    distinct += seen ? 0 : 1;
+  }
+  return group_build(c, n_slabs, 0, n_slabs, device_ids, distinct, 0, nullptr, flags, out);
+}
+
+extern "C" int hsk_group_unique_id(void* id128) {
+  if (!id128) return HSK_ERR_ARG;
+  std::string why;
+  Rccl* R = rccl(&why);
+  if (!R) {
+    g_group_err = why;
+    return HSK_ERR_STATE;
+  }
+  ncclUniqueId id;
+  if (R->GetUniqueId(&id) != ncclSuccess) {
+    g_group_err = "ncclGetUniqueId failed";
+    return HSK_ERR_HIP;
+  }
+  memcpy(id128, &id, sizeof(id));
+  return HSK_OK;
+}
+
+extern "C" int hsk_group_create_rank(const hsk_config* c, int rank, int world, const void* comm_id, int flags, hsk_group** out) {
+  if (!c || rank < 0 || rank >= world || (world > 1 && !comm_id)) {
+    g_group_err = "hsk_group_create_rank: invalid argument";
+    return HSK_ERR_ARG;
+  }
+  const int dev = c->device_id;
+  return group_build(c, world, rank, 1, &dev, world, rank, comm_id, flags, out);
+}
+
+extern "C" void hsk_group_destroy(hsk_group* g) { group_free(g); }
+extern "C" const char* hsk_group_last_error(const hsk_group* g) { return g ? g->err.c_str() : g_group_err.c_str(); }
+extern "C" int hsk_group_n_slabs(const hsk_group* g) { return g ? (int)g->slabs.size() : -1; }
+extern "C" hsk_ctx* hsk_group_slab(hsk_group* g, int i) { return (g && i >= 0 && i < (int)g->slabs.size()) ? g->slabs[i].k : nullptr; }
+
+// all-reduce `buf` (per device) in place over the communicator; one call per device inside an RCCL group
+static int group_allreduce(hsk_group* g, bool keys, ncclDataType_t type, ncclRedOp_t op, size_t count, int which) {
+  (void)keys;
+  if (!g->use_rccl) return HSK_OK;
+  Rccl* R = rccl(nullptr);
+  GNCCL(g, R, R->GroupStart());
+  for (auto& d : g->devs) {
+    void* buf = which == 0 ? (void*)d.kmin : (which == 1 ? (void*)d.bsum : (void*)d.sums);
+    ncclResult_t r = R->AllReduce(buf, buf, count, type, op, d.comm, d.stream);
+    if (r != ncclSuccess) {
+      (void)R->GroupEnd();
+      g->err = std::string("ncclAllReduce failed: ") + R->GetErrorString(r);
+      return HSK_ERR_HIP;
+    }
+  }
+  GNCCL(g, R, R->GroupEnd());
+  return HSK_OK;
+}
+
+// the 19 ICP iterations with the 27 sums all-reduced every iteration (the north_star's form): slab i takes image rows
+// [i H / n, (i + 1) H / n) of the level, devices add their slabs' shares, RCCL adds the devices'
+static int group_icp_allreduce(hsk_group* g) {
+  for (int level = HSK_LEVELS - 1; level >= 0; --level) {
+    const int h = g->cfg.height >> level;
+    for (int it = 0; it < g->cfg.icp_iters[level]; ++it) {
+      for (auto& d : g->devs) {
+        GHIP(g, hipSetDevice(d.id));
+        bool first = true;
+        for (int si : d.slabs) {
+          Slab& s = g->slabs[si];
+          const int n = g->n_slabs_total;
+          const int r0 = (int)((long)s.index * h / n), r1 = (int)((long)(s.index + 1) * h / n);
+          GSLAB(g, s, hsk_mgpu_icp_accumulate(s.k, level, r0, r1, first ? (void*)d.sums : (void*)s.sums));
+          if (!first) hipLaunchKernelGGL(k_add_into_f64, dim3(1), dim3(32), 0, d.stream, d.sums, s.sums, 27);
+          first = false;
+        }
+      }
+      int r = group_allreduce(g, false, ncclFloat64, ncclSum, 27, 2);
+      if (r != HSK_OK) return r;
+      for (auto& d : g->devs) {
+        GHIP(g, hipSetDevice(d.id));
+        for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_icp_update(g->slabs[si].k, d.sums));
+      }
+    }
+  }
+  return HSK_OK;
+}
+
+// enqueue one whole frame on every device: depth upload, frame front of every slab, the two composites; frame end
+// queued (async) or, for the first frame of a scan, taken synchronously.  depth_dev: per device, or null = from host
+static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* const* depth_dev, int w, int h) {
+  if (w != g->cfg.width || h != g->cfg.height) GFAIL(g, HSK_ERR_ARG, "depth frame size does not match the group");
+  if (g->in_flight >= HSK_MAX_IN_FLIGHT) GFAIL(g, HSK_ERR_STATE, "too many frames in flight: call hsk_group_wait_frame first");
+  const size_t P = (size_t)w * h;
+  const int P_i = (int)P;
+  const uint16_t* src = nullptr;
+  if (depth_host) {
+    uint16_t* stage = g->h_stage + (size_t)(g->stage_turn % (HSK_MAX_IN_FLIGHT + 1)) * P;
+    g->stage_turn += 1;
+    memcpy(stage, depth_host, P * 2);  // the caller's buffer may be freed on return (HoniHelper's Vector is pinned only inside unsafeWith)
+    src = stage;
+  }
+  const bool restart = hsk_mgpu_restart_pending(g->slabs[0].k) == 1;
+  const bool icp_ar = (g->flags & HSK_GROUP_ICP_ALLREDUCE) != 0;
+  if (restart && g->in_flight > 0) GFAIL(g, HSK_ERR_STATE, "a scan (re)starts: collect the frames in flight first");
+  for (size_t di = 0; di < g->devs.size(); ++di) {
+    Dev& d = g->devs[di];
+    GHIP(g, hipSetDevice(d.id));
+    const void* frame = d.depth;
+    if (src)
+      GHIP(g, hipMemcpyAsync(d.depth, src, P * 2, hipMemcpyHostToDevice, d.stream));
+    else
+      frame = depth_dev[di];
+    for (int si : d.slabs) {
+      Slab& s = g->slabs[si];
+      if (icp_ar && !restart)
+        GSLAB(g, s, hsk_mgpu_frame_begin(s.k, frame, w, h));
+      else
+        GSLAB(g, s, hsk_mgpu_frame_front(s.k, frame, w, h, s.keys));
+    }
+  }
+  if (restart) {
+    // first frame of a (re)started scan: integrate + transformed maps only, finished synchronously
+    float pose[16];
+    int tracked = 0;
+    for (auto& s : g->slabs) {
+      GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
+      GSLAB(g, s, hsk_mgpu_frame_end(s.k, nullptr, nullptr, pose, &tracked));
+    }
+    memcpy(g->sync_pose, pose, sizeof(pose));
+    g->sync_tracked = tracked;
+    g->fifo_sync.push_back(1);
+    g->in_flight += 1;
+    return HSK_OK;
+  }
+  if (icp_ar) {
+    int r = group_icp_allreduce(g);
+    if (r != HSK_OK) return r;
+    for (auto& d : g->devs) {
+      GHIP(g, hipSetDevice(d.id));
+      for (int si : d.slabs) {
+        Slab& s = g->slabs[si];
+        GSLAB(g, s, hsk_mgpu_integrate(s.k));
+        GSLAB(g, s, hsk_mgpu_raycast_local(s.k, s.keys));
+      }
+    }
+  }
+  // composite 1: the first event along every ray
+  for (auto& d : g->devs) {
+    GHIP(g, hipSetDevice(d.id));
+    bool first = true;
+    for (int si : d.slabs) {
+      Slab& s = g->slabs[si];
+      if (first)
+        GHIP(g, hipMemcpyAsync(d.kmin, s.keys, P * 4, hipMemcpyDeviceToDevice, d.stream));
+      else
+        hipLaunchKernelGGL(k_min_into, dim3((P_i + 255) / 256), dim3(256), 0, d.stream, d.kmin, s.keys, P_i);
+      first = false;
+    }
+  }
+  int r = group_allreduce(g, true, ncclInt32, ncclMin, P, 0);
+  if (r != HSK_OK) return r;
+  // composite 2: the winner's vertex / normal bit patterns
+  for (auto& d : g->devs) {
+    GHIP(g, hipSetDevice(d.id));
+    bool first = true;
+    for (int si : d.slabs) {
+      Slab& s = g->slabs[si];
+      GSLAB(g, s, hsk_mgpu_raycast_resolve(s.k, d.kmin, first ? (void*)d.bsum : (void*)s.bits));
+      if (!first) hipLaunchKernelGGL(k_add_into, dim3((6 * P_i + 255) / 256), dim3(256), 0, d.stream, d.bsum, s.bits, 6 * P_i);
+      first = false;
+    }
+  }
+  r = group_allreduce(g, false, ncclInt32, ncclSum, 6 * P, 1);
+  if (r != HSK_OK) return r;
+  for (auto& d : g->devs) {
+    GHIP(g, hipSetDevice(d.id));
+    for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_frame_end_async(g->slabs[si].k, d.kmin, d.bsum));
+  }
+  g->fifo_sync.push_back(0);
+  g->in_flight += 1;
+  return HSK_OK;
+}
+
+extern "C" int hsk_group_submit_frame(hsk_group* g, const uint16_t* depth, int w, int h) {
+  if (!g || !depth) return HSK_ERR_ARG;
+  return group_enqueue(g, depth, nullptr, w, h);
+}
+extern "C" int hsk_group_submit_frame_dev(hsk_group* g, const void* const* depth_dev, int w, int h) {
+  if (!g || !depth_dev) return HSK_ERR_ARG;
+  for (size_t d = 0; d < g->devs.size(); ++d)
+    if (!depth_dev[d]) GFAIL(g, HSK_ERR_ARG, "a device pointer is null (one per distinct device of the group, in creation order)");
+  return group_enqueue(g, nullptr, depth_dev, w, h);
+}
+
+extern "C" int hsk_group_wait_frame(hsk_group* g, float pose_out[16], int* tracked) {
+  if (!g) return HSK_ERR_ARG;
+  if (g->in_flight == 0) GFAIL(g, HSK_ERR_STATE, "no frame in flight");
+  const int sync = g->fifo_sync.front();
+  g->fifo_sync.erase(g->fifo_sync.begin());
+  g->in_flight -= 1;
+  if (sync) {
+    if (pose_out) memcpy(pose_out, g->sync_pose, sizeof(g->sync_pose));
+    if (tracked) *tracked = g->sync_tracked;
+    return HSK_OK;
+  }
+  float pose[16], first[16];
+  int tr = 0, tr0 = 0;
+  for (size_t i = 0; i < g->slabs.size(); ++i) {
+    Slab& s = g->slabs[i];
+    GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
+    GSLAB(g, s, hsk_wait_frame(s.k, pose, &tr));
+    if (i == 0) {
+      memcpy(first, pose, sizeof(pose));
+      tr0 = tr;
+    } else if (tr != tr0 || memcmp(first, pose, sizeof(pose)) != 0) {
+      GFAIL(g, HSK_ERR_STATE, "slabs disagree on the pose: the composite is not the same on every slab");
+    }
+  }
+  if (pose_out) memcpy(pose_out, first, sizeof(first));
+  if (tracked) *tracked = tr0;
+  return HSK_OK;
+}
+
+extern "C" int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked) {
+  if (!g || !depth) return HSK_ERR_ARG;
+  if (g->in_flight > 0) GFAIL(g, HSK_ERR_STATE, "frames are in flight: collect them with hsk_group_wait_frame first");
+  int r = group_enqueue(g, depth, nullptr, w, h);
+  if (r != HSK_OK) return r;
+  return hsk_group_wait_frame(g, pose_out, tracked);
+}
+
+extern "C" int hsk_group_reset(hsk_group* g) {
+  if (!g) return HSK_ERR_ARG;
+  while (g->in_flight > 0) {
+    int r = hsk_group_wait_frame(g, nullptr, nullptr);
+    if (r != HSK_OK) return r;
+  }
+  for (auto& s : g->slabs) {
+    GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
+    GSLAB(g, s, hsk_reset(s.k));
+  }
+  return HSK_OK;
+}
+
+// the planes this process owns, placed at their z in a full-volume array (planes of other processes are left untouched)
+extern "C" int hsk_group_download_tsdf(hsk_group* g, int16_t* full) {
+  if (!g || !full) return HSK_ERR_ARG;
+  const size_t plane = (size_t)g->cfg.vol_x * g->cfg.vol_y * 2;
+  std::vector<int16_t> tmp;
+  for (auto& s : g->slabs) {
+    GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
+    int z0 = 0, nz = 0, o0 = 0, o1 = 0;
+    GSLAB(g, s, hsk_stored_planes(s.k, &z0, &nz));
+    slab_range(s.index, g->n_slabs_total, g->cfg.vol_z, &o0, &o1);
+    tmp.resize((size_t)nz * plane);
+    GSLAB(g, s, hsk_download_tsdf(s.k, tmp.data()));
+    memcpy(full + (size_t)o0 * plane, tmp.data() + (size_t)(o0 - z0) * plane, (size_t)(o1 - o0) * plane * sizeof(int16_t));
+  }
+  return HSK_OK;
+}

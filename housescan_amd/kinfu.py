@@ -226,6 +226,99 @@ class KinfuTracker:
         return list(ms), n.value
 
 
+GROUP_FORCE_RCCL = 1
+GROUP_ICP_ALLREDUCE = 2
+
+
+class KinfuGroup:
+    """One TSDF volume sharded as z-slabs over several GPUs, behind one frame call (`hsk_group_*`): the slab frame loop
+    and its RCCL collectives live inside the library.  `device_ids` names the device of every slab (single process), or
+    pass rank / world / comm_id for one process per GPU."""
+
+    def __init__(self, cfg=None, device_ids=(0,), flags=0, rank=None, world=None, comm_id=None, **over):
+        self.lib = _lib.load()
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        h = C.c_void_p()
+        if rank is None:
+            ids = (C.c_int * len(device_ids))(*device_ids)
+            rc = self.lib.hsk_group_create(C.byref(self.cfg), len(device_ids), ids, int(flags), C.byref(h))
+        else:
+            buf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
+            rc = self.lib.hsk_group_create_rank(C.byref(self.cfg), int(rank), int(world), buf, int(flags), C.byref(h))
+        if rc != 0:
+            raise KinfuError(f"hsk_group_create failed ({rc}): {self.lib.hsk_group_last_error(None).decode()}")
+        self.h = h
+        self.w, self.hgt = self.cfg.width, self.cfg.height
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().hsk_group_unique_id(buf)
+        if rc != 0:
+            raise KinfuError(f"hsk_group_unique_id failed ({rc}): {_lib.load().hsk_group_last_error(None).decode()}")
+        return buf.raw
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise KinfuError(f"hskinfu group error {rc}: {self.lib.hsk_group_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsk_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_frame(self, depth):
+        d = KinfuTracker._depth(depth)
+        pose = np.empty(16, np.float32)
+        tracked = C.c_int()
+        self._ck(self.lib.hsk_group_process_frame(self.h, d.ctypes.data, d.shape[1], d.shape[0], _fp(pose), C.byref(tracked)))
+        return pose.reshape(4, 4), bool(tracked.value)
+
+    def submit_frame(self, depth):
+        d = KinfuTracker._depth(depth)
+        self._ck(self.lib.hsk_group_submit_frame(self.h, d.ctypes.data, d.shape[1], d.shape[0]))
+
+    def submit_frame_dev(self, device_ptrs):
+        arr = (C.c_void_p * len(device_ptrs))(*device_ptrs)
+        self._ck(self.lib.hsk_group_submit_frame_dev(self.h, arr, self.w, self.hgt))
+
+    def wait_frame(self):
+        pose = np.empty(16, np.float32)
+        tracked = C.c_int()
+        self._ck(self.lib.hsk_group_wait_frame(self.h, _fp(pose), C.byref(tracked)))
+        return pose.reshape(4, 4), bool(tracked.value)
+
+    def reset(self):
+        self._ck(self.lib.hsk_group_reset(self.h))
+
+    def n_slabs(self):
+        return self.lib.hsk_group_n_slabs(self.h)
+
+    def slab(self, i):
+        """a borrowed KinfuTracker view of slab i (owned by the group: never close it)"""
+        t = KinfuTracker.__new__(KinfuTracker)
+        t.lib, t.cfg, t.h = self.lib, self.cfg, C.c_void_p(self.lib.hsk_group_slab(self.h, i))
+        t.w, t.hgt = self.w, self.hgt
+        z0, nz = C.c_int(), C.c_int()
+        self.lib.hsk_stored_planes(t.h, C.byref(z0), C.byref(nz))
+        t.stored_z0, t.stored_nz = z0.value, nz.value
+        t.close = lambda: None
+        return t
+
+    def download_tsdf(self, out=None):
+        """the planes this process owns, at their place in a full [Z, Y, X, 2] array"""
+        if out is None:
+            out = np.zeros((self.cfg.vol_z, self.cfg.vol_y, self.cfg.vol_x, 2), np.int16)
+        self._ck(self.lib.hsk_group_download_tsdf(self.h, out.ctypes.data))
+        return out
+
+
 def synth_pose(frame):
     lib = _lib.load()
     p = np.empty(16, np.float32)

@@ -138,6 +138,41 @@ int hsk_mgpu_frame_index(const hsk_ctx* k);
 int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev);
 int hsk_mgpu_restart_pending(const hsk_ctx* k);
 
+/* ---- ONE volume sharded as z-slabs over several GPUs, behind one frame call (SURVEY.md 8(b) n_devices / device_ids,
+ * 8(e); BASELINE.json configs[3]).  The host keeps feeding whole depth frames (HoniHelper.hs:20, the loop that would
+ * replace Main.hs:1285-1290); slab s of n owns planes [s Z / n, (s + 1) Z / n) plus a redundantly integrated halo, and
+ * the per-frame exchanges -- MIN of the raycast's step keys, SUM of the winning vertex / normal bit patterns, optionally
+ * the 27 ICP sums of every iteration -- run inside the library: a kernel between slabs that share a device,
+ * ncclAllReduce (RCCL over xGMI, loaded at run time) between devices.  Results are bit-identical to a single context.
+ * A group is not re-entrant; it is driven from one host thread. */
+typedef struct hsk_group hsk_group;
+#define HSK_GROUP_FORCE_RCCL 1     /* run the collectives through RCCL even when the group has a single device / rank */
+#define HSK_GROUP_ICP_ALLREDUCE 2  /* row-shard the ICP over the slabs and all-reduce its 27 sums every iteration
+                                      (default: every slab runs the whole ICP on the composited maps, no collective) */
+/* single process: slab s lives on device_ids[s] (a device may be named several times); the distinct devices form one
+ * communicator.  c->device_id, own_z0, own_z1, halo and use_graph are set by the library. */
+int hsk_group_create(const hsk_config* c, int n_slabs, const int* device_ids, int flags, hsk_group** out);
+/* one process per GPU (c->device_id): rank r of `world` owns slab r.  comm_id: the 128 bytes hsk_group_unique_id() gave
+ * ONE of the ranks, handed to all of them by the host's own means (ignored when world == 1) */
+int hsk_group_unique_id(void* id128);
+int hsk_group_create_rank(const hsk_config* c, int rank, int world, const void* comm_id, int flags, hsk_group** out);
+void hsk_group_destroy(hsk_group* g);
+const char* hsk_group_last_error(const hsk_group* g); /* g may be NULL: last create error */
+int hsk_group_reset(hsk_group* g);
+/* the tracker step of hsk_process_frame, on the sharded volume */
+int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked);
+/* pipelined form (as hsk_submit_frame / hsk_wait_frame): the frame and its collectives are enqueued, the pose collected
+ * later, in order, at most HSK_MAX_IN_FLIGHT outstanding; the first frame of a (re)started scan completes at submission */
+int hsk_group_submit_frame(hsk_group* g, const uint16_t* depth, int w, int h);
+/* depth_dev[d]: the frame in the memory of the d-th distinct device of this process (creation order), complete and
+ * valid until the frame has been waited for */
+int hsk_group_submit_frame_dev(hsk_group* g, const void* const* depth_dev, int w, int h);
+int hsk_group_wait_frame(hsk_group* g, float pose_out[16], int* tracked);
+int hsk_group_n_slabs(const hsk_group* g);            /* slabs held by this process */
+hsk_ctx* hsk_group_slab(hsk_group* g, int i);         /* for hsk_download_map, hsk_extract_cloud, ... on one slab */
+/* the planes this process owns, at their place in a full 2 * X * Y * Z array (other planes are left untouched) */
+int hsk_group_download_tsdf(hsk_group* g, int16_t* full_tsdf_weight_pairs);
+
 /* streams / profiling */
 void* hsk_stream(hsk_ctx* k);                 /* hipStream_t the context launches on */
 int hsk_set_stream(hsk_ctx* k, void* stream); /* adopt the caller's hipStream_t (e.g. torch's current stream) */

@@ -94,6 +94,14 @@ def test_no_gpu_fails_loudly(hsk):
         hsk.KinfuTracker(n=64)
 
 
+def test_group_without_gpu_fails_loudly(hsk):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(hsk.KinfuError, match="no HIP device|device setup failed"):
+        hsk.KinfuGroup(hsk.default_config(64), device_ids=[0, 0])
+
+
 def test_host_solve_mirror_matches_oracle(hsk, oracle):
     """hsk_icp_solve is host code: the device solve's mirror must equal the oracle's bit for bit"""
     import ctypes

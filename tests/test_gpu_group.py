@@ -1,0 +1,109 @@
+"""Multi-GPU behind the C ABI (SURVEY.md 8(b) n_devices / device_ids, 8(e)): `hsk_group_*` runs the z-slab frame loop and
+its collectives inside the library.  One GPU is enough to test it: several slabs on device 0 composite through the
+library's own kernels, and HSK_GROUP_FORCE_RCCL sends the same data through ncclAllReduce (a one-rank communicator).
+Everything must be bit-identical to a single context.  The last test drives the library from a plain C program."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_same_bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _reference(hsk, synth_frames, n, frames):
+    ref = hsk.KinfuTracker(n=n)
+    poses = [ref.process_frame(synth_frames(k)[1]) for k in frames]
+    return ref, poses
+
+
+@pytest.mark.parametrize("slabs,flags", [(2, 0), (3, 2), (3, 1), (2, 3)])
+def test_group_matches_single_context(hsk, synth_frames, slabs, flags):
+    """slabs on one device (flags: 1 = collectives through RCCL, 2 = ICP sums all-reduced every iteration), synchronous
+    and pipelined calls mixed: poses, the owned planes of every slab and the model maps equal the single context's"""
+    n, frames = 64, list(range(9))
+    ref, want = _reference(hsk, synth_frames, n, frames)
+    grp = hsk.KinfuGroup(hsk.default_config(n), device_ids=[0] * slabs, flags=flags)
+    assert grp.n_slabs() == slabs
+    got = []
+    for k in frames[:4]:
+        got.append(grp.process_frame(synth_frames(k)[1]))
+    grp.submit_frame(synth_frames(4)[1])
+    for k in frames[5:]:
+        grp.submit_frame(synth_frames(k)[1])
+        got.append(grp.wait_frame())
+    got.append(grp.wait_frame())
+    for k, ((p, ok), (pr, okr)) in enumerate(zip(got, want)):
+        assert ok == okr == (k > 0)
+        assert_same_bits(p, pr, f"group pose frame {k} ({slabs} slabs, flags {flags})")
+    assert_same_bits(grp.download_tsdf(), ref.download_tsdf(), "group tsdf")
+    for i in range(slabs):
+        s = grp.slab(i)
+        for level in range(3):
+            assert_same_bits(s.download_map(2, level), ref.download_map(2, level), f"slab {i} model vmap {level}")
+            assert_same_bits(s.download_map(3, level), ref.download_map(3, level), f"slab {i} model nmap {level}")
+    grp.close()
+    ref.close()
+
+
+def test_group_eight_slabs_256(hsk, synth_frames):
+    """configs[3]'s eight-way partition through the group call (256^3 here; the 1024^3 partition is composed slab by
+    slab in test_gpu_configs.py)"""
+    n, frames = 256, list(range(4))
+    ref, want = _reference(hsk, synth_frames, n, frames)
+    grp = hsk.KinfuGroup(hsk.default_config(n), device_ids=[0] * 8)
+    for k, (pr, okr) in zip(frames, want):
+        p, ok = grp.process_frame(synth_frames(k)[1])
+        assert ok == okr
+        assert_same_bits(p, pr, f"8-slab pose frame {k}")
+    assert_same_bits(grp.download_tsdf(), ref.download_tsdf(), "8-slab tsdf")
+    grp.close()
+    ref.close()
+
+
+def test_group_rank_form_and_tracking_loss(hsk, synth_frames):
+    """the one-process-per-GPU constructor (world of one rank, communicator from a unique id) and the loss / reset path"""
+    n = 64
+    ref = hsk.KinfuTracker(n=n)
+    grp = hsk.KinfuGroup(hsk.default_config(n), rank=0, world=1, comm_id=hsk.KinfuGroup.unique_id(), flags=hsk.GROUP_FORCE_RCCL)
+    zero = np.zeros_like(synth_frames(0)[1])
+    seq = [synth_frames(0)[1], synth_frames(1)[1], zero, synth_frames(2)[1], synth_frames(3)[1]]
+    for i, d in enumerate(seq):
+        pr, okr = ref.process_frame(d)
+        p, ok = grp.process_frame(d)
+        assert ok == okr, i
+        assert_same_bits(p, pr, f"rank-form pose step {i}")
+    assert_same_bits(grp.download_tsdf(), ref.download_tsdf(), "rank-form tsdf after a loss and a restart")
+    with pytest.raises(hsk.KinfuError, match="size"):
+        grp.process_frame(np.zeros((10, 10), np.uint16))
+    grp.reset()
+    assert not grp.download_tsdf().any()
+    grp.close()
+    ref.close()
+
+
+def test_c_harness_drives_the_library_without_python(hsk, synth_frames, tmp_path):
+    """tests/abi_harness.c: a C program linked against libhskinfu (no Python, no torch in that process) runs 4 frames
+    through one context and through a two-slab group; its poses equal the ones this process gets"""
+    exe = str(tmp_path / "abi_harness")
+    lib_dir = os.path.join(ROOT, "housescan_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_harness.c"),
+                           "-L" + lib_dir, "-lhskinfu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, "64", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    ref, want = _reference(hsk, synth_frames, 64, range(4))
+    _, total = ref.extract_cloud(cap=0)
+    lines = out.stdout.strip().splitlines()
+    assert lines[-1] == "done"
+    for tag in ("single", "group"):
+        rows = [ln.split() for ln in lines if ln.startswith(tag + " ")]
+        assert len(rows) == 4
+        for k, r in enumerate(rows):
+            assert int(r[2]) == int(want[k][1])
+            words = np.array([int(x, 16) for x in r[3:]], np.uint32)
+            assert np.array_equal(words, np.ascontiguousarray(want[k][0][:3, :4]).view(np.uint32).reshape(-1)), (tag, k)
+    assert int([ln for ln in lines if ln.startswith("cloud ")][0].split()[1]) == total
+    ref.close()
