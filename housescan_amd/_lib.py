@@ -195,7 +195,11 @@ def _share_torch_hip_runtime():
         try:
             C.CDLL(path, mode=C.RTLD_GLOBAL)
         except OSError:
-            pass  # fall back to the system runtime; a later `import torch` in this process may then fail
+            return  # fall back to the system runtime; a later `import torch` in this process may then fail
+        # ... and one RCCL: hsk_group_* loads RCCL at run time; beside torch's HIP runtime it must be torch's copy
+        rccl = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("HSK_RCCL_PATH", rccl)
 
 
 def load():

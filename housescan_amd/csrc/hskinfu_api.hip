@@ -1130,12 +1130,10 @@ extern "C" int hsk_mgpu_prefetch(hsk_ctx* k, const void* depth_dev, int w, int h
   if (k->set_used[set]) HIPCHK(k, hipStreamWaitEvent(k->pstream, k->ev_free[set], 0));  // its previous frame has finished
   const int keep = k->cur;
   k->cur = set;
-  // the frame may still be in the making on the context's (adopted) stream: order the second stream behind it
-  if (!k->own_stream) {
-    HIPCHK(k, hipEventRecord(k->ev_src, k->stream));
-    HIPCHK(k, hipStreamWaitEvent(k->pstream, k->ev_src, 0));
-  }
-  hipError_t e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->pstream);
+  // (No ordering against the context's stream: the point of the prefetch is to run beside the frame that stream is busy
+  // with.  The contract -- include/hskinfu.h -- asks for a frame that is complete when this is called; it may live in
+  // device memory or in pinned host memory, hence hipMemcpyDefault.)
+  hipError_t e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDefault, k->pstream);
   if (e == hipSuccess) {
     enqueue_preprocess(k, k->pstream);
     e = hipEventRecord(k->ev_pre[set], k->pstream);
@@ -1162,7 +1160,7 @@ extern "C" int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, in
     HIPCHK(k, hipStreamWaitEvent(k->stream, k->ev_pre[k->mgpu_set], 0));
   } else {
     k->cur = k->mgpu_set;  // same set as the previous frame: stream order protects it
-    HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDeviceToDevice, k->stream));
+    HIPCHK(k, hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, hipMemcpyDefault, k->stream));
     enqueue_preprocess(k, k->stream);
   }
   k->pf_ptr = nullptr;

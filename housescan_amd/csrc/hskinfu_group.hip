@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,10 +45,15 @@ Rccl* rccl(std::string* err) {
   static std::string why;
   if (!tried) {
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      R.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (R.so) break;
-    }
+    // One RCCL per process, and the one that belongs to the HIP runtime in use: (1) the copy the host names
+    // (HSK_RCCL_PATH: the Python mirror sets it to torch's when it shares torch's HIP runtime -- a second copy beside
+    // torch's corrupts the heap at exit), (2) a copy the process has loaded already, (3) the system's.
+    const char* named = getenv("HSK_RCCL_PATH");
+    if (named && *named) R.so = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    for (const char* name : {"librccl.so", "librccl.so.1"})
+      if (!R.so) R.so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!R.so) R.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (!R.so) {
       why = std::string("RCCL is not loadable: ") + dlerror();
     } else {
@@ -91,7 +97,6 @@ struct Slab {
 struct Dev {
   int id = 0;
   hipStream_t stream = nullptr;
-  uint16_t* depth = nullptr;  // the frame, uploaded once per device
   int* kmin = nullptr;        // MIN of the keys over all slabs (after the collective: over all devices)
   int* bsum = nullptr;        // SUM of the bit patterns
   double* sums = nullptr;     // double[27]
@@ -186,7 +191,6 @@ static void group_free(hsk_group* g) {
   for (auto& d : g->devs) {
     (void)hipSetDevice(d.id);
     if (d.comm && R) (void)R->CommDestroy(d.comm);
-    if (d.depth) (void)hipFree(d.depth);
     if (d.kmin) (void)hipFree(d.kmin);
     if (d.bsum) (void)hipFree(d.bsum);
     if (d.sums) (void)hipFree(d.sums);
@@ -241,7 +245,7 @@ static int group_build(const hsk_config* c, int n_total, int first, int n_local,
   }
   for (auto& d : g->devs) {
     if (hipSetDevice(d.id) != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&d.depth, P * 2) != hipSuccess || hipMalloc((void**)&d.kmin, P * 4) != hipSuccess ||
+        hipMalloc((void**)&d.kmin, P * 4) != hipSuccess ||
         hipMalloc((void**)&d.bsum, P * 24) != hipSuccess || hipMalloc((void**)&d.sums, 27 * sizeof(double)) != hipSuccess) {
       g->err = "hsk_group_create: device setup failed (device id out of range, or out of memory)";
       return bail(HSK_ERR_HIP);
@@ -417,13 +421,14 @@ static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* c
   for (size_t di = 0; di < g->devs.size(); ++di) {
     Dev& d = g->devs[di];
     GHIP(g, hipSetDevice(d.id));
-    const void* frame = d.depth;
-    if (src)
-      GHIP(g, hipMemcpyAsync(d.depth, src, P * 2, hipMemcpyHostToDevice, d.stream));
-    else
-      frame = depth_dev[di];
+    // the frame as every slab of this device reads it: the caller's device buffer, or the pinned staging slot itself
+    // (device-visible).  With a frame still in flight the copy + preprocessing go to each slab's second stream
+    // (hsk_mgpu_prefetch), beside the work the device's stream is busy with; the frame front then picks them up.
+    const void* frame = src ? (const void*)src : depth_dev[di];
+    const bool overlap = g->in_flight > 0 && !restart;
     for (int si : d.slabs) {
       Slab& s = g->slabs[si];
+      if (overlap) GSLAB(g, s, hsk_mgpu_prefetch(s.k, frame, w, h));
       if (icp_ar && !restart)
         GSLAB(g, s, hsk_mgpu_frame_begin(s.k, frame, w, h));
       else

@@ -119,7 +119,9 @@ int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n
  * torch.distributed) can run on them without a host round trip.  All work is enqueued on hsk_stream(). */
 int hsk_mgpu_frame_begin(hsk_ctx* k, const void* depth_dev, int w, int h); /* preprocess + (frame 0) transform */
 /* optional: enqueue the copy + preprocessing of the NEXT frame on a second stream, under the current frame's work; the
- * next hsk_mgpu_frame_begin with the same pointer picks it up (the pointer's contents must not change in between) */
+ * next hsk_mgpu_frame_begin with the same pointer picks it up.  depth_dev: device memory or pinned host memory holding
+ * a COMPLETE frame (host-synchronised: this call orders against no stream); its contents must not change until that
+ * hsk_mgpu_frame_begin has been enqueued */
 int hsk_mgpu_prefetch(hsk_ctx* k, const void* depth_dev, int w, int h);
 /* frame_begin + icp_replicated + integrate + raycast_local in one call; everything after the preprocessing is replayed
  * from a hipGraph (config use_graph).  keys_dev: int32[h*w], the SAME buffer on every call */
