@@ -1,19 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec fused (640x480 depth into a 512^3 TSDF): integrate + ICP + raycast per frame.
 
-One "step" = one whole tracker step (`hsk_process_frame_dev`: bilateral/pyramid/maps, 19 ICP iterations,
-TSDF integrate, TSDF raycast, model pyramid) on one synthetic 640x480 depth frame that is already resident
-in HBM when the timed region starts.  Prints ONE JSON line (see the task contract) with the extra objects
-`roofline` (integrate kernel vs the HBM roofline, algorithmic bytes = 8 B x V_upd + 2 B x W x H, SURVEY.md
-8(d)) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+One "step" = one whole tracker step (bilateral / pyramid / maps, 19 ICP iterations, TSDF integrate, TSDF raycast, model
+pyramid) on one synthetic 640x480 depth frame that is already resident in HBM when the timed region starts.  Prints ONE
+JSON line (the task contract) with, beside the contract's keys (SURVEY.md 8(d), row by row):
 
-  python bench.py                       # 1 GPU, 512^3
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   # z-slab sharded
+  roofline        integrate stage vs the HBM roofline: algorithmic bytes = 8 B x V_upd + 2 B x W x H per launch (V_upd
+                  counted by the library's own count-only kernels), duration from HIP events on the library's stream over a
+                  replay of exactly the timed frames; `traffic` = HBM bytes per launch from FETCH_SIZE / WRITE_SIZE passes of
+                  rocprofv3 over the same frames, run as child processes of THIS invocation (null when rocprofv3 is absent)
+  roofline_1024   the same on a 1024^3 volume (the HBM measurement: 4 GiB, sixteen times the Infinity Cache)
+  stage_us, icp_us_per_iter, frame_ms (median / p10 / p90), raycast (rays/s, algorithmic GB/s from oracle-counted steps)
+  pcie_inclusive  the same frames handed over as HOST buffers (the real shape of HoniHelper.hs:20), pipelined
+  cpu_baseline    the CPU oracle (kind "port") on this box's host cores: all cores and one thread, built -O3 -march=native
+
+  python bench.py                                   # 1 GPU, 512^3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+      z-slab sharded over N GPUs through the C ABI (hsk_group_*: RCCL inside the library); torch.distributed (gloo) only
+      hands the communicator id round and takes the max over the ranks' clocks
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -22,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+W, H = 640, 480
 
 
 def make_frames(hsk, first, count):
@@ -29,138 +44,400 @@ def make_frames(hsk, first, count):
     return poses, [hsk.synth_depth(p) for p in poses]
 
 
-def cpu_baseline(volume, sample_frames, hsk):
-    """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload: frames 0..sample_frames."""
-    from oracle import oracle as O
-    threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    cfg = O.default_config(volume, omp=True)
-    trk = O.Tracker(cfg, omp=True)
-    _, frames = make_frames(hsk, 0, sample_frames + 1)
-    trk.process(frames[0])  # frame 0 is the untracked first frame (integrate only)
-    t0 = time.perf_counter()
-    done = 0
-    for d in frames[1:]:
-        trk.process(d)
-        done += 1
-        if done >= 8 and time.perf_counter() - t0 > 12.0:  # bounded: about 12 s of CPU work, at least 8 frames
-            break
-    dt = time.perf_counter() - t0
-    sample_frames = done
-    stages = trk.stage_seconds()
-    trk.close()
-    return {
-        "value": round(sample_frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-        "sample": f"{sample_frames} tracked frames of the same synthetic stream into a {volume}^3 TSDF "
-                  f"(oracle/kinfu_oracle.c, gcc -O2 -fopenmp, {threads} threads)",
-        "stage_seconds": {"preprocess": round(stages[0], 3), "icp": round(stages[1], 3),
-                          "integrate": round(stages[2], 3), "raycast": round(stages[3], 3)},
-    }
-
-
-def pmc_traffic(volume):
-    """HBM bytes per integrate launch from the committed PMC passes (tools/pmc.sh: separate --pmc runs of this
-    same command; FETCH_SIZE in KiB doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE in KiB)."""
-    path = os.path.join(ROOT, "profiles", "latest_integrate_traffic.json")
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the only place, with the raycast step count, where bench.py touches oracle/)
+# ---------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """the CPU cores this process can really use: its affinity mask, cut down to the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs quota) -- 256 OpenMP threads on a 16-core quota run 30 times slower than 16"""
     try:
-        with open(path) as f:
-            t = json.load(f)
-        return t["bytes_per_launch"] if int(t.get("volume", 0)) == int(volume) else None
-    except (OSError, ValueError, KeyError):
-        return None
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--volume", type=int, default=512)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2; the API allows 3 in flight)")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="upper bound of the CPU sample (it stops after about 12 s)")
-    ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
-    ap.add_argument("--slab-graph", type=int, default=0, help="replay the z-slab frame front from a hipGraph (default: eager)")
-    ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of the submit/wait pair")
-    ap.add_argument("--mode", choices=["slab", "rooms"], default="slab")
-    ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
-    ap.add_argument("--host-frames", action="store_true", help="also time hsk_process_frame with HOST depth buffers (PCIe-inclusive)")
-    ap.add_argument("--force-sharded", action="store_true", help="use the z-slab host + collectives even at 1 GPU (plumbing check)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the check below)")
-    ap.add_argument("--share-gpu", action="store_true", help="all ranks on device 0 (with --backend gloo: a logic check of the "
-                    "N > 1 path on a one-GPU box; its numbers mean nothing)")
-    args = ap.parse_args()
 
-    import torch
+def cpu_baseline(volume, hsk, budget_s=12.0):
+    """Oracle (CPU restatement, kind "port") on a bounded sample of the same workload, all host cores, then one thread."""
+    from oracle import oracle as O
+    threads = host_cores()
+    native = O.build_native() is not None
+    mode = "native" if native else True
+    build = "gcc -O3 -march=native -fopenmp" if native else "gcc -O3 -fopenmp (portable build: the native one could not be built here)"
 
-    import housescan_amd as hsk
+    def run(nthreads, budget, min_frames):
+        O.lib(mode).ora_set_threads(int(nthreads))
+        cfg = O.default_config(volume, omp=mode)
+        trk = O.Tracker(cfg, omp=mode)
+        _, frames = make_frames(hsk, 0, 64)
+        trk.process(frames[0])  # frame 0 is the untracked first frame (integrate only)
+        t0 = time.perf_counter()
+        done = 0
+        for d in frames[1:]:
+            trk.process(d)
+            done += 1
+            if done >= min_frames and time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        stages = trk.stage_seconds()
+        trk.close()
+        return done, dt, stages
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or args.force_sharded:
-        import torch.distributed as dist
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    n_all, dt_all, st_all = run(threads, budget_s, 8)
+    out = {
+        "value": round(n_all / dt_all, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{n_all} tracked frames of the same synthetic stream into a {volume}^3 TSDF (oracle/kinfu_oracle.c, {build}, "
+                  f"{threads} threads = the cores of this container's CPU quota; about {budget_s:.0f} s of CPU work)",
+        "stage_seconds": {"preprocess": round(st_all[0], 3), "icp": round(st_all[1], 3), "integrate": round(st_all[2], 3),
+                          "raycast": round(st_all[3], 3)},
+    }
+    n_one, dt_one, _ = run(1, 0.6 * budget_s, 2)
+    out["single_thread"] = {"value": round(n_one / dt_one, 4), "unit": "frames/s", "cores": 1,
+                            "sample": f"{n_one} tracked frames, same build, one OpenMP thread"}
+    return out
 
-    K, Wm = args.steps, args.warmup
-    n = args.volume
-    total = 1 + Wm + K  # frame 0 is the untracked first frame
-    poses_gt, frames = make_frames(hsk, 0, total)
-    host_extra = make_frames(hsk, total, 180)[1] if args.host_frames else []
-    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)  # one upload
-    dev_frames = [dev_all[i] for i in range(len(frames))]
-    torch.cuda.synchronize()
 
-    if world > 1 or args.force_sharded:
-        from housescan_amd.sharded import ShardedKinfu
-        eng = ShardedKinfu(n, rank, world, local_rank, mode=args.mode, icp=args.icp, force_collectives=args.force_sharded,
-                           use_graph=args.slab_graph)
-        step = eng.process_frame_dev
-        trk = eng.tracker
-    else:
-        trk = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=args.graph)
-        step = lambda t: trk.process_frame_dev(t.data_ptr())  # noqa: E731
+def raycast_algorithmic_bytes(volume, trk, pose):
+    """B_ray = sum over rays (n_steps x 4 B + [hit] x 64 taps x 4 B) + 2 x 3 x W x H x 4 B, with the march
+    steps counted by the oracle on the very volume and pose the GPU raycast ran on"""
+    from oracle import oracle as O
+    cfg = O.default_config(volume, omp=True)
+    vol = trk.download_tsdf()
+    _, _, keys, n_steps = O.raycast(cfg, vol, pose, omp=True)
+    hits = int(((keys != O.KEY_NONE) & ((keys & 1) == 0)).sum())
+    return int(n_steps) * 4 + hits * 64 * 4 + 2 * 3 * W * H * 4, int(n_steps), hits
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    # warmup (includes frame 0 and the hipGraph capture)
+# ---------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the integrate stage from PMC counters, collected by child processes of this run
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(volume, total, window_first, timeout_s=150):
+    """FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes: they do not fit one) over a replay of the same frames by
+    tools/replay_frames.py; mean over the integrate launches of the timed window.  gfx950: FETCH_SIZE counts 64 B per
+    128-B request on wide streams, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.  KiB units."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="hsk_pmc_")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "replay_frames.py"), str(volume), str(total)]
+            try:
+                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s, check=True)
+            except (subprocess.SubprocessError, OSError) as e:
+                return None, f"rocprofv3 --pmc {ctr} failed: {type(e).__name__}"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr} wrote no counter file"
+            rows = {}
+            for r in csv.DictReader(open(files[0])):
+                name = r["Kernel_Name"]
+                if name.startswith("void k_integrate<false") or name.startswith("void k_integrate_detail2<false") or \
+                        name.startswith("k_column_zrange"):
+                    rows.setdefault(name.split("(")[0], []).append(float(r["Counter_Value"]))
+            per[ctr] = rows
+        kib = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        for ctr, rows in per.items():
+            for name, vals in rows.items():
+                win = vals[window_first:total]   # one launch per frame, frame 0 included: index = frame number
+                kib[ctr] += float(np.mean(win)) if win else 0.0
+        fetch, write = kib["FETCH_SIZE"] * 1024 * 2, kib["WRITE_SIZE"] * 1024
+        return int(fetch + write), {"fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
+                                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of tools/replay_frames.py over the "
+                                              "same frames as the timed region; mean per frame of the three integrate kernels"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, sync_api=False):
+    """the timed region at one GPU: warm-up, then K frames through hsk_submit_frame_dev / hsk_wait_frame"""
+    trk = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=graph)
+    total = 1 + Wm + K
     lost = 0
     for i in range(1 + Wm):
-        _, ok = step(dev_frames[i])
-    use_async = world == 1 and not args.force_sharded and not args.sync_api
-    barrier()
+        trk.process_frame_dev(dev_frames[i].data_ptr())
+    torch.cuda.synchronize()
+    stamps = []
     t0 = time.perf_counter()
-    if use_async:
-        # hsk_submit_frame_dev / hsk_wait_frame: frame i+1 is enqueued before the pose of frame i is read back
-        ahead = max(1, min(args.ahead, 2, K - 1))
-        for i in range(1 + Wm, 1 + Wm + ahead):
+    if sync_api:
+        for i in range(1 + Wm, total):
+            pose, ok = trk.process_frame_dev(dev_frames[i].data_ptr())
+            lost += (not ok)
+            stamps.append(time.perf_counter())
+    else:
+        ahead = max(1, min(ahead, 2, K - 1)) if K > 1 else 1
+        for i in range(1 + Wm, min(1 + Wm + ahead, total)):
             trk.submit_frame_dev(dev_frames[i].data_ptr())
         for i in range(1 + Wm + ahead, total):
             trk.submit_frame_dev(dev_frames[i].data_ptr())
             pose, ok = trk.wait_frame()
             lost += (not ok)
-        for _ in range(ahead):
+            stamps.append(time.perf_counter())
+        for _ in range(min(ahead, K)):
             pose, ok = trk.wait_frame()
             lost += (not ok)
-    elif (world > 1 or args.force_sharded) and args.mode == "slab" and args.icp == "replicated" and not args.sync_api:
-        # pipelined slab frames: frame i + 1 (with its collectives) is enqueued before the pose of frame i is read;
-        # the next frame is named so that its preprocessing overlaps on the second stream
+            stamps.append(time.perf_counter())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per = np.diff(np.array([t0] + stamps)) * 1e3
+    return trk, pose, lost, elapsed, per
+
+
+def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose):
+    """stage times, ICP level times and V_upd over exactly the timed frames (a second context with events around every
+    stage: the timed loop carries none, they would sit in the pipelined stream)"""
+    total = 1 + Wm + K
+    rep = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=0)
+    rep.set_profiling(True)
+    rep_poses = {}
+    sample = list(range(1 + Wm, total, max(1, K // 10)))
+    p = None
+    for i in range(total):
+        if i == 1 + Wm:
+            rep.stage_ms(reset=True)  # warm-up frames are not part of the timed region
+        p, _ = rep.process_frame_dev(dev_frames[i].data_ptr())
+        if i in sample:
+            rep_poses[i] = p.copy()
+    icp_ms = rep.icp_level_ms()
+    ms, nf = rep.stage_ms(reset=True)
+    rep.set_profiling(False)
+    if final_pose is not None:
+        assert np.array_equal(p, final_pose), "the replay must reproduce the timed run's final pose bit for bit"
+    vupd = [rep.count_updates(frames[i], rep_poses[i]) for i in sample]
+    return rep, ms, nf, icp_ms, float(np.mean(vupd)), p
+
+
+def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
+    t_int = ms[2] / nf * 1e-3
+    alg_bytes = 8.0 * v_mean + 2.0 * W * H
+    achieved = alg_bytes / t_int / 1e9
+    touched_mib = alg_bytes / 2 / (1 << 20)  # the voxels a frame rewrites, 4 B each
+    block = {
+        "bound": "hbm",
+        "kernel": "integrate stage: k_column_zrange + k_integrate<false> (pass A) + k_integrate_detail2<false> (pass B), one event pair",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
+        "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
+        "window": "the frames of the timed region, replayed with HIP events between the stages (non-pipelined replay: preprocessing on the "
+                  "main stream, the frame's last ICP solve in a launch of its own)",
+        "sweep_GBps_upper_bound_bytes_not_algorithmic": round(8.0 * n ** 3 / t_int / 1e9, 1),
+        "cache_note": ("%d^3 x 4 B = %d MiB volume, of which a frame rewrites %.0f MiB; the Infinity Cache holds 256 MiB, so part of the "
+                       "touched set stays MALL-resident from frame to frame: partly cache-resident, not a pure HBM measurement "
+                       "(roofline_1024 is)" % (n, n ** 3 * 4 >> 20, touched_mib)) if n ** 3 * 4 <= (1 << 30) else
+                      ("%d^3 x 4 B = %d MiB volume, a frame rewrites %.0f MiB: far beyond the 256 MiB Infinity Cache => HBM measurement"
+                       % (n, n ** 3 * 4 >> 20, touched_mib)),
+    }
+    if traffic_info is not None:
+        block["traffic_detail"] = traffic_info
+    return block
+
+
+def run_single(args, hsk, torch, local_rank):
+    K, Wm, n = args.steps, args.warmup, args.volume
+    total = 1 + Wm + K
+    poses_gt, frames = make_frames(hsk, 0, total)
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)  # one upload
+    dev_frames = [dev_all[i] for i in range(total)]
+    torch.cuda.synchronize()
+    trk, pose, lost, elapsed, per = timed_single(hsk, torch, n, K, Wm, args.ahead, dev_frames, local_rank, args.graph, args.sync_api)
+    gt = poses_gt[total - 1]
+    out = {
+        "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
+        "value": round(K / elapsed, 2), "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+        "config": {"workload": "configs[2]-shaped: synthetic 640x480 depth @ scripted trajectory into %d^3 TSDF, 3 m cube, "
+                               "integrate + 19-iteration ICP + raycast per frame" % n,
+                   "volume": n, "image": [W, H], "icp_iters": [10, 5, 4], "parallelism": "1 gpu", "graph": bool(args.graph),
+                   "api": "process_frame (sync per frame)" if args.sync_api else "submit/wait (%d frame(s) in flight ahead)" % max(1, min(args.ahead, 2))},
+        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
+                     "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
+        "frame_ms": {"median": round(float(np.median(per)), 4), "p10": round(float(np.percentile(per, 10)), 4),
+                     "p90": round(float(np.percentile(per, 90)), 4),
+                     "note": "host clock between consecutive hsk_wait_frame returns over the timed region"},
+    }
+    # ---- stage times + roofline of the dominant kernel group (integrate) ----
+    rep, ms, nf, icp_ms, v_mean, _ = replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, pose)
+    traffic, tinfo = (None, "skipped (--no-traffic)")
+    if not args.no_traffic:
+        traffic, tinfo = pmc_traffic(n, total, 1 + Wm)
+    out["roofline"] = roofline_block(n, ms, nf, v_mean, traffic, tinfo if isinstance(tinfo, dict) else None)
+    if traffic is None:
+        out["roofline"]["traffic_note"] = str(tinfo)
+    out["stage_us"] = {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1), "integrate": round(ms[2] / nf * 1e3, 1),
+                       "raycast": round(ms[3] / nf * 1e3, 1),
+                       "note": "means over the %d frames of the timed region, replayed with HIP events between the stages" % nf}
+    iters = [10, 5, 4]
+    out["icp_us_per_iter"] = {"fine_640x480": round(icp_ms[0] / nf / iters[0] * 1e3, 2), "mid_320x240": round(icp_ms[1] / nf / iters[1] * 1e3, 2),
+                              "coarse_160x120": round(icp_ms[2] / nf / iters[2] * 1e3, 2),
+                              "note": "latency-bound (19 dependent launches): microseconds per iteration, not a roofline fraction"}
+    t_ray = ms[3] / nf * 1e-3
+    out["raycast"] = {"rays_per_s": round(W * H / t_ray, 0), "us": round(t_ray * 1e6, 1)}
+    if not args.no_cpu_baseline:
+        b_ray, n_steps, hits = raycast_algorithmic_bytes(n, rep, rep.get_pose())
+        out["raycast"].update({"algorithmic_bytes": b_ray, "GBps": round(b_ray / t_ray / 1e9, 1), "march_steps_oracle": n_steps, "hit_rays": hits,
+                               "note": "B_ray = steps x 4 B + hits x 64 taps x 4 B + map writes (SURVEY.md 8(d)); steps counted by the oracle on "
+                                       "the volume and pose of the last timed frame; gather / latency-bound, reported as rays/s"})
+    rep.close()
+    # ---- the frames handed over as HOST buffers (PCIe-inclusive), pipelined ----
+    if not args.no_host_frames:
+        hf = make_frames(hsk, total, min(60, max(8, K)))[1]
+        trk.synchronize()
+        t1 = time.perf_counter()
+        trk.submit_frame(hf[0])
+        stamps = []
+        for f in hf[1:]:
+            trk.submit_frame(f)
+            trk.wait_frame()
+            stamps.append(time.perf_counter())
+        trk.wait_frame()
+        t2 = time.perf_counter()
+        per_h = np.diff(np.array([t1] + stamps + [t2]))
+        out["pcie_inclusive_pipelined_fps"] = round(len(hf) / (t2 - t1), 2)
+        out["pcie_inclusive_note"] = ("hsk_submit_frame / hsk_wait_frame with HOST frames (memcpy into a pinned ring, H2D under the previous "
+                                      "frame), %d frames; worst single frame %.2f ms" % (len(hf), float(per_h.max()) * 1e3))
+    trk.close()
+    # ---- 1024^3: the HBM measurement ----
+    if n == 512 and not args.no_1024:
+        K2, W2 = min(K, 40), min(Wm, 5)
+        tot2 = 1 + W2 + K2
+        trk2, pose2, lost2, el2, _ = timed_single(hsk, torch, 1024, K2, W2, args.ahead, dev_frames[:tot2], local_rank)
+        trk2.close()
+        rep2, ms2, nf2, _, v2, _ = replay_with_events(hsk, 1024, K2, W2, frames[:tot2], dev_frames[:tot2], local_rank, pose2)
+        rep2.close()
+        blk = roofline_block(1024, ms2, nf2, v2, None, None)
+        blk["traffic_note"] = "not collected for this block"
+        blk.update({"frames_per_s": round(K2 / el2, 2), "steps": K2, "warmup": W2, "lost_frames": int(lost2),
+                    "stage_us": {"preprocess": round(ms2[0] / nf2 * 1e3, 1), "icp": round(ms2[1] / nf2 * 1e3, 1),
+                                 "integrate": round(ms2[2] / nf2 * 1e3, 1), "raycast": round(ms2[3] / nf2 * 1e3, 1)}})
+        out["roofline_1024"] = blk
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, hsk)
+    return out
+
+
+def run_multi(args, hsk, torch, world, rank, local_rank):
+    """N > 1: z-slabs (one per rank) through the C ABI's hsk_group_* (RCCL inside the library), or one room per GPU"""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # host-side only: the id, the barrier, the max of the clocks
+    K, Wm, n = args.steps, args.warmup, args.volume
+    total = 1 + Wm + K
+    poses_gt, frames = make_frames(hsk, 0, total)
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+    dev_frames = [dev_all[i] for i in range(total)]
+    torch.cuda.synchronize()
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    lost = 0
+    if args.mode == "rooms":
+        trk = hsk.KinfuTracker(n=n, device_id=local_rank)
+        submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
+        first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
+        wait = trk.wait_frame
+    else:
+        ids = [hsk.KinfuGroup.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        flags = hsk.GROUP_ICP_ALLREDUCE if args.icp == "allreduce" else 0
+        trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
+        submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
+
+        def first(i):
+            submit(i)
+            return trk.wait_frame()
+        wait = trk.wait_frame
+    for i in range(1 + Wm):
+        first(i)
+    barrier()
+    t0 = time.perf_counter()
+    submit(1 + Wm)
+    for i in range(2 + Wm, total):
+        submit(i)
+        pose, ok = wait()
+        lost += (not ok)
+    pose, ok = wait()
+    lost += (not ok)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    rooms = world if args.mode == "rooms" else 1
+    gt = poses_gt[total - 1]
+    out = {
+        "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
+        "value": round(rooms * K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True,
+        "scaling": "weak" if rooms > 1 else "strong", "vs_baseline": None,
+        "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n if rooms == 1 else
+                               "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n,
+                   "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
+                   "parallelism": ("slab%d-icp-%s" % (world, args.icp)) if rooms == 1 else "rooms%d" % world,
+                   "api": "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI; RCCL inside the library), 1 frame in flight ahead"
+                   if rooms == 1 else "hsk_submit_frame_dev / hsk_wait_frame"},
+        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
+                     "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
+    }
+    trk.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def run_multi_torch(args, hsk, torch, world, rank, local_rank):
+    """The N > 1 slab flow with the collectives issued from Python through torch.distributed (housescan_amd/sharded.py:
+    the harness the group call was checked against).  --backend gloo --share-gpu runs all ranks on device 0: a logic
+    check of the flow on a one-GPU box, its numbers mean nothing."""
+    import torch.distributed as dist
+    from housescan_amd.sharded import ShardedKinfu
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    K, Wm, n = args.steps, args.warmup, args.volume
+    total = 1 + Wm + K
+    poses_gt, frames = make_frames(hsk, 0, total)
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+    dev_frames = [dev_all[i] for i in range(total)]
+    torch.cuda.synchronize()
+    eng = ShardedKinfu(n, rank, world, local_rank, mode="slab", icp=args.icp)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    lost = 0
+    for i in range(1 + Wm):
+        eng.process_frame_dev(dev_frames[i])
+    barrier()
+    t0 = time.perf_counter()
+    if args.icp == "replicated":
         nxt = lambda i: dev_frames[i + 1] if i + 1 < total else None  # noqa: E731
         eng.submit_frame_dev(dev_frames[1 + Wm], nxt(1 + Wm))
         for i in range(2 + Wm, total):
@@ -169,136 +446,76 @@ def main():
             lost += (not ok)
         pose, ok = eng.wait_frame()
         lost += (not ok)
-    elif world > 1 or args.force_sharded:
-        for i in range(1 + Wm, total):
-            pose, ok = step(dev_frames[i], dev_frames[i + 1] if i + 1 < total else None)
-            lost += (not ok)
     else:
         for i in range(1 + Wm, total):
-            pose, ok = step(dev_frames[i])
+            pose, ok = eng.process_frame_dev(dev_frames[i], dev_frames[i + 1] if i + 1 < total else None)
             lost += (not ok)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    rooms = world if (world > 1 and args.mode == "rooms") else 1
-    fps = rooms * K / elapsed
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
     gt = poses_gt[total - 1]
-    err_mm = float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0)
-
     out = {
         "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True,
-        "scaling": "weak" if rooms > 1 else ("strong" if world > 1 else "weak"),
-        "vs_baseline": None, "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
-        "config": {"workload": "configs[2]-shaped: synthetic 640x480 depth @ scripted trajectory into %d^3 TSDF, "
-                               "3 m cube, integrate + 19-iteration ICP + raycast per frame" % n,
-                   "volume": n, "image": [640, 480], "icp_iters": [10, 5, 4],
-                   "parallelism": ("1 gpu" if world == 1 else f"{args.mode}{world}" + (f"-icp-{args.icp}" if args.mode == "slab" else "")),
-                   "graph": bool(args.graph), **({"check_only": "all ranks share device 0 over %s" % args.backend} if args.share_gpu else {}),
-                   "api": ("submit/wait (%d frame(s) in flight ahead)" % (max(1, min(args.ahead, 2)) if use_async else 1)) if (use_async or ((world > 1 or args.force_sharded) and args.mode == "slab"
-                                                                                    and args.icp == "replicated" and not args.sync_api))
-                   else "process_frame (sync per frame)"},
-        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(err_mm, 3),
+        "value": round(K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n, "volume": n, "image": [W, H],
+                   "icp_iters": [10, 5, 4], "parallelism": "slab%d-icp-%s" % (world, args.icp),
+                   "api": "housescan_amd/sharded.py over torch.distributed (%s)" % args.backend,
+                   **({"check_only": "all ranks share device 0 over %s" % args.backend} if args.share_gpu else {})},
+        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
                      "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
     }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out if rank == 0 else None
 
-    if rank == 0 and world == 1 and not args.force_sharded:
-        # ---- roofline of the dominant kernel (integrate), HIP events on the library's own stream ----
-        # The timed loop above carries no events (they would sit in the pipelined stream), so the SAME frames are
-        # replayed through a second context with an event pair around every stage: the stream is deterministic, so frame
-        # i of the replay does exactly the work frame i of the timed region did (same poses, same volume, same weights --
-        # the first 128 frames write every voxel they touch, later ones skip the stores of saturated free space).
-        rep = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=0)
-        rep.set_profiling(True)
-        rep_poses = {}
-        sample = list(range(1 + Wm, total, max(1, K // 10)))
-        for i in range(total):
-            if i == 1 + Wm:
-                rep.stage_ms(reset=True)  # warm-up frames are not part of the timed region
-            p, ok = rep.process_frame_dev(dev_frames[i].data_ptr())
-            if i in sample:
-                rep_poses[i] = p.copy()
-        ms, nf = rep.stage_ms(reset=True)
-        rep.set_profiling(False)
-        assert np.array_equal(p, pose), "the replay must reproduce the timed run's final pose bit for bit"
-        vupd = [rep.count_updates(frames[i], rep_poses[i]) for i in sample]
-        rep.close()
-        t_int = ms[2] / nf * 1e-3
-        v_mean = float(np.mean(vupd))
-        alg_bytes = 8.0 * v_mean + 2.0 * 640 * 480
-        achieved = alg_bytes / t_int / 1e9
-        sweep = 8.0 * n ** 3 / t_int / 1e9
-        out["roofline"] = {
-            "bound": "hbm",
-            "kernel": "integrate stage: k_column_zrange + k_integrate<false> (pass A) + k_integrate_detail<false> (pass B), one event pair",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n),
-            "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
-            "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
-            "window": "the frames of the timed region (replayed with events); rocprofv3 --stats averages the whole run, warm-up included",
-            "sweep_GBps_upper_bound_bytes_not_algorithmic": round(sweep, 1),
-            "cache_note": ("%d^3 x 4 B = %d MiB; > 256 MiB Infinity Cache => HBM measurement" % (n, n ** 3 * 4 >> 20))
-            if n ** 3 * 4 > (256 << 20) else "volume fits the 256 MiB Infinity Cache: cache-resident, NOT an HBM measurement",
-        }
-        out["stage_us"] = {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1),
-                           "integrate": round(ms[2] / nf * 1e3, 1), "raycast": round(ms[3] / nf * 1e3, 1),
-                           "note": "means over the %d frames of the timed region, replayed with HIP events between the stages" % nf}
-        if args.host_frames:
-            hf = host_extra[:60]
-            trk.synchronize()
-            t1 = time.perf_counter()
-            for f in hf:
-                trk.process_frame(f)
-            out["pcie_inclusive_fps"] = round(len(hf) / (time.perf_counter() - t1), 2)
-            hf2 = host_extra[60:]
-            trk.synchronize()
-            lost2, per = 0, []
-            t1 = time.perf_counter()
-            trk.submit_frame(hf2[0])
-            for f in hf2[1:]:
-                trk.submit_frame(f)
-                lost2 += not trk.wait_frame()[1]
-                per.append(time.perf_counter())
-            lost2 += not trk.wait_frame()[1]
-            t2 = time.perf_counter()
-            per = np.diff(np.array([t1] + per + [t2]))
-            out["pcie_inclusive_pipelined_fps"] = round(len(hf2) / (t2 - t1), 2)
-            # the HIP runtime was seen to hold one H2D copy back for ~40 ms once per process (GPU idle, copy enqueued:
-            # profiles/r01/host_frames_note.md); the figure without the single worst frame is the steady state
-            out["pcie_inclusive_pipelined_worst_frame_ms"] = round(float(per.max()) * 1e3, 3)
-            out["pcie_inclusive_pipelined_fps_excl_worst"] = round((len(hf2) - 1) / (t2 - t1 - float(per.max())), 2)
-            out["pcie_inclusive_pipelined_lost"] = int(lost2)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_frames, hsk)
-    if (world > 1 or args.force_sharded) and args.mode == "slab":
-        # configs[4] beside the z-slab number: every GPU scans its own room (a full volume per rank, no data-path
-        # collective), aggregated over the ranks -- weak scaling of the same fused frame
-        room = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=args.graph)
-        k2 = min(K, 100)
-        for i in range(1 + Wm):
-            room.process_frame_dev(dev_frames[i].data_ptr())
-        barrier()
-        t1 = time.perf_counter()
-        room.submit_frame_dev(dev_frames[1 + Wm].data_ptr())
-        for i in range(2 + Wm, 1 + Wm + k2):
-            room.submit_frame_dev(dev_frames[i].data_ptr())
-            room.wait_frame()
-        room.wait_frame()
-        barrier()
-        el2 = time.perf_counter() - t1
-        tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        out["independent_rooms"] = {"value": round(world * k2 / float(tt.item()), 2), "unit": "frames/s", "scaling": "weak",
-                                    "steps": k2, "note": "one %d^3 volume per GPU, no collective (BASELINE configs[4])" % n}
-        room.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the oracle-counted raycast bytes)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
+    ap.add_argument("--no-1024", action="store_true", help="skip the 1024^3 roofline block")
+    ap.add_argument("--no-host-frames", action="store_true", help="skip the PCIe-inclusive (host frame) figure")
+    ap.add_argument("--quick", action="store_true", help="all four of the above")
+    ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
+    ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
+    ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of submit/wait")
+    ap.add_argument("--mode", choices=["slab", "rooms"], default="slab", help="N > 1: z-slabs of one volume, or one room per GPU")
+    ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
+    ap.add_argument("--engine", choices=["group", "torch"], default="group",
+                    help="N > 1 slabs: hsk_group_* (C ABI, RCCL inside the library) or the Python harness over torch.distributed")
+    ap.add_argument("--backend", default="nccl", help="--engine torch: torch.distributed backend (nccl = RCCL; gloo for the check below)")
+    ap.add_argument("--share-gpu", action="store_true", help="--engine torch: all ranks on device 0 (logic check on a one-GPU box)")
+    args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = True
+
+    import torch
+
+    import housescan_amd as hsk
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world == 1 and not os.environ.get("HSK_BENCH_FORCE_MULTI"):  # (the variable: the N > 1 flow on a world of one rank, for the tests)
+        out = run_single(args, hsk, torch, local_rank)
+    elif args.engine == "torch" and args.mode == "slab":
+        out = run_multi_torch(args, hsk, torch, world, rank, local_rank)
+    else:
+        out = run_multi(args, hsk, torch, world, rank, local_rank)
+    if rank == 0 and out is not None:
         # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then
         sys.stdout.flush()
         try:

@@ -44,7 +44,8 @@ void launch_begin_frame(hipStream_t s, TrackState* st, void* icp_pose_buf);
 size_t icp_pose_bytes();
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
-                      void* pose_buf, double* part_a, double* part_b, IcpFinal* defer_final = nullptr);
+                      void* pose_buf, double* part_a, double* part_b, IcpFinal* defer_final = nullptr,
+                      hipEvent_t* level_events = nullptr);
 bool host_solve6(const double* in27, float* x6);
 void host_pose_update(float* R, float* t, const float* x6);
 void hsk_build_tet_table(TetTable* tt);

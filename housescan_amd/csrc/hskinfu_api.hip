@@ -100,6 +100,8 @@ struct hsk_ctx {
   // profiling
   bool prof = false;
   hipEvent_t ev[HSK_NSTAGES + 1] = {};
+  hipEvent_t ev_icp[HSK_NLEVELS + 1] = {};  // profiling: start of each ICP level (coarsest first) and the end of the last
+  double icp_level_ms[HSK_NLEVELS] = {};    // ... summed per level, index = level (0 = finest)
   double stage_ms[HSK_NSTAGES] = {};
   uint64_t prof_frames = 0;
 };
@@ -235,6 +237,8 @@ static void free_all(hsk_ctx* k) {
   for (auto& e : k->ring_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : k->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : k->ev_icp)
     if (e) (void)hipEventDestroy(e);
   if (k->own_stream && k->stream) (void)hipStreamDestroy(k->stream);
 }
@@ -410,6 +414,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     CK(hipMemcpy(k->d_wc, wc, sizeof(wc), hipMemcpyHostToDevice));
   }
   for (auto& e : k->ev) CK(hipEventCreate(&e));
+  for (auto& e : k->ev_icp) CK(hipEventCreate(&e));
 #undef CK
   int r = do_reset(k);
   if (r != HSK_OK) return bail(r);
@@ -473,7 +478,8 @@ static void enqueue_preprocess(hsk_ctx* k, hipStream_t s) {
 static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
   if (fin) *fin = IcpFinal{nullptr, nullptr, 0};
   launch_icp_fused(k->stream, k->B().d_vcur, k->B().d_ncur, k->d_vmod, k->d_nmod, k->lv, k->cfg.icp_iters, k->d_st,
-                   k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2, fin);
+                   k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2, fin,
+                   (k->prof && !fin) ? k->ev_icp : nullptr);
 }
 
 static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr) {
@@ -590,6 +596,10 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
     for (int i = 0; i < HSK_NSTAGES; ++i) {
       float ms = 0.0f;
       if (hipEventElapsedTime(&ms, k->ev[i], k->ev[i + 1]) == hipSuccess) k->stage_ms[i] += ms;
+    }
+    for (int i = 0; i < HSK_NLEVELS; ++i) {  // event i starts level HSK_NLEVELS - 1 - i
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, k->ev_icp[i], k->ev_icp[i + 1]) == hipSuccess) k->icp_level_ms[HSK_NLEVELS - 1 - i] += ms;
     }
     k->prof_frames += 1;
   }
@@ -1109,8 +1119,14 @@ extern "C" int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_
   if (n_frames) *n_frames = k->prof_frames;
   if (reset) {
     for (int i = 0; i < HSK_NSTAGES; ++i) k->stage_ms[i] = 0.0;
+    for (int i = 0; i < HSK_NLEVELS; ++i) k->icp_level_ms[i] = 0.0;
     k->prof_frames = 0;
   }
+  return HSK_OK;
+}
+extern "C" int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]) {
+  if (!k || !sum_ms) return HSK_ERR_ARG;
+  for (int i = 0; i < HSK_NLEVELS; ++i) sum_ms[i] = k->icp_level_ms[i];
   return HSK_OK;
 }
 

@@ -841,7 +841,7 @@ static inline double* icp_slots(void* pose_buf) { return (double*)((char*)pose_b
 // enqueue the whole ICP of one frame: levels coarse -> fine, iters[l] iterations each
 void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, float* const* vmod, float* const* nmod,
                       const ImgLevel* lv, const int* iters, TrackState* st, float dist_thresh, float angle_thresh,
-                      void* pose_buf, double* part_a, double* part_b, IcpFinal* defer_final) {
+                      void* pose_buf, double* part_a, double* part_b, IcpFinal* defer_final, hipEvent_t* level_events) {
   (void)part_a;
   (void)part_b;
   static_assert(2 * sizeof(IcpPose) <= ICP_POSE_AREA, "pose ping-pong must fit its area");
@@ -852,6 +852,7 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
   for (int l = HSK_NLEVELS - 1; l >= 0; --l) {
     const int W = lv[l].W, H = lv[l].H;
     const int nb = icp_num_blocks(W, H);
+    if (level_events) (void)hipEventRecord(level_events[HSK_NLEVELS - 1 - l], s);  // profiling: the level's iterations start
     for (int it = 0; it < iters[l]; ++it, ++i) {
       if (icp_px(W) == ICP_PX_FINE)
         hipLaunchKernelGGL(k_icp_iter<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
@@ -864,6 +865,7 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
                            lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
     }
   }
+  if (level_events) (void)hipEventRecord(level_events[HSK_NLEVELS], s);
   if (i > 0 && defer_final) {
     // the caller's next launch (k_column_zrange, first kernel of integrate) does the last solve in its prologue: one
     // launch and one kernel boundary less per frame

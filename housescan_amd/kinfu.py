@@ -219,6 +219,12 @@ class KinfuTracker:
     def set_profiling(self, on):
         self._ck(self.lib.hsk_set_profiling(self.h, int(on)))
 
+    def icp_level_ms(self):
+        """profiling: summed time of each ICP level's iterations (index 0 = finest), over the frames of stage_ms()"""
+        ms = (C.c_double * _lib.HSK_LEVELS)()
+        self._ck(self.lib.hsk_icp_level_ms(self.h, ms))
+        return list(ms)
+
     def stage_ms(self, reset=False):
         ms = (C.c_double * _lib.HSK_NSTAGES)()
         n = C.c_uint64()

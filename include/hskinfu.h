@@ -186,6 +186,9 @@ int hsk_synchronize(hsk_ctx* k);
 #define HSK_NSTAGES 4
 int hsk_set_profiling(hsk_ctx* k, int on);    /* record HIP events around each stage of process_frame */
 int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int reset);
+/* while profiling: time of the ICP iterations of each pyramid level, summed over the same frames as hsk_stage_ms (read it
+ * before resetting that); index = level, 0 = finest.  Divide by frames x icp_iters[level] for the time of an iteration. */
+int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]);
 int hsk_bilateral_tables(float ws[169], float wc[512]);
 /* Exhaustive self-test, on the GPU itself, of the exact-arithmetic shortcuts the kernels use for the specification's
  * correctly rounded 1/x, sqrt(x) and a/n (hardware approximation + one fused correction step; hsk_dev.h): every binary32

@@ -22,7 +22,19 @@
 #include <string.h>
 #include <time.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #define NANF (__builtin_nanf(""))
+
+/* threads of the OpenMP builds (bench.py's cpu_baseline times the same build on all cores and on one); no effect otherwise */
+void ora_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
 
 static double now_s(void) {
   struct timespec ts;

@@ -31,13 +31,30 @@ def build():
 _libs = {}
 
 
+def build_native():
+    """-O3 -march=native -fopenmp build for bench.py's cpu_baseline leg, made ON the machine that
+    times it (oracle/_native/, never shipped); returns its path, or None when it cannot be built here"""
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native"])
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    path = os.path.join(_HERE, "_native", "libkinfu_oracle_native.so")
+    return path if os.path.exists(path) else None
+
+
 def lib(omp=False):
     name = "libkinfu_oracle_omp.so" if omp else "libkinfu_oracle.so"
+    if omp == "native":
+        name = "_native/libkinfu_oracle_native.so"
     if name in _libs:
         return _libs[name]
     path = os.path.join(_HERE, name)
     if not os.path.exists(path):
-        build()
+        if omp == "native":
+            if build_native() is None:
+                return lib(True)
+        else:
+            build()
     L = C.CDLL(path)
     L.ora_tau.restype = C.c_float
     L.ora_integrate.restype = C.c_uint64

@@ -718,7 +718,7 @@ def test_bench_two_ranks_match_one(tmp_path):
     import socket
     import subprocess
     import sys
-    common = ["--steps", "24", "--warmup", "6", "--volume", "256", "--no-cpu-baseline"]
+    common = ["--steps", "24", "--warmup", "6", "--volume", "256", "--quick"]
 
     def last_json(cmd):
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -726,13 +726,39 @@ def test_bench_two_ranks_match_one(tmp_path):
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
     one = last_json([sys.executable, "bench.py"] + common)
-    assert one["tracking"]["lost_frames"] == 0
+    assert one["tracking"]["lost_frames"] == 0 and one["roofline"]["traffic"] is None and "frame_ms" in one
     for icp in ("replicated", "allreduce"):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         two = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--share-gpu", "--icp", icp] + common)
+                         "--master-port", str(port), "bench.py", "--gpus", "2", "--engine", "torch", "--backend", "gloo", "--share-gpu",
+                         "--icp", icp] + common)
         assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["tracking"]["lost_frames"] == 0
         assert two["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"], icp
-        assert two["independent_rooms"]["scaling"] == "weak"
+
+
+def test_bench_group_engine_world_of_one(tmp_path):
+    """the default N > 1 engine of bench.py (hsk_group_* with a communicator made from a broadcast unique id) on a world of
+    ONE rank launched through torch.distributed.run: the id hand-over, the RCCL communicator, the pipelined group calls and
+    the JSON line; the pose equals the single-GPU run's"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    common = ["--steps", "12", "--warmup", "3", "--volume", "128", "--quick"]
+
+    def last_json(cmd, env=None):
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one = last_json([sys.executable, "bench.py"] + common)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSK_BENCH_FORCE_MULTI="1")
+    grp = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), "bench.py", "--gpus", "1"] + common, env=env)
+    assert grp["config"]["parallelism"].startswith("slab1") and grp["tracking"]["lost_frames"] == 0
+    assert grp["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"]
