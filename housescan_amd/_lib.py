@@ -42,6 +42,7 @@ _F = C.POINTER(C.c_float)
 _D = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int)
 SYMBOLS = {
+    "hsk_build_id": (C.c_char_p, []),
     "hsk_default_config": (None, [C.POINTER(HskConfig), C.c_int]),
     "hsk_create": (C.c_int, [C.POINTER(HskConfig), C.POINTER(_P)]),
     "hsk_destroy": (None, [_P]),

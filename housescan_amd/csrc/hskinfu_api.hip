@@ -18,6 +18,9 @@
 #include "hsk_dev.h"
 #include "hsk_launch.h"
 
+#include "build/build_id.h"
+extern "C" const char* hsk_build_id(void) { return HSK_BUILD_ID; }
+
 static thread_local std::string g_create_err;
 
 // image-space buffers of one frame; two sets so that the asynchronous path can preprocess frame k+1 on a second

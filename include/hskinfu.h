@@ -59,6 +59,10 @@ typedef struct {
   int use_graph;                /* 1 = replay synchronous frames from one hipGraph; 0 (default) = eager  */
 } hsk_config;
 
+/* identity of the sources this library was built from (first 16 hex digits of their sha256; "+exp" appended when it
+ * was built with other than the default compiler flags) */
+const char* hsk_build_id(void);
+
 /* fills *c with the defaults above for an n^3 volume */
 void hsk_default_config(hsk_config* c, int n);
 

@@ -22,6 +22,16 @@ def oracle():
 @pytest.fixture(scope="session")
 def hsk():
     import housescan_amd
+    # the library under test must have been built from THIS tree with the default flags (built .so files travel to the GPU
+    # box with the snapshot; a stale or experimental one would be tested in good faith otherwise)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hsk_build_id", os.path.join(ROOT, "housescan_amd", "csrc", "build_id.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    have = housescan_amd._lib.load().hsk_build_id().decode()
+    want = mod.build_id()
+    assert have == want, (f"housescan_amd/libhskinfu.so was built from other sources or flags (library {have}, tree {want}): "
+                          "run `python -c 'import __graft_entry__ as g; g.build()'`")
     return housescan_amd
 
 

@@ -12,7 +12,7 @@ for defs in "$@"; do
   make -s -C housescan_amd/csrc FLAGS="$BASE $defs" 2>&1 | grep -E "error" 
   OUT=$ROOT/gpurun_out/$tag/v$i
   rm -rf $OUT; mkdir -p $OUT
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline $BARGS ${HSK_BENCH_ARGS} > $OUT/log.txt 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --quick $BARGS ${HSK_BENCH_ARGS} > $OUT/log.txt 2>&1)
   echo "== [$i] $defs"
   grep -o '{"metric.*' $OUT/log.txt | python3 -c "
 import json,sys

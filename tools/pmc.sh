@@ -11,6 +11,6 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/p$i -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/$OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/p$i -- python3 $ROOT/bench.py --quick "$@" > $ROOT/$OUT/p$i.log 2>&1
 done
 python3 $ROOT/tools/pmc_summary.py $ROOT/$OUT

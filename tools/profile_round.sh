@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/round
 rm -rf $OUT/trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --quick > $OUT/bench_profiled.log 2>&1
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 grep -o '{"metric.*' $OUT/bench_profiled.log > $OUT/bench_profiled.json
 cd $ROOT && tools/pmc.sh gpurun_out/round/pmc > $OUT/pmc_summary.txt 2>&1
