@@ -219,12 +219,20 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
         p, _ = rep.process_frame_dev(dev_frames[i].data_ptr())
         if i in sample:
             rep_poses[i] = p.copy()
-    icp_ms = rep.icp_level_ms()
     ms, nf = rep.stage_ms(reset=True)
     rep.set_profiling(False)
     if final_pose is not None:
         assert np.array_equal(p, final_pose), "the replay must reproduce the timed run's final pose bit for bit"
     vupd = [rep.count_updates(frames[i], rep_poses[i]) for i in sample]
+    # ICP time per pyramid level: a few more frames with an event at every level (those events cost about 4 us each, so
+    # they stay out of the stage times above); count_updates left the tracker state alone
+    rep.set_profiling(2)
+    for _ in range(16):   # the last frame again (camera at rest: the iteration counts are fixed, so the times are the same)
+        rep.process_frame_dev(dev_frames[total - 1].data_ptr())
+    icp_sum = rep.icp_level_ms()
+    _, nf2 = rep.stage_ms(reset=True)
+    rep.set_profiling(False)
+    icp_ms = [v * nf / max(1, nf2) for v in icp_sum]   # scaled to the nf frames the caller divides by
     return rep, ms, nf, icp_ms, float(np.mean(vupd)), p
 
 

@@ -102,6 +102,7 @@ struct hsk_ctx {
   bool graph_ready = false;
   // profiling
   bool prof = false;
+  bool prof_levels = false;  // profiling level 2: also an event at every ICP level (they cost about 4 us each)
   hipEvent_t ev[HSK_NSTAGES + 1] = {};
   hipEvent_t ev_icp[HSK_NLEVELS + 1] = {};  // profiling: start of each ICP level (coarsest first) and the end of the last
   double icp_level_ms[HSK_NLEVELS] = {};    // ... summed per level, index = level (0 = finest)
@@ -482,7 +483,7 @@ static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
   if (fin) *fin = IcpFinal{nullptr, nullptr, 0};
   launch_icp_fused(k->stream, k->B().d_vcur, k->B().d_ncur, k->d_vmod, k->d_nmod, k->lv, k->cfg.icp_iters, k->d_st,
                    k->cfg.icp_dist_thresh_m, k->cfg.icp_angle_thresh_sin, k->d_icp_pose, k->d_partials, k->d_partials2, fin,
-                   (k->prof && !fin) ? k->ev_icp : nullptr);
+                   (k->prof && k->prof_levels && !fin) ? k->ev_icp : nullptr);
 }
 
 static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr) {
@@ -600,7 +601,7 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
       float ms = 0.0f;
       if (hipEventElapsedTime(&ms, k->ev[i], k->ev[i + 1]) == hipSuccess) k->stage_ms[i] += ms;
     }
-    for (int i = 0; i < HSK_NLEVELS; ++i) {  // event i starts level HSK_NLEVELS - 1 - i
+    for (int i = 0; i < HSK_NLEVELS && k->prof_levels; ++i) {  // event i starts level HSK_NLEVELS - 1 - i
       float ms = 0.0f;
       if (hipEventElapsedTime(&ms, k->ev_icp[i], k->ev_icp[i + 1]) == hipSuccess) k->icp_level_ms[HSK_NLEVELS - 1 - i] += ms;
     }
@@ -1113,6 +1114,7 @@ extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles
 extern "C" int hsk_set_profiling(hsk_ctx* k, int on) {
   if (!k) return HSK_ERR_ARG;
   k->prof = on != 0;
+  k->prof_levels = on == 2;
   return HSK_OK;
 }
 extern "C" int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int reset) {

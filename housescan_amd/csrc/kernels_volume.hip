@@ -659,6 +659,17 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
           Dx = fmaxf(Dx, t.x);
           Dn = fminf(Dn, t.y);
         }
+#ifdef HSK_EXPA_DOUBLE_LOOKUPS  // timing experiment: the nine look-ups a second time (other table), results unused
+      {
+        const float2* __restrict__ tab2 = fine ? ftab : qtab;
+        float w = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) w += tab2[(tys[a] + txs[b]) >> 2].x;
+        if (w == -12345.0f) Dx = w;  // never
+      }
+#endif
       // exact distance range of the block: its 16 voxel centres lie in the rectangle [gx0, gx3] x {gy} x [gza, gzb], over
       // which the distance to the camera centre is largest at a corner and smallest where each coordinate is nearest 0
       const float gz2_hi = fmaxf(gza * gza, gzb * gzb);
@@ -804,18 +815,49 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* _
                                                                         const unsigned* __restrict__ qcount, unsigned qcap) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
-  const unsigned n = qcount[blockIdx.y * HSK_QCOUNT_STRIDE];
-  const unsigned* __restrict__ queue = queue_all + (size_t)blockIdx.y * qcap;
+  // The HSK_NQUEUES queues are walked as ONE list (their lengths differ by 1.6x: a grid that strides over each queue
+  // by itself ends with the longest queue's last round, a third of the chip idle).  Every block scans the 256 counters
+  // once (LDS prefix array); an entry's queue is then found by bisection.
+  __shared__ unsigned pre[HSK_NQUEUES + 1];
+  {
+    static_assert(HSK_NQUEUES == 256, "one counter per thread of the block");
+    const unsigned c = qcount[threadIdx.x * HSK_QCOUNT_STRIDE];
+    unsigned incl = c;  // inclusive scan inside the wave, then across the four waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned v = (unsigned)__shfl_up((int)incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    __shared__ unsigned wsum[4];
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
+    pre[threadIdx.x + 1] = base + incl;
+    if (threadIdx.x == 0) pre[0] = 0u;
+    __syncthreads();
+  }
+  const unsigned n = pre[HSK_NQUEUES];
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned long long cnt = 0;
   const DetailPose P = detail_pose(st);
   const int qx = vp.X / 4;
+  auto entry_at = [&](unsigned g) -> unsigned {  // g-th entry of the concatenated queues (0 beyond the end)
+    if (g >= n) return 0u;
+    unsigned lo = 0, hi = HSK_NQUEUES;  // pre[lo] <= g < pre[hi]
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (pre[mid] <= g) lo = mid; else hi = mid;
+    }
+    return queue_all[(size_t)lo * qcap + (g - pre[lo])];
+  };
   // the entry of the NEXT trip is fetched while the current one is worked on (its address needs nothing but the trip index)
   unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
-  unsigned id_next = (e0 + lane < n) ? queue[e0 + lane] : 0u;
+  unsigned id_next = entry_at(e0 + lane);
   for (; e0 < n; e0 += stride) {  // wave-uniform trip count
     const unsigned id = id_next;
-    id_next = (e0 + stride + lane < n) ? queue[e0 + stride + lane] : 0u;
+    id_next = entry_at(e0 + stride + lane);
     const unsigned lb = id & 0x0fffffffu;
     const int x0 = (int)(lb % (unsigned)qx) * 4, y = (int)((lb / (unsigned)qx) % (unsigned)vp.Y);
     const int zb = (int)(lb / ((unsigned)qx * (unsigned)vp.Y)) * 4;
@@ -872,7 +914,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
   const unsigned nblk = grid.x * grid.y * (unsigned)zchunks;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
-  const dim3 detail_grid(DETAIL2_GX, HSK_NQUEUES);  // DETAIL2_GX blocks stride over each queue
+  const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr);

@@ -188,9 +188,9 @@ int hsk_synchronize(hsk_ctx* k);
 #define HSK_STAGE_INTEGRATE 2
 #define HSK_STAGE_RAYCAST 3
 #define HSK_NSTAGES 4
-int hsk_set_profiling(hsk_ctx* k, int on);    /* record HIP events around each stage of process_frame */
+int hsk_set_profiling(hsk_ctx* k, int on);    /* 1: record HIP events around each stage of process_frame; 2: also at every ICP level */
 int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int reset);
-/* while profiling: time of the ICP iterations of each pyramid level, summed over the same frames as hsk_stage_ms (read it
+/* while profiling at level 2: time of the ICP iterations of each pyramid level, summed over the same frames as hsk_stage_ms (read it
  * before resetting that); index = level, 0 = finest.  Divide by frames x icp_iters[level] for the time of an iteration. */
 int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]);
 int hsk_bilateral_tables(float ws[169], float wc[512]);
