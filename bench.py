@@ -351,7 +351,10 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
     dist.init_process_group("gloo", rank=rank, world_size=world)  # host-side only: the id, the barrier, the max of the clocks
     K, Wm, n = args.steps, args.warmup, args.volume
     total = 1 + Wm + K
-    poses_gt, frames = make_frames(hsk, 0, total)
+    if args.mode == "pairs" and world % 2:
+        raise SystemExit("--mode pairs needs an even number of GPUs")
+    room = rank // 2 if args.mode == "pairs" else (rank if args.mode == "rooms" else 0)
+    poses_gt, frames = make_frames(hsk, 25 * room if args.mode != "slab" else 0, total)  # every room its own stretch of the trajectory
     dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
     dev_frames = [dev_all[i] for i in range(total)]
     torch.cuda.synchronize()
@@ -372,10 +375,17 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
         first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
         wait = trk.wait_frame
     else:
-        ids = [hsk.KinfuGroup.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
         flags = hsk.GROUP_ICP_ALLREDUCE if args.icp == "allreduce" else 0
-        trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
+        if args.mode == "pairs":
+            # BASELINE configs[4]: one room per PAIR of GPUs -- a two-slab group with its own two-rank communicator
+            pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
+            ids = [hsk.KinfuGroup.unique_id() if rank % 2 == 0 else None]
+            dist.broadcast_object_list(ids, src=2 * room, group=pgs[room])
+            trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank % 2, world=2, comm_id=ids[0], flags=flags)
+        else:
+            ids = [hsk.KinfuGroup.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
         submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
 
         def first(i):
@@ -395,20 +405,22 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
     lost += (not ok)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    rooms = world if args.mode == "rooms" else 1
+    rooms = world if args.mode == "rooms" else (world // 2 if args.mode == "pairs" else 1)
     gt = poses_gt[total - 1]
     out = {
         "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
         "value": round(rooms * K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True,
-        "scaling": "weak" if rooms > 1 else "strong", "vs_baseline": None,
+        "scaling": "strong" if args.mode == "slab" else "weak", "vs_baseline": None,
         "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
-        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n if rooms == 1 else
-                               "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n,
+        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n if args.mode == "slab" else
+                               ("configs[4]: %d concurrent %d^3 rooms, a GPU pair (two z-slabs, own communicator) each" % (rooms, n)
+                                if args.mode == "pairs" else "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n),
                    "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
-                   "parallelism": ("slab%d-icp-%s" % (world, args.icp)) if rooms == 1 else "rooms%d" % world,
-                   "api": "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI; RCCL inside the library), 1 frame in flight ahead"
-                   if rooms == 1 else "hsk_submit_frame_dev / hsk_wait_frame"},
+                   "parallelism": ("slab%d-icp-%s" % (world, args.icp)) if args.mode == "slab" else
+                                  ("rooms%d" % world if args.mode == "rooms" else "pairs%d-icp-%s" % (rooms, args.icp)),
+                   "api": "hsk_submit_frame_dev / hsk_wait_frame" if args.mode == "rooms" else
+                          "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI; RCCL inside the library), 1 frame in flight ahead"},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
                      "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
     }
@@ -495,7 +507,8 @@ def main():
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
     ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of submit/wait")
-    ap.add_argument("--mode", choices=["slab", "rooms"], default="slab", help="N > 1: z-slabs of one volume, or one room per GPU")
+    ap.add_argument("--mode", choices=["slab", "rooms", "pairs"], default="slab",
+                    help="N > 1: z-slabs of ONE volume (strong scaling), one room per GPU, or one room per GPU pair (configs[4])")
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
     ap.add_argument("--engine", choices=["group", "torch"], default="group",
                     help="N > 1 slabs: hsk_group_* (C ABI, RCCL inside the library) or the Python harness over torch.distributed")
@@ -519,7 +532,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world == 1 and not os.environ.get("HSK_BENCH_FORCE_MULTI"):  # (the variable: the N > 1 flow on a world of one rank, for the tests)
         out = run_single(args, hsk, torch, local_rank)
-    elif args.engine == "torch" and args.mode == "slab":
+    elif args.engine == "torch" and args.mode == "slab":  # (the harness has no rooms / pairs form)
         out = run_multi_torch(args, hsk, torch, world, rank, local_rank)
     else:
         out = run_multi(args, hsk, torch, world, rank, local_rank)

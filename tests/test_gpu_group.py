@@ -107,3 +107,46 @@ def test_c_harness_drives_the_library_without_python(hsk, synth_frames, tmp_path
             assert np.array_equal(words, np.ascontiguousarray(want[k][0][:3, :4]).view(np.uint32).reshape(-1)), (tag, k)
     assert int([ln for ln in lines if ln.startswith("cloud ")][0].split()[1]) == total
     ref.close()
+
+
+def test_config5_four_rooms_each_a_two_slab_group_from_four_threads(hsk, synth_frames):
+    """BASELINE configs[4] as specified -- four concurrent 512^3 volumes, a PAIR of slabs each -- on the one device of the
+    box: four two-slab groups driven from four OS threads at once; every room must reproduce, bit for bit, what a single
+    context gives for its frames (the pairs' composites must not leak into each other)"""
+    import threading
+    n, rooms, nframes = 512, 4, 6
+    streams = [[synth_frames(25 * r + k)[1] for k in range(nframes)] for r in range(rooms)]
+    want = []
+    for r in range(rooms):
+        ref = hsk.KinfuTracker(n=n)
+        want.append(([ref.process_frame(d) for d in streams[r]], ref.download_tsdf()))
+        ref.close()
+    groups = [hsk.KinfuGroup(hsk.default_config(n), device_ids=[0, 0]) for _ in range(rooms)]
+    outs, errs = [None] * rooms, []
+
+    def run(r):
+        try:
+            g, res = groups[r], []
+            res.append(g.process_frame(streams[r][0]))
+            g.submit_frame(streams[r][1])
+            for d in streams[r][2:]:
+                g.submit_frame(d)
+                res.append(g.wait_frame())
+            res.append(g.wait_frame())
+            outs[r] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(rooms)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    full = np.zeros((n, n, n, 2), np.int16)
+    for r in range(rooms):
+        for k, ((p, ok), (pr, okr)) in enumerate(zip(outs[r], want[r][0])):
+            assert ok == okr == (k > 0)
+            assert_same_bits(p, pr, f"room {r} frame {k}: pair of slabs, four rooms at once, vs one context alone")
+        assert_same_bits(groups[r].download_tsdf(full), want[r][1], f"room {r} tsdf")
+        groups[r].close()
