@@ -353,11 +353,6 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
     total = 1 + Wm + K
     if args.mode == "pairs" and world % 2:
         raise SystemExit("--mode pairs needs an even number of GPUs")
-    room = rank // 2 if args.mode == "pairs" else (rank if args.mode == "rooms" else 0)
-    poses_gt, frames = make_frames(hsk, 25 * room if args.mode != "slab" else 0, total)  # every room its own stretch of the trajectory
-    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
-    dev_frames = [dev_all[i] for i in range(total)]
-    torch.cuda.synchronize()
 
     def barrier():
         dist.barrier()
@@ -368,45 +363,54 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    lost = 0
-    if args.mode == "rooms":
-        trk = hsk.KinfuTracker(n=n, device_id=local_rank)
-        submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
-        first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
-        wait = trk.wait_frame
-    else:
-        flags = hsk.GROUP_ICP_ALLREDUCE if args.icp == "allreduce" else 0
-        if args.mode == "pairs":
-            # BASELINE configs[4]: one room per PAIR of GPUs -- a two-slab group with its own two-rank communicator
-            pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
-            ids = [hsk.KinfuGroup.unique_id() if rank % 2 == 0 else None]
-            dist.broadcast_object_list(ids, src=2 * room, group=pgs[room])
-            trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank % 2, world=2, comm_id=ids[0], flags=flags)
+    def timed(mode):
+        """W untimed + K timed frames in `mode`; returns (elapsed max over ranks, lost, last pose, its ground truth, rooms)"""
+        room = rank // 2 if mode == "pairs" else (rank if mode == "rooms" else 0)
+        poses_gt, frames = make_frames(hsk, 25 * room if mode != "slab" else 0, total)  # every room its own stretch of the trajectory
+        dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+        dev_frames = [dev_all[i] for i in range(total)]
+        torch.cuda.synchronize()
+        lost = 0
+        if mode == "rooms":
+            trk = hsk.KinfuTracker(n=n, device_id=local_rank)
+            submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
+            first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
         else:
-            ids = [hsk.KinfuGroup.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
-        submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
+            flags = hsk.GROUP_ICP_ALLREDUCE if args.icp == "allreduce" else 0
+            if mode == "pairs":
+                # BASELINE configs[4]: one room per PAIR of GPUs -- a two-slab group with its own two-rank communicator
+                pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
+                ids = [hsk.KinfuGroup.unique_id() if rank % 2 == 0 else None]
+                dist.broadcast_object_list(ids, src=2 * room, group=pgs[room])
+                trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank % 2, world=2, comm_id=ids[0], flags=flags)
+            else:
+                ids = [hsk.KinfuGroup.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
+            submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
 
-        def first(i):
-            submit(i)
-            return trk.wait_frame()
+            def first(i):
+                submit(i)
+                return trk.wait_frame()
         wait = trk.wait_frame
-    for i in range(1 + Wm):
-        first(i)
-    barrier()
-    t0 = time.perf_counter()
-    submit(1 + Wm)
-    for i in range(2 + Wm, total):
-        submit(i)
+        for i in range(1 + Wm):
+            first(i)
+        barrier()
+        t0 = time.perf_counter()
+        submit(1 + Wm)
+        for i in range(2 + Wm, total):
+            submit(i)
+            pose, ok = wait()
+            lost += (not ok)
         pose, ok = wait()
         lost += (not ok)
-    pose, ok = wait()
-    lost += (not ok)
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    rooms = world if args.mode == "rooms" else (world // 2 if args.mode == "pairs" else 1)
-    gt = poses_gt[total - 1]
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        trk.close()
+        del dev_frames, dev_all
+        return elapsed, lost, pose, poses_gt[total - 1], (world if mode == "rooms" else (world // 2 if mode == "pairs" else 1))
+
+    elapsed, lost, pose, gt, rooms = timed(args.mode)
     out = {
         "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
         "value": round(rooms * K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -424,7 +428,13 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
                      "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
     }
-    trk.close()
+    if args.mode == "slab" and not args.no_rooms:
+        # the same GPUs on the path's other partition (BASELINE configs[4]-shaped): an independent room per GPU, no
+        # data-path collective -- weak scaling, next to the strong-scaling slab figure above
+        el_r, lost_r, _, _, rooms_r = timed("rooms")
+        out["rooms_weak"] = {"value": round(rooms_r * K / el_r, 2), "unit": "frames/s", "scaling": "weak", "rooms": rooms_r,
+                             "ms_per_step": round(1000.0 * el_r / K, 4), "lost_frames": int(lost_r),
+                             "workload": "one %d^3 room per GPU, hsk_submit_frame_dev / hsk_wait_frame, %d frames each" % (n, K)}
     dist.barrier()
     dist.destroy_process_group()
     return out if rank == 0 else None
@@ -503,7 +513,8 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--no-1024", action="store_true", help="skip the 1024^3 roofline block")
     ap.add_argument("--no-host-frames", action="store_true", help="skip the PCIe-inclusive (host frame) figure")
-    ap.add_argument("--quick", action="store_true", help="all four of the above")
+    ap.add_argument("--no-rooms", action="store_true", help="N > 1, --mode slab: skip the secondary one-room-per-GPU (weak scaling) block")
+    ap.add_argument("--quick", action="store_true", help="all of the above")
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
     ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of submit/wait")
@@ -516,7 +527,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="--engine torch: all ranks on device 0 (logic check on a one-GPU box)")
     args = ap.parse_args()
     if args.quick:
-        args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = True
+        args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = args.no_rooms = True
 
     import torch
 

@@ -109,16 +109,6 @@ static __device__ __forceinline__ float hsk_tsdf_unpack(int raw) {
   return (float)((double)raw * (1.0 / 32767.0));
 }
 
-// x / n of the specification for a small positive integer n (a weight + 1 <= 129): a binary32 quotient m/n cannot lie
-// within 2^-32 (relative) of a rounding boundary unless it is exactly representable, and the binary64 product with the
-// correctly rounded binary64 reciprocal is within 2^-52 of it, so rounding the product to binary32 gives the correctly
-// rounded quotient.  The reciprocals come from a table: v_rcp_f64 alone is only a Newton seed (~2^-27) and is NOT
-// accurate enough (a 130-frame run differed in 24 voxels), and refining it costs what the division costs.
-__device__ __constant__ static const double hsk_recip_table[130] = {0.0, 1.0 / 1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 / 5.0, 1.0 / 6.0, 1.0 / 7.0, 1.0 / 8.0, 1.0 / 9.0, 1.0 / 10.0, 1.0 / 11.0, 1.0 / 12.0, 1.0 / 13.0, 1.0 / 14.0, 1.0 / 15.0, 1.0 / 16.0, 1.0 / 17.0, 1.0 / 18.0, 1.0 / 19.0, 1.0 / 20.0, 1.0 / 21.0, 1.0 / 22.0, 1.0 / 23.0, 1.0 / 24.0, 1.0 / 25.0, 1.0 / 26.0, 1.0 / 27.0, 1.0 / 28.0, 1.0 / 29.0, 1.0 / 30.0, 1.0 / 31.0, 1.0 / 32.0, 1.0 / 33.0, 1.0 / 34.0, 1.0 / 35.0, 1.0 / 36.0, 1.0 / 37.0, 1.0 / 38.0, 1.0 / 39.0, 1.0 / 40.0, 1.0 / 41.0, 1.0 / 42.0, 1.0 / 43.0, 1.0 / 44.0, 1.0 / 45.0, 1.0 / 46.0, 1.0 / 47.0, 1.0 / 48.0, 1.0 / 49.0, 1.0 / 50.0, 1.0 / 51.0, 1.0 / 52.0, 1.0 / 53.0, 1.0 / 54.0, 1.0 / 55.0, 1.0 / 56.0, 1.0 / 57.0, 1.0 / 58.0, 1.0 / 59.0, 1.0 / 60.0, 1.0 / 61.0, 1.0 / 62.0, 1.0 / 63.0, 1.0 / 64.0, 1.0 / 65.0, 1.0 / 66.0, 1.0 / 67.0, 1.0 / 68.0, 1.0 / 69.0, 1.0 / 70.0, 1.0 / 71.0, 1.0 / 72.0, 1.0 / 73.0, 1.0 / 74.0, 1.0 / 75.0, 1.0 / 76.0, 1.0 / 77.0, 1.0 / 78.0, 1.0 / 79.0, 1.0 / 80.0, 1.0 / 81.0, 1.0 / 82.0, 1.0 / 83.0, 1.0 / 84.0, 1.0 / 85.0, 1.0 / 86.0, 1.0 / 87.0, 1.0 / 88.0, 1.0 / 89.0, 1.0 / 90.0, 1.0 / 91.0, 1.0 / 92.0, 1.0 / 93.0, 1.0 / 94.0, 1.0 / 95.0, 1.0 / 96.0, 1.0 / 97.0, 1.0 / 98.0, 1.0 / 99.0, 1.0 / 100.0, 1.0 / 101.0, 1.0 / 102.0, 1.0 / 103.0, 1.0 / 104.0, 1.0 / 105.0, 1.0 / 106.0, 1.0 / 107.0, 1.0 / 108.0, 1.0 / 109.0, 1.0 / 110.0, 1.0 / 111.0, 1.0 / 112.0, 1.0 / 113.0, 1.0 / 114.0, 1.0 / 115.0, 1.0 / 116.0, 1.0 / 117.0, 1.0 / 118.0, 1.0 / 119.0, 1.0 / 120.0, 1.0 / 121.0, 1.0 / 122.0, 1.0 / 123.0, 1.0 / 124.0, 1.0 / 125.0, 1.0 / 126.0, 1.0 / 127.0, 1.0 / 128.0, 1.0 / 129.0};
-static __device__ __forceinline__ float hsk_div_small_int(float x, int n) {
-  return (float)((double)x * hsk_recip_table[n]);
-}
-
 // x / c of the specification for a fixed binary32 divisor c, as a binary64 product with the correctly rounded binary64
 // reciprocal rc: a binary32 quotient of two binary32 numbers is either exact or at least 2^-48 (relative) away from a
 // rounding boundary (ties need c to be a power of two, where rc is exact), and the product is within 2^-52 of it.

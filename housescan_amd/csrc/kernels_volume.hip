@@ -213,8 +213,6 @@ struct IntegrateConst {
   float cull_thr2, free_thr2;              // second level: against the block's exact distance range (no cell margin)
 };
 
-static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]);
-
 // A voxel (x, y, stored plane zz) has just been given a negative TSDF: set its brick's bit and, the first time, its
 // super-brick's.  Test first: after the first frames the bits are already set and no atomic is issued (a stale read
 // only costs a redundant OR).
@@ -230,70 +228,44 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
   }
 }
 
-// All four voxels of the vector observed as free space (F == 1).  When all four already store +1 the running
-// mean leaves +1 ((1*W + 1) / (W + 1) == 1 exactly) and only the weights move: W <- min(W + 1, 128), done on the
-// packed words with one add and one min per voxel.  Otherwise the general update runs.
+// All four voxels of the vector observed as free space (F == 1).  Onto a stored +1 the running mean leaves +1
+// ((1*W + 1) / (W + 1) == 1 exactly) and only the weight moves, W <- min(W + 1, 128): one add and one min on the packed
+// word; an unseen voxel (W == 0) becomes (+1, 1).  Anything else -- a voxel that was inside the band in an earlier
+// frame -- takes the running mean on the exact shortcuts (a = Fp * Wp + 1 lies in hsk_div_small_exact's domain:
+// |a| <= 129, and a sum of a binary32 product and 1 is 0 or at least 2^-24 in magnitude), behind ONE wave-uniform
+// branch.  (Round 2 measured the former per-voxel branches with binary64 arithmetic behind them at 23 of pass A's 71 us:
+// one such voxel among a wave's 1024 sent the whole wave through them.)  F == 1 cannot turn a non-negative value
+// negative, so no brick flag can newly be due.  Returns whether the vector changed (false: the store is skipped).
 static __device__ __forceinline__ bool update_vector_free4(uint4& q) {
-  const unsigned a = q.x & q.y & q.z & q.w, o = q.x | q.y | q.z | q.w;
-  if ((a & 0x7fffu) == 0x7fffu && (o & 0x8000u) == 0u) {
-    const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
-    // all four weights already at the cap: the update leaves the vector as it is, and the store is skipped
-    if (min(min(q.x, q.y), min(q.z, q.w)) >= cap) return false;
-    q.x = min(q.x + 0x10000u, cap);
-    q.y = min(q.y + 0x10000u, cap);
-    q.z = min(q.z + 0x10000u, cap);
-    q.w = min(q.w + 0x10000u, cap);
-  } else {
-    const float F1[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    (void)update_vector(q, 0xFu, 0xFu, F1);  // F == 1 never writes a negative value
-  }
-  return true;
-}
-
-// Phase 4 for one plane: running mean (A.4), repack.  Returns true when a negative TSDF was written.
-static __device__ __forceinline__ bool update_vector(uint4& q, unsigned mask, unsigned one, const float F[4]) {
-  unsigned w4[4] = {q.x, q.y, q.z, q.w};
-  // saturated free space: F == 1 onto a stored +1 gives (1*W + 1) / (W + 1) == 1 exactly: only W moves
-  bool simple = true;
+  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
+  const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+  unsigned nw[4];
+  bool gen[4], gen_any = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const bool upd = (mask >> j) & 1u;
-    const bool sj = ((one >> j) & 1u) && (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
-    simple = simple && (!upd || sj);
+    const bool unseen = (w4[j] >> 16) == 0u;
+    const bool simple = unseen || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
+    nw[j] = unseen ? (0x10000u | (unsigned)HSK_DIVISOR) : min(w4[j] + 0x10000u, cap);
+    gen[j] = !simple;
+    gen_any = gen_any || gen[j];
   }
-  bool neg = false;
-  if (simple) {
+#ifndef HSK_EXPA_NO_FALLBACK  // (timing experiment: such vectors are updated as if they held +1; results wrong)
+  if (__ballot(gen_any) != 0ull) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool upd = (mask >> j) & 1u;
-      w4[j] += (upd && (w4[j] >> 16) < (unsigned)HSK_MAX_WEIGHT) ? 0x10000u : 0u;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (!((mask >> j) & 1u)) continue;
       const int tp = (int)(short)(w4[j] & 0xffffu);
-      const int wp = (int)(short)(w4[j] >> 16);
-      const float Fj = ((one >> j) & 1u) ? 1.0f : F[j];
-      float Fn;
-      if (wp == 0) {
-        Fn = Fj;  // (Fp*0 + F) / (0 + 1) == F exactly
-      } else if (Fj == 1.0f && tp == HSK_DIVISOR) {
-        Fn = 1.0f;
-      } else {
-        const float Fp = hsk_tsdf_unpack(tp);
-        const float Wp = (float)wp;
-        Fn = hsk_div_small_int(Fp * Wp + Fj, wp + 1);
-      }
+      const unsigned wp = w4[j] >> 16;
+      const float Wp = (float)wp;
+      const float Fn = hsk_div_small_exact(hsk_tsdf_unpack(tp) * Wp + 1.0f, Wp + 1.0f);
       int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
       fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
-      const int wn = min(wp + 1, HSK_MAX_WEIGHT);
-      neg = neg || (fixed < 0);
-      w4[j] = ((unsigned)fixed & 0xffffu) | ((unsigned)wn << 16);
+      const unsigned wg = ((unsigned)fixed & 0xffffu) | (min(wp + 1u, (unsigned)HSK_MAX_WEIGHT) << 16);
+      nw[j] = gen[j] ? wg : nw[j];
     }
   }
-  q = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-  return neg;
+#endif
+  q = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+  return nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3];
 }
 
 // wave-uniform constants of the per-voxel path: the pose (world -> camera rows) of the frame

@@ -759,6 +759,7 @@ def test_bench_group_engine_world_of_one(tmp_path):
         port = s.getsockname()[1]
     env = dict(os.environ, HSK_BENCH_FORCE_MULTI="1")
     grp = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                     "--master-port", str(port), "bench.py", "--gpus", "1"] + common, env=env)
+                     "--master-port", str(port), "bench.py", "--gpus", "1"] + common[:-1], env=env)
     assert grp["config"]["parallelism"].startswith("slab1") and grp["tracking"]["lost_frames"] == 0
+    assert grp["scaling"] == "strong" and grp["rooms_weak"]["scaling"] == "weak" and grp["rooms_weak"]["lost_frames"] == 0
     assert grp["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters of the integrate kernels on the integrate-only bench (tools/int_bench.py), one rocprofv3 pass per group,
 # each under a timeout (the SPI_* counters abort rocprofv3 and hang: never add them).
-# usage: tools/pmc_int.sh <outdir under gpurun_out> [volume] [groups: all|mem]
+# usage: tools/pmc_int.sh <outdir under gpurun_out> [volume] [groups: all|mem|tlb]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$1; VOL=${2:-512}
 rm -rf $OUT; mkdir -p $OUT
@@ -13,10 +13,13 @@ G4="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY
 G5="TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum GRBM_TC_BUSY GRBM_EA_BUSY"
 G6="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_TAG_STALL_sum"
 G7="TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TD_TD_BUSY_sum SQ_VMEM_TA_ADDR_FIFO_FULL"
+G8="TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum GRBM_UTCL2_BUSY"
+G9="TCP_UTCL1_SERIALIZATION_STALL TCP_UTCL1_STALL_INFLIGHT_MAX TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS"
 i=0
-for grp in "$G1" "$G2" "$G4" "$G5" "$G6" "$G7"; do
+for grp in "$G1" "$G2" "$G4" "$G5" "$G6" "$G7" "$G8" "$G9"; do
   i=$((i+1))
-  if [ "$3" = "mem" ] && [ $i -le 2 ]; then continue; fi
+  if [ "$3" = "mem" ] && { [ $i -le 2 ] || [ $i -ge 7 ]; }; then continue; fi
+  if [ "$3" = "tlb" ] && [ $i -le 6 ]; then continue; fi
   timeout 60 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/int_bench.py $VOL 0 16 > $OUT/p$i.log 2>&1 || echo "group $i failed or timed out"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT k_integrate k_column > $OUT/summary.txt 2>&1
