@@ -69,6 +69,83 @@ def test_integrate_ragged_and_empty(hsk, oracle, synth_frames):
     trk.close()
 
 
+def _random_pose(rng, centre, spread):
+    """camera-to-world: a rotation by a random angle about a random axis (any angle: the camera may look away from the
+    volume, upside down, along an axis), the centre anywhere within `spread` of `centre`"""
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    ang = rng.uniform(-np.pi, np.pi)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    P = np.eye(4, dtype=np.float32)
+    P[:3, :3] = R.astype(np.float32)
+    P[:3, 3] = (np.asarray(centre) + rng.uniform(-1, 1, 3) * spread).astype(np.float32)
+    return P
+
+
+def _lookat_pose(rng, centre, spread):
+    """camera somewhere within `spread` of `centre`, its z axis towards a point near the centre, any roll"""
+    P = _random_pose(rng, centre, spread)
+    z = np.asarray(centre) + rng.uniform(-0.3, 0.3, 3) * spread - P[:3, 3]
+    z /= np.linalg.norm(z) + 1e-9
+    x = np.cross(rng.normal(size=3), z)
+    x /= np.linalg.norm(x)
+    P[:3, :3] = np.stack([x, np.cross(z, x), z], axis=1).astype(np.float32)
+    return P
+
+
+def _random_depth(rng, h=480, w=640):
+    """blocky random depth in millimetres: patches of 1..48 px with independent values (discontinuities at every patch
+    edge: the tile min / max tables of pass A see their worst case), holes, a band of per-pixel noise, and a few
+    extreme values (1 mm, 65535 mm)"""
+    by, bx = int(rng.integers(1, 49)), int(rng.integers(1, 49))
+    coarse = rng.integers(300, 5000, size=(h // by + 2, w // bx + 2))
+    d = np.kron(coarse, np.ones((by, bx), np.int64))[:h, :w]
+    d = d + rng.integers(-20, 21, size=(h, w)) * (rng.random((h, w)) < 0.5)
+    d[rng.random((h, w)) < 0.1] = 0
+    hy, hx = rng.integers(0, h - 60), rng.integers(0, w - 80)
+    d[hy:hy + 60, hx:hx + 80] = 0
+    ex = rng.random((h, w))
+    d[ex < 0.001] = 1
+    d[ex > 0.999] = 65535
+    return np.clip(d, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_integrate_and_raycast_fuzz(hsk, oracle, seed):
+    """random blocky depth images and arbitrary camera poses (inside / outside the volume, looking anywhere) into a cubic
+    and a non-cubic volume: TSDF, update counts and the raycast of the result bit-exact against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    if seed % 2 == 0:
+        n, shape, kw_o, kw_h = 128, (128, 128, 128), {}, {}
+    else:
+        n, shape = 64, (96, 160, 64)     # (z, y, x)
+        kw_o = dict(vol=(64, 160, 96), size=(1.5, 3.75, 2.25))
+        kw_h = dict(vol_y=160, vol_z=96, vol_size_m=(1.5, 3.75, 2.25), own_z1=96)
+    cfg_o = oracle.default_config(n, **kw_o)
+    trk = hsk.KinfuTracker(hsk.default_config(n, **kw_h)) if kw_h else hsk.KinfuTracker(n=n)
+    size = np.array(kw_o.get("size", (3.0, 3.0, 3.0)))
+    vol = np.zeros(shape + (2,), np.int16)
+    total = 0
+    for k in range(8):
+        pose = (_lookat_pose if k % 2 else _random_pose)(rng, size / 2, size * (0.9 if k % 4 >= 2 else 0.4))
+        depth = _random_depth(rng)
+        n_upd = oracle.integrate(cfg_o, vol, oracle.scale_depth(cfg_o, depth), pose)
+        assert trk.count_updates(depth, pose) == n_upd
+        trk.integrate(depth, pose)
+        assert_same_bits(trk.download_tsdf(), vol, f"tsdf, seed {seed} frame {k}")
+        total += n_upd
+    assert total > 50000
+    for k in range(3):
+        pose = (_lookat_pose if k else _random_pose)(rng, size / 2, size * 0.5)
+        vm, nm, keys = trk.raycast(pose, want_keys=True)
+        ovm, onm, okeys, _ = oracle.raycast(cfg_o, vol, pose)
+        assert np.array_equal(keys, okeys)
+        assert_same_bits(vm, ovm, "raycast vmap (fuzz)")
+        assert_same_bits(nm, onm, "raycast nmap (fuzz)")
+    trk.close()
+
+
 def test_weight_saturates_at_128(hsk, oracle, synth_frames):
     n = 32
     cfg_o = oracle.default_config(n)
