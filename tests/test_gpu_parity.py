@@ -346,6 +346,58 @@ def test_tracking_lost_resets(hsk, synth_frames):
     trk.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_tracker_fuzz_vs_oracle(hsk, oracle, synth_frames, seed):
+    """a stream that mixes good frames with garbage (random blocky depth: ICP correspondences everywhere and nowhere,
+    degenerate or wild solves), empty frames and frames repeated after a loss: every pose, every tracked / lost verdict and
+    the final TSDF and model maps identical to the oracle tracker -- synchronous and pipelined"""
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    n = 96
+    cfg_o = oracle.default_config(n)
+    ot = oracle.Tracker(cfg_o, omp=True)
+    trk = hsk.KinfuTracker(n=n)
+    pipe = hsk.KinfuTracker(n=n)
+    frames = []
+    k = 0
+    for i in range(14):
+        r = rng.random()
+        if i >= 2 and r < 0.2:
+            frames.append(_random_depth(rng))
+        elif i >= 2 and r < 0.3:
+            frames.append(np.zeros((480, 640), np.uint16))
+        elif i >= 2 and r < 0.4:
+            k += int(rng.integers(5, 30))     # a jump along the trajectory: ICP starts far from the answer
+            frames.append(synth_frames(k)[1])
+        else:
+            frames.append(synth_frames(k)[1])
+            k += 1
+    want = []
+    for i, depth in enumerate(frames):
+        po, oko = ot.process(depth)
+        ph, okh = trk.process_frame(depth)
+        assert oko == okh, f"seed {seed} frame {i}: tracked verdicts differ"
+        assert_same_bits(ph, po, f"seed {seed} pose frame {i}")
+        want.append((po, oko))
+    assert seed == 0 or sum(not ok for _, ok in want[1:]) >= 2   # (seed 0 tracks through its garbage frames; the others lose 2-4 frames)
+    assert_same_bits(trk.download_tsdf(), ot.volume(), "tsdf (tracker fuzz)")
+    for level in range(3):
+        assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"model vmap {level} (tracker fuzz)")
+    dev = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
+    # pipelined: a loss drops the frame submitted behind it (the caller resubmits), exactly as the synchronous order
+    i, got = 0, []
+    while i < len(frames):
+        pipe.submit_frame_dev(dev[i].data_ptr())
+        got.append(pipe.wait_frame())
+        i += 1
+    for i, ((po, oko), (pp, okp)) in enumerate(zip(want, got)):
+        assert oko == okp
+        assert_same_bits(pp, po, f"seed {seed} submit/wait pose frame {i}")
+    assert_same_bits(pipe.download_tsdf(), ot.volume(), "tsdf (tracker fuzz, submit/wait)")
+    trk.close()
+    pipe.close()
+
+
 def test_errors_are_values(hsk, synth_frames):
     trk = hsk.KinfuTracker(n=32)
     with pytest.raises(hsk.KinfuError, match="size"):
