@@ -347,3 +347,63 @@ def test_twin_tracker_equals_oracle_tracker(oracle, hsk):
     po, oko = ot.process(np.zeros((H, W), np.uint16))
     pt, okt = tt.process(np.zeros((H, W), np.uint16))
     assert not oko and not okt and np.array_equal(po, pt) and not tt.vol.any()
+
+
+def _fuzz_pose(rng, lookat):
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    ang = rng.uniform(-np.pi, np.pi)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    P = np.eye(4, dtype=np.float32)
+    P[:3, 3] = (1.5 + rng.uniform(-1, 1, 3) * (2.4 if not lookat else 1.2)).astype(np.float32)
+    if lookat:
+        z = 1.5 + rng.uniform(-0.4, 0.4, 3) - P[:3, 3]
+        z /= np.linalg.norm(z) + 1e-9
+        x = np.cross(rng.normal(size=3), z)
+        x /= np.linalg.norm(x)
+        R = np.stack([x, np.cross(z, x), z], axis=1)
+    P[:3, :3] = R.astype(np.float32)
+    return P
+
+
+def _fuzz_depth(rng):
+    by, bx = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+    coarse = rng.integers(300, 5000, size=(H // by + 2, W // bx + 2))
+    d = np.kron(coarse, np.ones((by, bx), np.int64))[:H, :W]
+    d = d + rng.integers(-20, 21, size=(H, W)) * (rng.random((H, W)) < 0.5)
+    d[rng.random((H, W)) < 0.1] = 0
+    ex = rng.random((H, W))
+    d[ex < 0.002] = 1
+    d[ex > 0.998] = 65535
+    return np.clip(d, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_twin_fuzz_integrate_and_raycast(oracle, hsk, seed):
+    """oracle == twin on inputs nobody tuned either for: blocky random depth (discontinuities, holes, 1 mm and 65535 mm
+    pixels) and arbitrary camera poses (inside / outside the volume, any orientation)"""
+    rng = np.random.default_rng(3000 + seed)
+    n = 32
+    cfg = small_cfg(oracle, n)
+    a = np.zeros((n, n, n, 2), np.int16)
+    b = a.copy()
+    total = 0
+    for k in range(6):
+        pose = _fuzz_pose(rng, k % 2 == 1)
+        sc = oracle.scale_depth(cfg, _fuzz_depth(rng))
+        na = oracle.integrate(cfg, a, sc, pose)
+        nb = T.integrate_full(b, (3.0, 3.0, 3.0), 0.03, sc, FX, FX, CX, CY, pose)
+        assert na == nb
+        assert np.array_equal(a, b)
+        total += na
+    assert total > 5000
+    hits = 0
+    for k in range(2):
+        pose = _fuzz_pose(rng, True)
+        o = oracle.raycast(cfg, a, pose)
+        t = T.raycast(a, (3.0, 3.0, 3.0), 0.03, W, H, FX, FX, CX, CY, pose)
+        assert np.array_equal(o[2], t[2]), "step keys"
+        assert same_bits(o[0], t[0]) and same_bits(o[1], t[1]) and o[3] == t[3]
+        hits += int((o[2] != 0x7FFFFFFF).sum())
+    assert hits > 200
