@@ -6,7 +6,10 @@
 // volume
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr);
+                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr,
+                      unsigned char* uni = nullptr);
+size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (kernels_volume.hip: hsk_uniform_code)
+void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
 size_t integrate_queue_words(const VolParams& vp);
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);

@@ -59,6 +59,8 @@ struct hsk_ctx {
   float* d_wc = nullptr;
   int* d_keys = nullptr;
   unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
+  unsigned char* d_uni = nullptr;    // lane-block summaries (kernels_volume.hip: hsk_uniform_code), one byte per 4x1x4 voxels
+  size_t uni_bytes = 0;
   size_t flags_bytes = 0;
   unsigned* d_queue = nullptr;       // integrate pass A -> pass B: count (4 words) + uncertain lane-block ids
   int2* d_zint = nullptr;            // per lane column: stored-plane range inside the padded frustum
@@ -228,6 +230,7 @@ static void free_all(hsk_ctx* k) {
   F(k->d_wc);
   F(k->d_keys);
   F(k->d_flags);
+  F(k->d_uni);
   F(k->d_zint);
   F(k->d_queue);
   F(k->d_counter);
@@ -262,6 +265,7 @@ static int do_reset(hsk_ctx* k) {
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   HIPCHK(k, hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream));
   HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
+  HIPCHK(k, hipMemsetAsync(k->d_uni, 1, k->uni_bytes, k->stream));  // 1: "all 16 voxels never observed"
   memset(k->h_st, 0, sizeof(TrackState));
   memcpy(k->h_st->R, k->init_R, sizeof(k->init_R));
   memcpy(k->h_st->t, k->init_t, sizeof(k->init_t));
@@ -407,6 +411,8 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     return bail(HSK_ERR_ARG);
   }
   CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
+  k->uni_bytes = uniform_bytes(vp);
+  CK(hipMalloc((void**)&k->d_uni, k->uni_bytes));
   // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of pass A's tiles
   CK(hipMalloc((void**)&k->d_queue, integrate_queue_words(vp) * sizeof(unsigned)));
   CK(hipMalloc((void**)&k->d_zint, (size_t)(vp.X / 4) * vp.Y * sizeof(int2)));
@@ -488,7 +494,8 @@ static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
 
 static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr) {
   launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
-                   k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue, (fin && fin->slots) ? fin : nullptr);
+                   k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue, (fin && fin->slots) ? fin : nullptr,
+                   k->d_uni);
 }
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys, bool report = false) {
@@ -1010,6 +1017,7 @@ extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
   HIPCHK(k, hipMemcpyAsync(k->d_vol, in, k->vol_bytes, hipMemcpyHostToDevice, k->stream));
   HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
   launch_rebuild_flags(k->stream, k->d_vol, k->vp, k->d_flags);
+  launch_rebuild_uniform(k->stream, k->d_vol, k->vp, k->d_uni);
   HIPCHK(k, hipStreamSynchronize(k->stream));
   return HSK_OK;
 }

@@ -228,6 +228,28 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
   }
 }
 
+// ---- lane-block summaries ------------------------------------------------------------------------------------------
+// One byte per lane-block (4 x-voxels x 4 planes, the unit pass A classifies), index = the queue entries' lane-block id:
+//   0         nothing known: the block's 16 words must be read
+//   1         all 16 voxels are (0, 0): never observed (the state after a reset)
+//   w + 1     all 16 voxels are (+1, w), 1 <= w <= 128: free space observed w times
+// A free-space update of a block with a summary needs NO read: every voxel becomes (+1, min(w + 1, 128)) -- stores only,
+// and none at all once w == 128.  Deep free space is where pass A's traffic was (246 MB of the 278 MB a frame moves at
+// 512^3), and it is exactly the region whose blocks are uniform.  Invariant: a non-zero summary describes the volume.
+// Writers of the volume keep it: pass A (below; it also withdraws the summary of every block it hands to pass B, which
+// therefore need not know about summaries -- recomputing them there was measured: the bookkeeping pushed pass B over
+// its 96 registers, +8 us),
+// hsk_reset (all 1), hsk_upload_tsdf (k_rebuild_uniform).  The volume's contents are what they were without the
+// summaries -- they are a cache of its state, not part of it.
+static __device__ __forceinline__ unsigned hsk_uniform_code(unsigned word) {
+  const unsigned w = word >> 16;
+  if (word == 0u) return 1u;
+  return ((word & 0xffffu) == (unsigned)HSK_DIVISOR && w >= 1u && w <= (unsigned)HSK_MAX_WEIGHT) ? w + 1u : 0u;
+}
+static __device__ __forceinline__ bool hsk_vector_is(const uint4& q, unsigned word) {
+  return q.x == word && q.y == word && q.z == word && q.w == word;
+}
+
 // All four voxels of the vector observed as free space (F == 1).  Onto a stored +1 the running mean leaves +1
 // ((1*W + 1) / (W + 1) == 1 exactly) and only the weight moves, W <- min(W + 1, 128): one add and one min on the packed
 // word; an unseen voxel (W == 0) becomes (+1, 1).  Anything else -- a voxel that was inside the band in an earlier
@@ -441,7 +463,8 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
                                                    int tw, int th, const int2* __restrict__ zint,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
-                                                   const float2* __restrict__ qtab, double* __restrict__ icp_slot0) {
+                                                   const float2* __restrict__ qtab, double* __restrict__ icp_slot0,
+                                                   unsigned char* __restrict__ uni) {
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
   // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
   if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -553,6 +576,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       actv[sidx] = zbs[sidx] <= wh;  // wave-uniform
       free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
       dc_s[sidx] = 0.0f;
+    }
+    // the summaries of the lane's (at most NS) lane-blocks: requested now, used in stage 3
+    unsigned sum8[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      sum8[sidx] = 0u;
+      if (!COUNT_ONLY && uni != nullptr && actv[sidx] && active)
+        sum8[sidx] = uni[((size_t)(zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2)];
     }
     PA_STAMP(6);
     // ---- stage 1: first level (16-px dilated tile table)
@@ -689,36 +720,65 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         if (actv[sidx] && free44_s[sidx]) cnt += 16;
     } else {
       typedef unsigned v4u __attribute__((ext_vector_type(4)));
-      uint4 q4[NS][4];
+      auto store_vec = [&](size_t at, const uint4& q) {
+        if (vp.stream_nt) {
+          // a volume far larger than the 256 MiB Infinity Cache gains nothing from caching these lines and loses
+          // what they evict: non-temporal loads and stores (1024^3: 838 -> 802 us; at 512^3, where half the volume
+          // stays cached from frame to frame, they cost 10 us, so the host decides by size)
+          const v4u t = {q.x, q.y, q.z, q.w};
+          __builtin_nontemporal_store(t, (v4u*)&vol[at]);
+        } else {
+          vol[at] = q;
+        }
+      };
+      // (a) blocks with a summary: no read.  (+1, min(w + 1, 128)) into all 16 voxels, nothing once w == 128
+      bool rd[NS];
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) {
-        if (!(actv[sidx] && free44_s[sidx])) continue;
+        const bool fr = actv[sidx] && free44_s[sidx];
+        rd[sidx] = fr && sum8[sidx] == 0u;
+        if (fr && sum8[sidx] != 0u && sum8[sidx] <= (unsigned)HSK_MAX_WEIGHT) {  // summary s: weight s - 1 < 128
+          const unsigned word = (sum8[sidx] << 16) | (unsigned)HSK_DIVISOR;    // weight (s - 1) + 1
+          const uint4 q = make_uint4(word, word, word, word);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (vp.stream_nt) {
-            // a volume far larger than the 256 MiB Infinity Cache gains nothing from caching these lines and loses
-            // what they evict: non-temporal loads and stores (1024^3: 838 -> 802 us; at 512^3, where half the volume
-            // stays cached from frame to frame, they cost 10 us, so the host decides by size)
-            const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
-            q4[sidx][u] = make_uint4(t.x, t.y, t.z, t.w);
-          } else {
-            q4[sidx][u] = vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec];
-          }
+          for (int u = 0; u < 4; ++u) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q);
+          uni[((size_t)(zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2)] = (unsigned char)(sum8[sidx] + 1u);
         }
       }
+      // (b) blocks without one: four batched vector updates per group, the loads of both groups in flight together;
+      //     afterwards the block may have become uniform
+      bool any_rd = false;
 #pragma unroll
-      for (int sidx = 0; sidx < NS; ++sidx) {
-        if (!(actv[sidx] && free44_s[sidx])) continue;
+      for (int sidx = 0; sidx < NS; ++sidx) any_rd = any_rd || rd[sidx];
+      if (__ballot(any_rd) != 0ull) {
+        uint4 q4[NS][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (update_vector_free4(q4[sidx][u])) {
+        for (int sidx = 0; sidx < NS; ++sidx) {
+          if (!rd[sidx]) continue;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
             if (vp.stream_nt) {
-              const v4u t = {q4[sidx][u].x, q4[sidx][u].y, q4[sidx][u].z, q4[sidx][u].w};
-              __builtin_nontemporal_store(t, (v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
+              const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
+              q4[sidx][u] = make_uint4(t.x, t.y, t.z, t.w);
             } else {
-              vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec] = q4[sidx][u];
+              q4[sidx][u] = vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec];
             }
           }
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+          if (!rd[sidx]) continue;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (update_vector_free4(q4[sidx][u])) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[sidx][u]);
+          if (uni != nullptr) {
+            const unsigned word = q4[sidx][0].x;
+            const unsigned code = (hsk_vector_is(q4[sidx][0], word) && hsk_vector_is(q4[sidx][1], word) &&
+                                   hsk_vector_is(q4[sidx][2], word) && hsk_vector_is(q4[sidx][3], word))
+                                      ? hsk_uniform_code(word) : 0u;
+            if (code != 0u) uni[((size_t)(zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2)] = (unsigned char)code;
+          }
+        }
       }
     }
 #endif
@@ -738,6 +798,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         for (int u = 0; u < 4; ++u) pm |= ((zbs[sidx] + u >= zl && zbs[sidx] + u <= zh) ? 1u : 0u) << u;
         const unsigned id = (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
         queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] = id | (pm << 28);
+        if (sum8[sidx] != 0u) uni[id] = 0;  // pass B may rewrite any of its voxels: the block's summary is withdrawn
       }
     }
 #endif
@@ -860,7 +921,7 @@ size_t integrate_queue_words(const VolParams& vp) {
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final) {
+                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final, unsigned char* uni) {
   const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
   const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
@@ -889,12 +950,13 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr,
+                       (unsigned char*)nullptr);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   } else {
     hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, uni);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   }
@@ -913,6 +975,30 @@ __global__ void k_rebuild_flags(const short2* __restrict__ vol, VolParams vp, un
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags) {
   const size_t n = (size_t)vp.X * vp.Y * vp.nzs;
   hipLaunchKernelGGL(k_rebuild_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const short2*)vol, vp, flags);
+}
+
+// lane-block summaries of a volume that was uploaded rather than integrated (one thread per lane-block; a block that
+// reaches beyond the last stored plane has no summary)
+size_t uniform_bytes(const VolParams& vp) { return (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4); }
+__global__ void k_rebuild_uniform(const uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
+  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int qx = vp.X / 4;
+  const int xl = (int)(i % qx), y = (int)((i / qx) % vp.Y), zb = (int)(i / ((size_t)qx * vp.Y)) * 4;
+  unsigned code = 0u;
+  if (zb + 3 < vp.nzs) {
+    const size_t plane_vec = (size_t)vp.X * vp.Y / 4, idx0 = (size_t)y * qx + xl;
+    const uint4 q0 = vol[idx0 + (size_t)zb * plane_vec];
+    bool same = hsk_vector_is(q0, q0.x);
+    for (int u = 1; u < 4; ++u) same = same && hsk_vector_is(vol[idx0 + (size_t)(zb + u) * plane_vec], q0.x);
+    code = same ? hsk_uniform_code(q0.x) : 0u;
+  }
+  uni[i] = (unsigned char)code;
+}
+void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni) {
+  const size_t n = uniform_bytes(vp);
+  hipLaunchKernelGGL(k_rebuild_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)vol, vp, uni);
 }
 
 // ------------------------------------------------------------------------------------------------------
