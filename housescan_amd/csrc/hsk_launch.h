@@ -10,6 +10,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
                       unsigned char* uni = nullptr);
 size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (kernels_volume.hip: hsk_uniform_code)
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
+void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni);  // before anything reads weights
 size_t integrate_queue_words(const VolParams& vp);
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);

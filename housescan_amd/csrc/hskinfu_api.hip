@@ -1007,6 +1007,7 @@ extern "C" int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz) {
 extern "C" int hsk_download_tsdf(hsk_ctx* k, int16_t* out) {
   if (!k || !out) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);  // the weights of deep free space live in the summaries until read
   HIPCHK(k, hipMemcpyAsync(out, k->d_vol, k->vol_bytes, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));
   return HSK_OK;
@@ -1071,6 +1072,7 @@ extern "C" int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size
     HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
     HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
   }
+  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);
   launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
   unsigned long long total = 0;
   HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
@@ -1099,6 +1101,7 @@ extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles
   }
   TetTable tt;
   hsk_build_tet_table(&tt);
+  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);
   launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
   unsigned long long total = 0;
   HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));

@@ -228,19 +228,29 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
   }
 }
 
-// ---- lane-block summaries ------------------------------------------------------------------------------------------
-// One byte per lane-block (4 x-voxels x 4 planes, the unit pass A classifies), index = the queue entries' lane-block id:
-//   0         nothing known: the block's 16 words must be read
-//   1         all 16 voxels are (0, 0): never observed (the state after a reset)
-//   w + 1     all 16 voxels are (+1, w), 1 <= w <= 128: free space observed w times
-// A free-space update of a block with a summary needs NO read: every voxel becomes (+1, min(w + 1, 128)) -- stores only,
-// and none at all once w == 128.  Deep free space is where pass A's traffic was (246 MB of the 278 MB a frame moves at
-// 512^3), and it is exactly the region whose blocks are uniform.  Invariant: a non-zero summary describes the volume.
-// Writers of the volume keep it: pass A (below; it also withdraws the summary of every block it hands to pass B, which
-// therefore need not know about summaries -- recomputing them there was measured: the bookkeeping pushed pass B over
-// its 96 registers, +8 us),
-// hsk_reset (all 1), hsk_upload_tsdf (k_rebuild_uniform).  The volume's contents are what they were without the
-// summaries -- they are a cache of its state, not part of it.
+// ---- lane-block summaries: deep free space without volume traffic ---------------------------------------------------
+// One byte per lane-block (4 x-voxels x 1 row x 4 planes: the unit pass A classifies):
+//   0            nothing known: the block's 16 words are what the volume holds, and must be read
+//   1            all 16 voxels are (0, 0): never observed (the state after a reset); the volume agrees
+//   2 .. 129     all 16 voxels are (+1, w), w = s - 1 in 1 .. 128.  The volume holds +1 in all 16; its WEIGHTS MAY LAG
+//   130 .. 255   all 16 voxels hold +1 with weights >= 1 that differ (the frustum's rim swept through the block); the
+//                weights in the volume lag by p = s - 130 observations
+// A free-space observation of a block in the last two states moves nothing but the byte: w <- min(w + 1, 128) is s + 1,
+// and one more pending observation is s + 1 too.  The volume's weights are brought up to date ("materialised") only
+// when somebody is about to look at them: pass A does it for every block it hands to pass B (which therefore knows
+// nothing of summaries), k_materialize for the calls that read the volume out (download, cloud, mesh).  The raycast
+// reads TSDF values only, and those are always current.  A block leaves state 1 with a store of (+1, 1) and no load;
+// state 0 is the read-modify-write of before, after which the block is classified again.  A frame at 512^3 used to move
+// 246 MB of its 278 MB through this path.
+// What the calls return is bit for bit what it was without the summaries; they are a representation of the weights of
+// deep free space, kept by: pass A, hsk_reset (all 1), hsk_upload_tsdf (k_rebuild_uniform).
+// Layout: the 64 bytes of a pass-A wave's group (16 lanes in x by 4 rows) are contiguous.
+#define HSK_SUM_RAGGED 130u
+#define HSK_SUM_MAX 255u
+static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams& vp, int x0, int y, int zb) {
+  const size_t tiles_x = (size_t)(vp.X + 63) / 64, tiles_y = (size_t)(vp.Y + 3) / 4;
+  return ((((size_t)(zb >> 2) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 + (size_t)((x0 >> 2) & 15);
+}
 static __device__ __forceinline__ unsigned hsk_uniform_code(unsigned word) {
   const unsigned w = word >> 16;
   if (word == 0u) return 1u;
@@ -248,6 +258,29 @@ static __device__ __forceinline__ unsigned hsk_uniform_code(unsigned word) {
 }
 static __device__ __forceinline__ bool hsk_vector_is(const uint4& q, unsigned word) {
   return q.x == word && q.y == word && q.z == word && q.w == word;
+}
+// state of a block from its 16 words (never 130 + p with p > 0: the words are the truth)
+static __device__ __forceinline__ unsigned hsk_sum_classify(const uint4 q[4]) {
+  const unsigned word = q[0].x;
+  if (hsk_vector_is(q[0], word) && hsk_vector_is(q[1], word) && hsk_vector_is(q[2], word) && hsk_vector_is(q[3], word))
+    return hsk_uniform_code(word);
+  unsigned a = 0xffffffffu, o = 0u, m = 0xffffffffu;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    a &= q[u].x & q[u].y & q[u].z & q[u].w;
+    o |= q[u].x | q[u].y | q[u].z | q[u].w;
+    m = min(m, min(min(q[u].x, q[u].y), min(q[u].z, q[u].w)));
+  }
+  // every TSDF half is 0x7fff (all of its low 15 bits set in the AND, bit 15 clear in the OR), every weight >= 1
+  return ((a & 0x7fffu) == 0x7fffu && (o & 0x8000u) == 0u && m >= 0x10000u && (o >> 16) <= (unsigned)HSK_MAX_WEIGHT) ? HSK_SUM_RAGGED : 0u;
+}
+// p more observations of a block whose 16 voxels all hold +1: w <- min(w + p, 128) on the packed words
+static __device__ __forceinline__ void hsk_vector_add_weight(uint4& q, unsigned p) {
+  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR, inc = p << 16;
+  q.x = min(q.x + inc, cap);
+  q.y = min(q.y + inc, cap);
+  q.z = min(q.z + inc, cap);
+  q.w = min(q.w + inc, cap);
 }
 
 // All four voxels of the vector observed as free space (F == 1).  Onto a stored +1 the running mean leaves +1
@@ -583,7 +616,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     for (int sidx = 0; sidx < NS; ++sidx) {
       sum8[sidx] = 0u;
       if (!COUNT_ONLY && uni != nullptr && actv[sidx] && active)
-        sum8[sidx] = uni[((size_t)(zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2)];
+        sum8[sidx] = uni[hsk_sum_index(vp, x0, y, zbs[sidx])];
     }
     PA_STAMP(6);
     // ---- stage 1: first level (16-px dilated tile table)
@@ -731,22 +764,30 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
           vol[at] = q;
         }
       };
-      // (a) blocks with a summary: no read.  (+1, min(w + 1, 128)) into all 16 voxels, nothing once w == 128
+      // (a) what needs no load.  Free-space blocks: state 1 -> (+1, 1) stored; uniform or rim blocks -> the byte moves.
+      //     Blocks on their way to pass B: a uniform one gets its weights stored, every one loses its summary.
       bool rd[NS];
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) {
-        const bool fr = actv[sidx] && free44_s[sidx];
-        rd[sidx] = fr && sum8[sidx] == 0u;
-        if (fr && sum8[sidx] != 0u && sum8[sidx] <= (unsigned)HSK_MAX_WEIGHT) {  // summary s: weight s - 1 < 128
-          const unsigned word = (sum8[sidx] << 16) | (unsigned)HSK_DIVISOR;    // weight (s - 1) + 1
+        const bool fr = actv[sidx] && free44_s[sidx], ot = actv[sidx] && other_s[sidx];
+        const unsigned sm = sum8[sidx];
+        const size_t ui = hsk_sum_index(vp, x0, y, zbs[sidx]);
+        unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
+        if (fr && sm == 1u) wstore = 1u;
+        if (ot && sm >= 2u && sm < HSK_SUM_RAGGED) wstore = sm - 1u;
+        if (wstore != 0u) {
+          const unsigned word = (wstore << 16) | (unsigned)HSK_DIVISOR;
           const uint4 q = make_uint4(word, word, word, word);
 #pragma unroll
           for (int u = 0; u < 4; ++u) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q);
-          uni[((size_t)(zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2)] = (unsigned char)(sum8[sidx] + 1u);
         }
+        // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays
+        if (fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX) uni[ui] = (unsigned char)(sm + 1u);
+        if (ot && sm != 0u) uni[ui] = 0;
+        // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
+        //     pending observations on its way to pass B
+        rd[sidx] = (fr && (sm == 0u || sm == HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED);
       }
-      // (b) blocks without one: four batched vector updates per group, the loads of both groups in flight together;
-      //     afterwards the block may have become uniform
       bool any_rd = false;
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) any_rd = any_rd || rd[sidx];
@@ -768,15 +809,23 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 #pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx) {
           if (!rd[sidx]) continue;
+          const bool fr = actv[sidx] && free44_s[sidx];
+          const unsigned sm = sum8[sidx];
+          if (sm == 0u) {  // (free) the update rule on whatever the block holds
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (update_vector_free4(q4[sidx][u])) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[sidx][u]);
-          if (uni != nullptr) {
-            const unsigned word = q4[sidx][0].x;
-            const unsigned code = (hsk_vector_is(q4[sidx][0], word) && hsk_vector_is(q4[sidx][1], word) &&
-                                   hsk_vector_is(q4[sidx][2], word) && hsk_vector_is(q4[sidx][3], word))
-                                      ? hsk_uniform_code(word) : 0u;
-            if (code != 0u) uni[((size_t)(zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2)] = (unsigned char)code;
+            for (int u = 0; u < 4; ++u)
+              if (update_vector_free4(q4[sidx][u])) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[sidx][u]);
+          } else {  // the pending observations (and this frame's, for a free block) onto weights under +1
+            const unsigned p = sm - HSK_SUM_RAGGED + (fr ? 1u : 0u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              hsk_vector_add_weight(q4[sidx][u], p);
+              store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[sidx][u]);
+            }
+          }
+          if (fr) {
+            const unsigned code = hsk_sum_classify(q4[sidx]);
+            if (code != 0u || sm != 0u) uni[hsk_sum_index(vp, x0, y, zbs[sidx])] = (unsigned char)code;
           }
         }
       }
@@ -798,7 +847,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         for (int u = 0; u < 4; ++u) pm |= ((zbs[sidx] + u >= zl && zbs[sidx] + u <= zh) ? 1u : 0u) << u;
         const unsigned id = (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
         queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] = id | (pm << 28);
-        if (sum8[sidx] != 0u) uni[id] = 0;  // pass B may rewrite any of its voxels: the block's summary is withdrawn
       }
     }
 #endif
@@ -978,27 +1026,48 @@ void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, u
 }
 
 // lane-block summaries of a volume that was uploaded rather than integrated (one thread per lane-block; a block that
-// reaches beyond the last stored plane has no summary)
-size_t uniform_bytes(const VolParams& vp) { return (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4); }
-__global__ void k_rebuild_uniform(const uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
-  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
+// reaches beyond the last stored plane has no summary), and the reverse: the volume's weights brought up to date
+size_t uniform_bytes(const VolParams& vp) { return (size_t)((vp.nzs + 3) / 4) * ((vp.Y + 3) / 4) * ((vp.X + 63) / 64) * 64; }
+template <bool MATERIALIZE>
+__global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
+  const int qx = vp.X / 4;
+  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * qx;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int qx = vp.X / 4;
   const int xl = (int)(i % qx), y = (int)((i / qx) % vp.Y), zb = (int)(i / ((size_t)qx * vp.Y)) * 4;
-  unsigned code = 0u;
-  if (zb + 3 < vp.nzs) {
-    const size_t plane_vec = (size_t)vp.X * vp.Y / 4, idx0 = (size_t)y * qx + xl;
-    const uint4 q0 = vol[idx0 + (size_t)zb * plane_vec];
-    bool same = hsk_vector_is(q0, q0.x);
-    for (int u = 1; u < 4; ++u) same = same && hsk_vector_is(vol[idx0 + (size_t)(zb + u) * plane_vec], q0.x);
-    code = same ? hsk_uniform_code(q0.x) : 0u;
+  const size_t ui = hsk_sum_index(vp, xl * 4, y, zb);
+  const size_t plane_vec = (size_t)vp.X * vp.Y / 4, idx0 = (size_t)y * qx + xl;
+  if (!MATERIALIZE) {
+    unsigned code = 0u;
+    if (zb + 3 < vp.nzs) {
+      uint4 q[4];
+      for (int u = 0; u < 4; ++u) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+      code = hsk_sum_classify(q);
+    }
+    uni[ui] = (unsigned char)code;
+    return;
   }
-  uni[i] = (unsigned char)code;
+  const unsigned sm = uni[ui];
+  if (sm >= 2u && sm < HSK_SUM_RAGGED) {
+    const unsigned word = ((sm - 1u) << 16) | (unsigned)HSK_DIVISOR;
+    for (int u = 0; u < 4; ++u) vol[idx0 + (size_t)(zb + u) * plane_vec] = make_uint4(word, word, word, word);
+  } else if (sm > HSK_SUM_RAGGED) {
+    uint4 q[4];
+    for (int u = 0; u < 4; ++u) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+    for (int u = 0; u < 4; ++u) {
+      hsk_vector_add_weight(q[u], sm - HSK_SUM_RAGGED);
+      vol[idx0 + (size_t)(zb + u) * plane_vec] = q[u];
+    }
+    uni[ui] = (unsigned char)hsk_sum_classify(q);
+  }
 }
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni) {
-  const size_t n = uniform_bytes(vp);
-  hipLaunchKernelGGL(k_rebuild_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)vol, vp, uni);
+  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
+  hipLaunchKernelGGL(k_summaries<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)const_cast<void*>(vol), vp, uni);
+}
+void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni) {
+  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
+  hipLaunchKernelGGL(k_summaries<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)vol, vp, uni);
 }
 
 // ------------------------------------------------------------------------------------------------------
