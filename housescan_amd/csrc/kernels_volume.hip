@@ -466,6 +466,7 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
       if (nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3])
         vol[idx0 + (size_t)(zb + h0 + u) * plane_vec] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
       if (neg) mark_brick_negative(flags, vp, x0, y, zb + h0 + u);
+
 #else
       if ((nw[0] ^ nw[1] ^ nw[2] ^ nw[3]) == 0x12345u || neg) vol[idx0] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
 #endif
@@ -775,6 +776,9 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
         if (fr && sm == 1u) wstore = 1u;
         if (ot && sm >= 2u && sm < HSK_SUM_RAGGED) wstore = sm - 1u;
+#ifdef HSK_EXPA_NO_WSTORE  // timing experiments (results wrong): one part of stage 3 dropped each
+        wstore = 0u;
+#endif
         if (wstore != 0u) {
           const unsigned word = (wstore << 16) | (unsigned)HSK_DIVISOR;
           const uint4 q = make_uint4(word, word, word, word);
@@ -782,49 +786,49 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
           for (int u = 0; u < 4; ++u) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q);
         }
         // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays
+#ifndef HSK_EXPA_NO_BYTE
         if (fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX) uni[ui] = (unsigned char)(sm + 1u);
         if (ot && sm != 0u) uni[ui] = 0;
+#endif
         // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
         //     pending observations on its way to pass B
         rd[sidx] = (fr && (sm == 0u || sm == HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED);
+#ifdef HSK_EXPA_NO_RD
+        rd[sidx] = false;
+#endif
       }
-      bool any_rd = false;
+      // (one group at a time: this path is the exception now, and four vectors live instead of eight keep the kernel at
+      // seven waves per SIMD)
 #pragma unroll
-      for (int sidx = 0; sidx < NS; ++sidx) any_rd = any_rd || rd[sidx];
-      if (__ballot(any_rd) != 0ull) {
-        uint4 q4[NS][4];
-#pragma unroll
-        for (int sidx = 0; sidx < NS; ++sidx) {
-          if (!rd[sidx]) continue;
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        if (__ballot(rd[sidx]) == 0ull) continue;
+        uint4 q4[4];
+        if (rd[sidx]) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (vp.stream_nt) {
               const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
-              q4[sidx][u] = make_uint4(t.x, t.y, t.z, t.w);
+              q4[u] = make_uint4(t.x, t.y, t.z, t.w);
             } else {
-              q4[sidx][u] = vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec];
+              q4[u] = vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec];
             }
           }
-        }
-#pragma unroll
-        for (int sidx = 0; sidx < NS; ++sidx) {
-          if (!rd[sidx]) continue;
           const bool fr = actv[sidx] && free44_s[sidx];
           const unsigned sm = sum8[sidx];
           if (sm == 0u) {  // (free) the update rule on whatever the block holds
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (update_vector_free4(q4[sidx][u])) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[sidx][u]);
+              if (update_vector_free4(q4[u])) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[u]);
           } else {  // the pending observations (and this frame's, for a free block) onto weights under +1
             const unsigned p = sm - HSK_SUM_RAGGED + (fr ? 1u : 0u);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              hsk_vector_add_weight(q4[sidx][u], p);
-              store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[sidx][u]);
+              hsk_vector_add_weight(q4[u], p);
+              store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[u]);
             }
           }
           if (fr) {
-            const unsigned code = hsk_sum_classify(q4[sidx]);
+            const unsigned code = hsk_sum_classify(q4);
             if (code != 0u || sm != 0u) uni[hsk_sum_index(vp, x0, y, zbs[sidx])] = (unsigned char)code;
           }
         }
