@@ -199,19 +199,34 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
   zint[c] = make_int2(zl, zh);
 }
 
-// per-lane, z-invariant terms of one column group (4 x-adjacent voxels)
+// per-lane, z-invariant terms of one column group (4 x-adjacent voxels): the group centre's R^T (gx, gy, 0), x / y terms
+// pre-multiplied by fx / fy, and gx^2 + gy^2 (the corner terms of the second level are computed when it is entered)
 struct ColumnTerms {
-  float ax[4], ay[4], az[4], pn[4];  // (R^T (gx, gy, 0)) per voxel and gx^2 + gy^2
-  float axfc, ayfc, azc, pnc;        // group centre: x/y terms pre-multiplied by fx/fy
-  float pn_lo, pn_hi;                // smallest / largest gx^2 + gy^2 over the lane's x range (not only at its 4 centres)
+  float axfc, ayfc, azc, pnc;
 };
-// wave-uniform constants of the launch
+// constants of the launch that depend on the configuration only: computed once on the host (they were ~40 instructions
+// with a division in every wave's prologue), passed by value
 struct IntegrateConst {
-  float i02, i12, i22, tz;
-  float rk, zmin, cull_thr, free_thr, hw, hh;
-  float rk4, zmin4, cull_thr4, free_thr4;  // the same for a 4-plane block (voxels within 2.2 cells of its centre)
+  float hw, hh;
+  float rk4, zmin4, cull_thr4, free_thr4;  // first level: a 4-plane block (voxels within 2.2 cells of its centre)
   float cull_thr2, free_thr2;              // second level: against the block's exact distance range (no cell margin)
 };
+static IntegrateConst integrate_const(const VolParams& vp, int W, int H, const Intr& in) {
+  IntegrateConst k;
+  // The 4 voxels of a lane lie within 1.5 cells of the group centre; their pixels lie within
+  // r = rk / z + 2.5 px of the centre's pixel when z > zmin (z - 2 cells >= z / 1.06).
+  const float cellm = fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2]));
+  const float rk = 1.06f * 2.75f * cellm * fmaxf(in.fx, in.fy);
+  k.hw = 0.5f * (float)(W - 1);
+  k.hh = 0.5f * (float)(H - 1);
+  k.rk4 = rk * 1.47f;  // sqrt(1.5^2 + 1.5^2) / 1.5, rounded up
+  k.zmin4 = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk4 / ((float)HSK_TILE - 2.5f));
+  k.cull_thr4 = vp.tau * 1.001f + 1e-4f + 2.3f * cellm;
+  k.free_thr4 = vp.tau * 1.0002f + 1e-4f + 2.3f * cellm;
+  k.cull_thr2 = vp.tau * 1.001f + 1e-4f;
+  k.free_thr2 = vp.tau * 1.0002f + 1e-4f;
+  return k;
+}
 
 // A voxel (x, y, stored plane zz) has just been given a negative TSDF: set its brick's bit and, the first time, its
 // super-brick's.  Test first: after the first frames the bits are already set and no atomic is issued (a stale read
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
                                                    const float2* __restrict__ qtab, double* __restrict__ icp_slot0,
-                                                   unsigned char* __restrict__ uni) {
+                                                   unsigned char* __restrict__ uni, IntegrateConst k) {
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
   // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
   if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -544,46 +559,16 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     const float tx = st->t[0], ty = st->t[1];
     // Rinv = R^T
     const float i00 = st->R[0], i01 = st->R[3], i10 = st->R[1], i11 = st->R[4], i20 = st->R[2], i21 = st->R[5];
-    IntegrateConst k;
-    k.i02 = st->R[6];
-    k.i12 = st->R[7];
-    k.i22 = st->R[8];
-    k.tz = st->t[2];
-    // The 4 voxels of a lane lie within 1.5 cells of the group centre; their pixels lie within
-    // r = rk / z + 2.5 px of the centre's pixel when z > zmin (z - 2 cells >= z / 1.06).
-    const float cellm = fmaxf(vp.cell[0], fmaxf(vp.cell[1], vp.cell[2]));
-    k.rk = 1.06f * 2.75f * cellm * fmaxf(in.fx, in.fy);
-    k.zmin = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk / ((float)HSK_TILE - 2.5f));
-    k.cull_thr = vp.tau * 1.001f + 1e-4f + 2.0f * vp.cell[0];
-    k.free_thr = vp.tau * 1.0002f + 1e-4f + 2.0f * vp.cell[0];
-    k.hw = 0.5f * (float)(W - 1);
-    k.hh = 0.5f * (float)(H - 1);
-    k.rk4 = k.rk * 1.47f;  // sqrt(1.5^2 + 1.5^2) / 1.5, rounded up
-    k.zmin4 = fmaxf(fmaxf(0.1f, 40.0f * cellm), k.rk4 / ((float)HSK_TILE - 2.5f));
-    k.cull_thr4 = vp.tau * 1.001f + 1e-4f + 2.3f * cellm;
-    k.free_thr4 = vp.tau * 1.0002f + 1e-4f + 2.3f * cellm;
-    k.cull_thr2 = vp.tau * 1.001f + 1e-4f;
-    k.free_thr2 = vp.tau * 1.0002f + 1e-4f;
+    const float i02 = st->R[6], i12 = st->R[7], i22 = st->R[8], tz = st->t[2];
     ColumnTerms c;
+    const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
     {
-      const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
-        c.ax[j] = i00 * gx + i01 * gy;
-        c.ay[j] = i10 * gx + i11 * gy;
-        c.az[j] = i20 * gx + i21 * gy;
-        c.pn[j] = gx * gx + gy * gy;
-      }
-      c.axfc = 0.5f * (c.ax[1] + c.ax[2]) * in.fx;
-      c.ayfc = 0.5f * (c.ay[1] + c.ay[2]) * in.fy;
-      c.azc = 0.5f * (c.az[1] + c.az[2]);
-      c.pnc = 0.5f * (c.pn[1] + c.pn[2]);
-      {
-        const float gx0 = ((float)x0 + 0.5f) * vp.cell[0] - tx, gx3 = ((float)(x0 + 3) + 0.5f) * vp.cell[0] - tx;
-        c.pn_hi = fmaxf(c.pn[0], c.pn[3]);
-        c.pn_lo = (gx0 <= 0.0f && gx3 >= 0.0f) ? gy * gy : fminf(c.pn[0], c.pn[3]);
-      }
+      const float gxc = ((float)x0 + 2.0f) * vp.cell[0] - tx;  // between the lane's second and third voxel
+      c.axfc = (i00 * gxc + i01 * gy) * in.fx;
+      c.ayfc = (i10 * gxc + i11 * gy) * in.fy;
+      c.azc = i20 * gxc + i21 * gy;
+      // (gx^2 at the centre is 0.25 cell^2 below the mean of the two middle voxels': the first level's 2.3-cell margin holds it)
+      c.pnc = gxc * gxc + gy * gy;
     }
     const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
     const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
@@ -627,11 +612,11 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       const int zb = zbs[sidx];
       const bool in_any = (zb + 3 >= zl) && (zb <= zh) && active;
       const bool in_all = (zb >= zl) && (zb + 3 <= zh) && active;
-      const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - k.tz;  // centre of planes zb .. zb+3
-      const float czc = c.azc + k.i22 * gz;
+      const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - tz;  // centre of planes zb .. zb+3
+      const float czc = c.azc + i22 * gz;
       const float rc = __builtin_amdgcn_rcpf(czc);
-      const float uc = (c.axfc + (k.i02 * gz) * in.fx) * rc + in.cx;
-      const float vc = (c.ayfc + (k.i12 * gz) * in.fy) * rc + in.cy;
+      const float uc = (c.axfc + (i02 * gz) * in.fx) * rc + in.cx;
+      const float vc = (c.ayfc + (i12 * gz) * in.fy) * rc + in.cy;
       const float r = k.rk4 * rc + 2.5f;
       const bool ok = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
       const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
@@ -650,21 +635,32 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
     //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
 #ifndef HSK_EXPA_NO_L2
+    // (the z-invariant terms of the lane's first and last voxel: only waves with an undecided lane come here)
+    float cax[2], cay[2], caz[2], pn_lo, pn_hi;
+    {
+      const float gx0 = ((float)x0 + 0.5f) * vp.cell[0] - tx, gx3 = ((float)(x0 + 3) + 0.5f) * vp.cell[0] - tx;
+      cax[0] = i00 * gx0 + i01 * gy; cax[1] = i00 * gx3 + i01 * gy;
+      cay[0] = i10 * gx0 + i11 * gy; cay[1] = i10 * gx3 + i11 * gy;
+      caz[0] = i20 * gx0 + i21 * gy; caz[1] = i20 * gx3 + i21 * gy;
+      const float p0 = gx0 * gx0 + gy * gy, p3 = gx3 * gx3 + gy * gy;
+      pn_hi = fmaxf(p0, p3);  // smallest / largest gx^2 + gy^2 over the lane's x range (not only at its 4 centres)
+      pn_lo = (gx0 <= 0.0f && gx3 >= 0.0f) ? gy * gy : fminf(p0, p3);
+    }
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       if (!actv[sidx] || __ballot(other_s[sidx]) == 0ull) continue;
       const int zb = zbs[sidx];
-      const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - k.tz;
-      const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - k.tz;
+      const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - tz;
+      const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - tz;
       float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f, zmn = 1e30f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int j = (q & 1) ? 3 : 0;
+        const int j = q & 1;
         const float gq = (q & 2) ? gzb : gza;
-        const float cz = c.az[j] + k.i22 * gq;
+        const float cz = caz[j] + i22 * gq;
         const float rq = __builtin_amdgcn_rcpf(cz);
-        const float uq = ((c.ax[j] + k.i02 * gq) * in.fx) * rq + in.cx;
-        const float vq = ((c.ay[j] + k.i12 * gq) * in.fy) * rq + in.cy;
+        const float uq = ((cax[j] + i02 * gq) * in.fx) * rq + in.cx;
+        const float vq = ((cay[j] + i12 * gq) * in.fy) * rq + in.cy;
         zmn = fminf(zmn, cz);
         umin = fminf(umin, uq);
         umax = fmaxf(umax, uq);
@@ -711,7 +707,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       // which the distance to the camera centre is largest at a corner and smallest where each coordinate is nearest 0
       const float gz2_hi = fmaxf(gza * gza, gzb * gzb);
       const float gz2_lo = (gza <= 0.0f && gzb >= 0.0f) ? 0.0f : fminf(gza * gza, gzb * gzb);
-      const float d_hi = __builtin_amdgcn_sqrtf(c.pn_hi + gz2_hi), d_lo = __builtin_amdgcn_sqrtf(c.pn_lo + gz2_lo);
+      const float d_hi = __builtin_amdgcn_sqrtf(pn_hi + gz2_hi), d_lo = __builtin_amdgcn_sqrtf(pn_lo + gz2_lo);
       const bool dead2 = ok2 && (d_lo * 0.99999f - Dx > k.cull_thr2);
       const bool free2 = in_all_s[sidx] && ok2 && (d_hi * 1.00001f + k.free_thr2 <= Dn);
       if (other_s[sidx] && free2) free44_s[sidx] = true;
@@ -999,16 +995,17 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
   const unsigned nblk = grid.x * grid.y * (unsigned)zchunks;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
+  const IntegrateConst kc = integrate_const(vp, W, H, in);
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr,
-                       (unsigned char*)nullptr);
+                       (unsigned char*)nullptr, kc);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   } else {
     hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, uni);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, uni, kc);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   }
