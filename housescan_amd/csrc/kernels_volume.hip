@@ -729,15 +729,15 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     // runs under the volume's -- one dependent round trip less in a wave's life)
     const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
+    // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_window)
     unsigned long long bo[NS];
-    unsigned base[NS];
+    unsigned n_other = 0u, base_all = 0u;
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       bo[sidx] = actv[sidx] ? __ballot(other_s[sidx]) : 0ull;
-      base[sidx] = 0;
-      if (bo[sidx] != 0ull && lane == (int)__builtin_ctzll(bo[sidx]))
-        base[sidx] = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned)__popcll(bo[sidx]));
+      n_other += (unsigned)__popcll(bo[sidx]);
     }
+    if (n_other != 0u && lane == 0) base_all = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], n_other);
 #endif
     // ---- stage 3: deep free space -- four batched vector updates per group, the loads of both groups in flight together
 #ifndef HSK_EXPA_NO_FREE
@@ -778,10 +778,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 #pragma unroll
           for (int u = 0; u < 4; ++u) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q);
         }
-        // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays
+        // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays;
+        // 0 for a block on its way to pass B (one store instruction for both cases)
 #ifndef HSK_EXPA_NO_BYTE
-        if (fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX) uni[ui] = (unsigned char)(sm + 1u);
-        if (ot && sm != 0u) uni[ui] = 0;
+        {
+          const bool tick = fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX;
+          if (tick || (ot && sm != 0u)) uni[ui] = (unsigned char)(tick ? sm + 1u : 0u);
+        }
 #endif
         // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
         //     pending observations on its way to pass B
@@ -833,10 +836,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 #endif
     PA_STAMP(4);
 #ifndef HSK_EXPA_NO_QUEUE
+    unsigned b0 = n_other != 0u ? (unsigned)__builtin_amdgcn_readfirstlane((int)base_all) : 0u;
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       if (bo[sidx] == 0ull) continue;
-      const unsigned b0 = (unsigned)__shfl((int)base[sidx], (int)__builtin_ctzll(bo[sidx]), 64);
       if (other_s[sidx]) {
         // the entry: lane-block id, and (when it fits: id_mask_shift != 0) which of its 4 planes lie in the lane's z range
         unsigned pm = 0u;
@@ -845,6 +848,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         const unsigned id = (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
         queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] = id | (pm << 28);
       }
+      b0 += (unsigned)__popcll(bo[sidx]);
     }
 #endif
   }
