@@ -354,7 +354,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     CK(hipMalloc((void**)&b.d_raw, P0 * 2));
     CK(hipMalloc((void**)&b.d_scaled, P0 * 4));
     CK(hipMalloc((void**)&b.d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4 +
-                                    (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8 * 10));  // 8-px table + 4-px table (4x), and their 3x3 window forms
+                                    (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8 * 50));  // 8-px table + 4-px table (4x), and nine window shapes of each
     for (int l = 0; l < HSK_NLEVELS; ++l) {
       const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
       CK(hipMalloc((void**)&b.d_dep[l], P * 2));

@@ -89,24 +89,25 @@ __global__ void k_tile_fine(const float* __restrict__ scaled, int W, int H, floa
   ftab[t] = make_float2(mx, mn);
 }
 
-// The second level always looks at the 3 x 3 tiles from the one that holds its box's top-left corner: that window's
-// (max, min) is formed here once per frame, so that pass A makes ONE look-up per lane-block where it made nine (pass A and
-// pass B are bound by the CU's vector-memory front end, profiles/r02/integrate_analysis.md section 7).  Entry (tx, ty) =
-// over a, b in 0..2 of tab[clamp(ty + a)][clamp(tx + b)] -- the clamping pass A's own nine look-ups had.
+// The second level needs the (max, min) of the depth over the tiles its pixel box touches: nx x ny tiles, nx, ny <= 3,
+// from the tile that holds the box's top-left corner.  Those windows are formed here once per frame, one table per
+// window shape (nine of them: blockIdx.y = (ny - 1) * 3 + (nx - 1)), so that pass A makes ONE look-up per lane-block
+// where it made nine -- pass A and pass B are bound by the CU's vector-memory front end
+// (profiles/r02/integrate_analysis.md section 7) -- and over exactly the tiles the box touches, not always 3 x 3.
+// Entry (tx, ty) of shape (nx, ny) = over a < ny, b < nx of tab[min(ty + a, last)][min(tx + b, last)].
 __global__ void k_tile_window(const float2* __restrict__ tab, int tbw, int tbh, float2* __restrict__ win) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= tbw * tbh) return;
+  const int nx = (int)blockIdx.y % 3 + 1, ny = (int)blockIdx.y / 3 + 1;
   const int ty = t / tbw, tx = t - ty * tbw;
   float mx = 0.0f, mn = 1e30f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
+  for (int a = 0; a < ny; ++a)
+    for (int b = 0; b < nx; ++b) {
       const float2 v = tab[min(ty + a, tbh - 1) * tbw + min(tx + b, tbw - 1)];
       mx = fmaxf(mx, v.x);
       mn = fminf(mn, v.y);
     }
-  win[t] = make_float2(mx, mn);
+  win[(size_t)blockIdx.y * tbw * tbh + t] = make_float2(mx, mn);
 }
 
 // clip [lo,hi] (in gz) with c + m*gz >= 0
@@ -694,11 +695,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       const bool fine = (iu1 >> 2) <= (iu0 >> 2) + 2 && (iv1 >> 2) <= (iv0 >> 2) + 2;
       const int sh = fine ? 2 : 3;
       const int tu0 = iu0 >> sh, tv0 = iv0 >> sh;
-      const bool ok2 = in_img && (iu1 >> sh) <= tu0 + 2 && (iv1 >> sh) <= tv0 + 2;
+      const int nx = (iu1 >> sh) - tu0, ny = (iv1 >> sh) - tv0;  // tiles spanned, less one
+      const bool ok2 = in_img && nx <= 2 && ny <= 2;
       const float2* __restrict__ tab = fine ? qtab : ftab;
       const int tbw = fine ? 2 * fw : fw, tbh = fine ? 2 * fh : fh;
-      // (one look-up: the tables hold the (max, min) of the 3 x 3 tiles from each tile on, k_tile_window)
-      const float2 t9 = tab[min(max(tv0, 0), tbh - 1) * tbw + min(max(tu0, 0), tbw - 1)];
+      // (one look-up: table (nx, ny) holds the (max, min) of the nx x ny tiles from each tile on, k_tile_window)
+      const int shape = min(max(ny, 0), 2) * 3 + min(max(nx, 0), 2);
+      const float2 t9 = tab[(size_t)shape * tbw * tbh + min(max(tv0, 0), tbh - 1) * tbw + min(max(tu0, 0), tbw - 1)];
       const float Dx = t9.x, Dn = t9.y;
       // exact distance range of the block: its 16 voxel centres lie in the rectangle [gx0, gx3] x {gy} x [gza, gzb], over
       // which the distance to the camera centre is largest at a corner and smallest where each coordinate is nearest 0
@@ -959,10 +962,10 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
   float2* ftab = (float2*)(tiles + 4 * tw * th);
   float2* qtab = ftab + (size_t)fw * fh;
   hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, ftab, fw, fh, qtab);
-  // behind them their 3 x 3 window forms (what pass A reads): 8-px, then 4-px
+  // behind them their window forms (what pass A reads): nine shapes of the 8-px table, then nine of the 4-px one
   float2* fwin = qtab + (size_t)4 * fw * fh;
-  hipLaunchKernelGGL(k_tile_window, dim3((fw * fh + 255) / 256), dim3(256), 0, s, ftab, fw, fh, fwin);
-  hipLaunchKernelGGL(k_tile_window, dim3((4 * fw * fh + 255) / 256), dim3(256), 0, s, qtab, 2 * fw, 2 * fh, fwin + (size_t)fw * fh);
+  hipLaunchKernelGGL(k_tile_window, dim3((fw * fh + 255) / 256, 9), dim3(256), 0, s, ftab, fw, fh, fwin);
+  hipLaunchKernelGGL(k_tile_window, dim3((4 * fw * fh + 255) / 256, 9), dim3(256), 0, s, qtab, 2 * fw, 2 * fh, fwin + (size_t)9 * fw * fh);
 }
 
 // words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
@@ -981,10 +984,10 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int ncols = (vp.X / 4) * vp.Y;
   const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
-  // behind the coarse tables (filled by launch_tile_fine): 8-px table, 4-px table, then their 3 x 3 window forms -- pass A
-  // reads the window forms
+  // behind the coarse tables (filled by launch_tile_fine): 8-px table, 4-px table, then their window forms (nine shapes
+  // each) -- pass A reads the window forms
   const float2* ftab = (const float2*)(tmax + 4 * tw * th) + (size_t)5 * fw * fh;
-  const float2* qtab = ftab + (size_t)fw * fh;
+  const float2* qtab = ftab + (size_t)9 * fw * fh;
   const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
   unsigned* qcount = queue;  // HSK_NQUEUES counters, one per 256-B line, cleared by k_column_zrange
   const IcpFinal none = {nullptr, nullptr, 0};
