@@ -280,12 +280,14 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
 // 246 MB of its 278 MB through this path.
 // What the calls return is bit for bit what it was without the summaries; they are a representation of the weights of
 // deep free space, kept by: pass A, hsk_reset (all 1), hsk_upload_tsdf (k_rebuild_uniform).
-// Layout: the 64 bytes of a pass-A wave's group (16 lanes in x by 4 rows) are contiguous.
+// Layout: the two groups of a chunk of 8 planes sit side by side, so a pass-A lane fetches (and rewrites) both of its
+// summaries with ONE 16-bit access, and the 128 bytes of a wave (16 lanes in x by 4 rows by 2 groups) are contiguous.
 #define HSK_SUM_RAGGED 130u
 #define HSK_SUM_MAX 255u
 static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams& vp, int x0, int y, int zb) {
   const size_t tiles_x = (size_t)(vp.X + 63) / 64, tiles_y = (size_t)(vp.Y + 3) / 4;
-  return ((((size_t)(zb >> 2) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 + (size_t)((x0 >> 2) & 15);
+  return (((((size_t)(zb >> 3) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 + (size_t)((x0 >> 2) & 15)) * 2 +
+         (size_t)((zb >> 2) & 1);
 }
 static __device__ __forceinline__ unsigned hsk_uniform_code(unsigned word) {
   const unsigned w = word >> 16;
@@ -497,7 +499,7 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
           neg = neg || (gen[j] && fixed < 0);
         }
       }
-#ifndef HSK_EXPB_NOVOL
+#if !defined(HSK_EXPB_NOVOL) && !defined(HSK_EXPB_NOSTORE)
       // (saturated free space -- +1 at the weight cap -- comes back unchanged: no store)
       if (nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3])
         vol[idx0 + (size_t)(zb + h0 + u) * plane_vec] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
@@ -618,13 +620,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       dc_s[sidx] = 0.0f;
     }
     // the summaries of the lane's (at most NS) lane-blocks: requested now, used in stage 3
+    static_assert(NS == 2, "the summaries of a chunk's two groups are fetched as one 16-bit word");
+    unsigned sum16 = 0u;  // both summaries of the lane's chunk (group g of the chunk in byte g)
+    unsigned short* const sum_at = (unsigned short*)(uni + hsk_sum_index(vp, x0, y, zbeg));
+    if (!COUNT_ONLY && uni != nullptr && active && (actv[0] || actv[1])) sum16 = *sum_at;
     unsigned sum8[NS];
 #pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) {
-      sum8[sidx] = 0u;
-      if (!COUNT_ONLY && uni != nullptr && actv[sidx] && active)
-        sum8[sidx] = uni[hsk_sum_index(vp, x0, y, zbs[sidx])];
-    }
+    for (int sidx = 0; sidx < NS; ++sidx) sum8[sidx] = actv[sidx] ? (sum16 >> (8 * ((zbs[sidx] - zbeg) >> 2))) & 0xffu : 0u;
+    unsigned new16 = sum16;
     PA_STAMP(6);
     // ---- stage 1: first level (16-px dilated tile table)
 #pragma unroll
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       for (int sidx = 0; sidx < NS; ++sidx) {
         const bool fr = actv[sidx] && free44_s[sidx], ot = actv[sidx] && other_s[sidx];
         const unsigned sm = sum8[sidx];
-        const size_t ui = hsk_sum_index(vp, x0, y, zbs[sidx]);
+        const int sbit = 8 * ((zbs[sidx] - zbeg) >> 2);  // where the group's summary sits in new16
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
         if (fr && sm == 1u) wstore = 1u;
         if (ot && sm >= 2u && sm < HSK_SUM_RAGGED) wstore = sm - 1u;
@@ -782,11 +785,11 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
           for (int u = 0; u < 4; ++u) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q);
         }
         // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays;
-        // 0 for a block on its way to pass B (one store instruction for both cases)
+        // 0 for a block on its way to pass B (the word is stored once, after the read path below)
 #ifndef HSK_EXPA_NO_BYTE
         {
           const bool tick = fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX;
-          if (tick || (ot && sm != 0u)) uni[ui] = (unsigned char)(tick ? sm + 1u : 0u);
+          if (tick || (ot && sm != 0u)) new16 = (new16 & ~(0xffu << sbit)) | ((tick ? sm + 1u : 0u) << sbit);
         }
 #endif
         // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
@@ -827,11 +830,12 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
             }
           }
           if (fr) {
-            const unsigned code = hsk_sum_classify(q4);
-            if (code != 0u || sm != 0u) uni[hsk_sum_index(vp, x0, y, zbs[sidx])] = (unsigned char)code;
+            const int sbit = 8 * ((zbs[sidx] - zbeg) >> 2);
+            new16 = (new16 & ~(0xffu << sbit)) | (hsk_sum_classify(q4) << sbit);
           }
         }
       }
+      if (new16 != sum16) *sum_at = (unsigned short)new16;
     }
 #endif
 #ifdef HSK_PA_TIMING
@@ -1039,7 +1043,7 @@ void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, u
 
 // lane-block summaries of a volume that was uploaded rather than integrated (one thread per lane-block; a block that
 // reaches beyond the last stored plane has no summary), and the reverse: the volume's weights brought up to date
-size_t uniform_bytes(const VolParams& vp) { return (size_t)((vp.nzs + 3) / 4) * ((vp.Y + 3) / 4) * ((vp.X + 63) / 64) * 64; }
+size_t uniform_bytes(const VolParams& vp) { return (size_t)((vp.nzs + 7) / 8) * ((vp.Y + 3) / 4) * ((vp.X + 63) / 64) * 128; }
 template <bool MATERIALIZE>
 __global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
   const int qx = vp.X / 4;
