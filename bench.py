@@ -548,6 +548,11 @@ def main():
     else:
         out = run_multi(args, hsk, torch, world, rank, local_rank)
     if rank == 0 and out is not None:
+        try:   # which sources the measured library was built from (sha256 over them: housescan_amd/csrc/build_id.py)
+            from housescan_amd import _lib
+            out["build_id"] = _lib.load().hsk_build_id().decode()
+        except Exception:  # noqa: BLE001
+            pass
         # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then
         sys.stdout.flush()
         try:
