@@ -559,8 +559,18 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
   PA_STAMP(0);
   // wave footprint: 64 voxels in x (16 lanes x 16 B = 256 contiguous bytes) by 4 rows in y -- compact, so
   // that the wave-uniform z range and the group classification reject whole planes, not just lanes
-  const int x0 = (blockIdx.x * 16 + (lane & 15)) * 4;
-  const int y = (blockIdx.y * 4 + threadIdx.y) * 4 + (lane >> 4);
+  // Which x block a workgroup takes rotates with its row and its chunk.  Workgroups go round the eight XCDs in turn, and a
+  // volume of 512 voxels has exactly eight blocks per row: unrotated, every workgroup of x block b ran on XCD b, and the
+  // frustum covers the middle blocks of a row far more than the outer ones -- the XCDs' loads differed by as much
+  // (profiles/r02/raycast_split_experiment.md met the same aliasing).
+#ifdef HSK_PA_NO_ROTATE
+  const unsigned bxr = blockIdx.x;
+#else
+  const unsigned bxr = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
+#endif
+  const unsigned byr = blockIdx.y;  // (rotating the rows with the chunk as well changes nothing: 42.2-42.9 us against 41.7)
+  const int x0 = (int)(bxr * 16u + (unsigned)(lane & 15)) * 4;
+  const int y = (int)(byr * 4u + threadIdx.y) * 4 + (lane >> 4);
   const bool active = (x0 < vp.X) && (y < vp.Y);
   unsigned long long cnt = 0;
   const int zbeg = blockIdx.z * zchunk;
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 #ifndef HSK_EXPA_NO_QUEUE
     // (the tickets are REQUESTED here, before the free-space loads, and used after the stores: the counters' round trip
     // runs under the volume's -- one dependent round trip less in a wave's life)
-    const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned lin = (blockIdx.z * gridDim.y + byr) * gridDim.x + bxr;
     const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
     // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_window)
     unsigned long long bo[NS];
