@@ -196,6 +196,32 @@ def test_free_space_weights_long_run(hsk, oracle, synth_frames):
     trk.close()
 
 
+def test_upload_then_integrate_more(hsk, oracle, synth_frames):
+    """a volume uploaded into a fresh context (its free-space summaries rebuilt from the words) takes further frames exactly
+    as the context it came from: both equal the oracle's volume, with and without a read-back in between"""
+    n = 64
+    cfg_o = oracle.default_config(n)
+    a = hsk.KinfuTracker(n=n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    for k in (0, 4, 8, 12):
+        pose, depth = synth_frames(k)
+        oracle.integrate(cfg_o, vol, oracle.scale_depth(cfg_o, depth), pose)
+        a.integrate(depth, pose)
+    b = hsk.KinfuTracker(n=n)
+    b.upload_tsdf(a.download_tsdf())
+    for k in (16, 20, 24, 12, 12):
+        pose, depth = synth_frames(k)
+        oracle.integrate(cfg_o, vol, oracle.scale_depth(cfg_o, depth), pose)
+        a.integrate(depth, pose)
+        b.integrate(depth, pose)
+    assert_same_bits(b.download_tsdf(), vol, "uploaded context after five more frames")
+    assert_same_bits(a.download_tsdf(), vol, "original context after five more frames")
+    ca, cb = a.extract_cloud(), b.extract_cloud()
+    assert_same_bits(np.asarray(cb[0] if isinstance(cb, tuple) else cb), np.asarray(ca[0] if isinstance(ca, tuple) else ca), "clouds of the two contexts")
+    a.close()
+    b.close()
+
+
 def test_preprocess_bit_exact(hsk, oracle, synth_frames):
     cfg_o = oracle.default_config(64)
     trk = hsk.KinfuTracker(n=64)
