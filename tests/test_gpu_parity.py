@@ -350,6 +350,33 @@ def test_tracker_bit_exact_and_accurate(hsk, oracle, synth_frames, graph):
     trk.close()
 
 
+def test_tracker_long_stream_vs_oracle(hsk, oracle):
+    """260 tracked frames, pipelined (submit / wait, one frame in flight ahead) -- past the saturation of the weights at
+    128 and through every state of the free-space summaries: every pose and the final TSDF are the oracle tracker's"""
+    import torch
+    n, total = 96, 260
+    cfg_o = oracle.default_config(n)
+    ot = oracle.Tracker(cfg_o, omp=True)
+    frames = [hsk.synth_depth(hsk.synth_pose(k)) for k in range(total)]
+    want = [ot.process(d) for d in frames]
+    dev = torch.from_numpy(np.stack(frames).view(np.int16)).cuda()
+    trk = hsk.KinfuTracker(n=n)
+    got = []
+    trk.submit_frame_dev(dev[0].data_ptr())
+    for k in range(1, total):
+        trk.submit_frame_dev(dev[k].data_ptr())
+        got.append(trk.wait_frame())
+    got.append(trk.wait_frame())
+    for k, ((po, oko), (pp, okp)) in enumerate(zip(want, got)):
+        assert oko == okp, f"frame {k}"
+        assert_same_bits(pp, po, f"pose of frame {k}")
+    assert all(ok for _, ok in want[1:])
+    vol = ot.volume()
+    assert vol[..., 1].max() == 128
+    assert_same_bits(trk.download_tsdf(), vol, "tsdf after 260 frames")
+    trk.close()
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (336, 252), (160, 120)])
 def test_tracker_other_image_sizes(hsk, oracle, w, h):
     """image sizes other than 640x480 take other kernel shapes (ICP pixels per lane by level width, the raycast's fused
