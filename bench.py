@@ -525,6 +525,9 @@ def main():
                     help="N > 1 slabs: hsk_group_* (C ABI, RCCL inside the library) or the Python harness over torch.distributed")
     ap.add_argument("--backend", default="nccl", help="--engine torch: torch.distributed backend (nccl = RCCL; gloo for the check below)")
     ap.add_argument("--share-gpu", action="store_true", help="--engine torch: all ranks on device 0 (logic check on a one-GPU box)")
+    ap.add_argument("--allow-exp", action="store_true",
+                    help="measure a library built with other than the default flags or from other sources (the A/B scripts under tools/); "
+                         "the line then carries \"experimental_build\": true and is not a result")
     args = ap.parse_args()
     if args.quick:
         args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = args.no_rooms = True
@@ -532,6 +535,15 @@ def main():
     import torch
 
     import housescan_amd as hsk
+    from housescan_amd import _lib
+    from housescan_amd.csrc import build_id as tree_id
+
+    # The measured library must be the default build of THIS tree: "+exp" marks other compiler flags (timing experiments,
+    # some of which give wrong results by construction), a different hash a stale .so.  tests/conftest.py refuses both too.
+    have, want = _lib.load().hsk_build_id().decode(), tree_id.build_id()
+    if have != want and not args.allow_exp:
+        raise SystemExit("bench.py: housescan_amd/libhskinfu.so is build %s, the tree is %s -- rebuild with "
+                         "`python -c 'import __graft_entry__ as g; g.build()'` (or pass --allow-exp for a timing experiment)" % (have, want))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -548,11 +560,9 @@ def main():
     else:
         out = run_multi(args, hsk, torch, world, rank, local_rank)
     if rank == 0 and out is not None:
-        try:   # which sources the measured library was built from (sha256 over them: housescan_amd/csrc/build_id.py)
-            from housescan_amd import _lib
-            out["build_id"] = _lib.load().hsk_build_id().decode()
-        except Exception:  # noqa: BLE001
-            pass
+        out["build_id"] = have   # which sources the measured library was built from (housescan_amd/csrc/build_id.py)
+        if have != want:
+            out["experimental_build"] = True
         # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then
         sys.stdout.flush()
         try:

@@ -342,7 +342,6 @@ static __device__ __forceinline__ bool update_vector_free4(uint4& q) {
     gen[j] = !simple;
     gen_any = gen_any || gen[j];
   }
-#ifndef HSK_EXPA_NO_FALLBACK  // (timing experiment: such vectors are updated as if they held +1; results wrong)
   if (__ballot(gen_any) != 0ull) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -356,7 +355,6 @@ static __device__ __forceinline__ bool update_vector_free4(uint4& q) {
       nw[j] = gen[j] ? wg : nw[j];
     }
   }
-#endif
   q = make_uint4(nw[0], nw[1], nw[2], nw[3]);
   return nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3];
 }
@@ -416,9 +414,7 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         q[u] = make_uint4(0u, 0u, 0u, 0u);
-#ifndef HSK_EXPB_NOVOL  // timing experiment: no volume traffic (results wrong)
         if (inr[u]) q[u] = vol[idx0 + (size_t)(zb + h0 + u) * plane_vec];
-#endif
       }
     }
     // 2. projection of the 4U voxel centres (A.4, exact), then their depth gathers
@@ -445,11 +441,7 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-#ifdef HSK_EXPB_NOGATHER  // timing experiment: coalesced loads instead of the gathers (results wrong)
-      for (int j = 0; j < 4; ++j) D[u][j] = scaled[(u * 4 + j) * 64 + lane];
-#else
       for (int j = 0; j < 4; ++j) D[u][j] = scaled[max(pix[u][j], 0)];
-#endif
     // 3. the observation: F in [-1, 1] for a voxel the rule rewrites, -4 for one it leaves alone
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -499,15 +491,11 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
           neg = neg || (gen[j] && fixed < 0);
         }
       }
-#if !defined(HSK_EXPB_NOVOL) && !defined(HSK_EXPB_NOSTORE)
       // (saturated free space -- +1 at the weight cap -- comes back unchanged: no store)
       if (nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3])
         vol[idx0 + (size_t)(zb + h0 + u) * plane_vec] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
       if (neg) mark_brick_negative(flags, vp, x0, y, zb + h0 + u);
 
-#else
-      if ((nw[0] ^ nw[1] ^ nw[2] ^ nw[3]) == 0x12345u || neg) vol[idx0] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-#endif
     }
   }
   return cnt;
@@ -544,9 +532,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // dtab: per 16x16-pixel tile (max, min-if-all-valid) of the scaled depth, 3x3-dilated.  It is 9.6 KB and stays
   // hot in every CU's vector L1; staging it in LDS per workgroup cost ~2.5 us of each short-lived block's life.
-#ifdef HSK_EXPA_EXTRA_IDLE  // timing experiment: as many extra waves again that exit at once (what does a launch cost?)
-  if ((int)blockIdx.z * zchunk >= vp.nzs) return;
-#endif
   const int lane = threadIdx.x;
   if (!COUNT_ONLY && st->lost) return;
 #ifdef HSK_PA_TIMING
@@ -563,11 +548,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
   // volume of 512 voxels has exactly eight blocks per row: unrotated, every workgroup of x block b ran on XCD b, and the
   // frustum covers the middle blocks of a row far more than the outer ones -- the XCDs' loads differed by as much
   // (profiles/r02/raycast_split_experiment.md met the same aliasing).
-#ifdef HSK_PA_NO_ROTATE
-  const unsigned bxr = blockIdx.x;
-#else
   const unsigned bxr = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
-#endif
   const unsigned byr = blockIdx.y;  // (rotating the rows with the chunk as well changes nothing: 42.2-42.9 us against 41.7)
   const int x0 = (int)(bxr * 16u + (unsigned)(lane & 15)) * 4;
   const int y = (int)(byr * 4u + threadIdx.y) * 4 + (lane >> 4);
@@ -668,7 +649,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
     //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
     //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
-#ifndef HSK_EXPA_NO_L2
     // (the z-invariant terms of the lane's first and last voxel: only waves with an undecided lane come here)
     float cax[2], cay[2], caz[2], pn_lo, pn_hi;
     {
@@ -726,7 +706,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       if (other_s[sidx] && free2) free44_s[sidx] = true;
       other_s[sidx] = other_s[sidx] && !dead2 && !free2;
     }
-#endif
     PA_STAMP(3);
 #ifdef HSK_PA_TIMING
     if (!COUNT_ONLY && pa_wave < 65536u) {
@@ -740,7 +719,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
     // few columns, and pass B's time is its longest queue.  Rotate the assignment by the row of HSK_NQUEUES blocks and by
     // the wave: within a row it stays a bijection, so every queue still receives at most one wave-quarter of one block
     // per row and wave index (the capacity bound).  Both groups' tickets are requested before either is used.
-#ifndef HSK_EXPA_NO_QUEUE
     // (the tickets are REQUESTED here, before the free-space loads, and used after the stores: the counters' round trip
     // runs under the volume's -- one dependent round trip less in a wave's life)
     const unsigned lin = (blockIdx.z * gridDim.y + byr) * gridDim.x + bxr;
@@ -754,9 +732,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       n_other += (unsigned)__popcll(bo[sidx]);
     }
     if (n_other != 0u && lane == 0) base_all = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], n_other);
-#endif
     // ---- stage 3: deep free space -- four batched vector updates per group, the loads of both groups in flight together
-#ifndef HSK_EXPA_NO_FREE
     if (COUNT_ONLY) {
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx)
@@ -785,9 +761,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
         if (fr && sm == 1u) wstore = 1u;
         if (ot && sm >= 2u && sm < HSK_SUM_RAGGED) wstore = sm - 1u;
-#ifdef HSK_EXPA_NO_WSTORE  // timing experiments (results wrong): one part of stage 3 dropped each
-        wstore = 0u;
-#endif
         if (wstore != 0u) {
           const unsigned word = (wstore << 16) | (unsigned)HSK_DIVISOR;
           const uint4 q = make_uint4(word, word, word, word);
@@ -796,18 +769,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
         }
         // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays;
         // 0 for a block on its way to pass B (the word is stored once, after the read path below)
-#ifndef HSK_EXPA_NO_BYTE
         {
           const bool tick = fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX;
           if (tick || (ot && sm != 0u)) new16 = (new16 & ~(0xffu << sbit)) | ((tick ? sm + 1u : 0u) << sbit);
         }
-#endif
         // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
         //     pending observations on its way to pass B
         rd[sidx] = (fr && (sm == 0u || sm == HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED);
-#ifdef HSK_EXPA_NO_RD
-        rd[sidx] = false;
-#endif
       }
       // (one group at a time: this path is the exception now, and four vectors live instead of eight keep the kernel at
       // seven waves per SIMD)
@@ -847,12 +815,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       }
       if (new16 != sum16) *sum_at = (unsigned short)new16;
     }
-#endif
 #ifdef HSK_PA_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp below sees the loads back and the stores acknowledged
 #endif
     PA_STAMP(4);
-#ifndef HSK_EXPA_NO_QUEUE
     unsigned b0 = n_other != 0u ? (unsigned)__builtin_amdgcn_readfirstlane((int)base_all) : 0u;
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
@@ -867,7 +833,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       }
       b0 += (unsigned)__popcll(bo[sidx]);
     }
-#endif
   }
   PA_STAMP(5);
   if (COUNT_ONLY) {
@@ -1009,11 +974,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, dil_blocks,
                      tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount, fin, const_cast<TrackState*>(st));
   dim3 block(64, 4, 1);
-#ifdef HSK_EXPA_EXTRA_IDLE
-  dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks * HSK_EXPA_EXTRA_IDLE);
-#else
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
-#endif
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
   // behind the counters: HSK_NQUEUES queues of qcap entries each; a block of pass A holds at most 4 waves x 64 lanes
   // x (zchunk / 4) blocks and every HSK_NQUEUES-th block shares a queue

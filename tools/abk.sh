@@ -1,4 +1,5 @@
 #!/bin/bash
+source "$(dirname "$0")/restore_default.sh"
 # usage: tools/abk.sh tag "<defines A>" "<defines B>" ... [-- bench args]
 # For each set of -D switches: rebuild the kernels on the GPU box, run a short bench under rocprofv3 --kernel-trace
 # and print the frame rate, the stage times and the integrate kernels' average durations.
@@ -12,7 +13,7 @@ for defs in "$@"; do
   make -s -C housescan_amd/csrc FLAGS="$BASE $defs" 2>&1 | grep -E "error" 
   OUT=$ROOT/gpurun_out/$tag/v$i
   rm -rf $OUT; mkdir -p $OUT
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --quick $BARGS ${HSK_BENCH_ARGS} > $OUT/log.txt 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --allow-exp --quick $BARGS ${HSK_BENCH_ARGS} > $OUT/log.txt 2>&1)
   echo "== [$i] $defs"
   grep -o '{"metric.*' $OUT/log.txt | python3 -c "
 import json,sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+source "$(dirname "$0")/restore_default.sh"
 # usage: tools/icp_timing.sh ["extra -D flags"] -- per-block phase times of the 19 ICP iterations (timing build)
 cd ${GRAFT_REPO_ROOT:-.}
 touch housescan_amd/csrc/kernels_image.hip

@@ -1,4 +1,5 @@
 #!/bin/bash
+source "$(dirname "$0")/restore_default.sh"
 # usage: tools/rc_timing.sh ["extra -D flags"] -- per-wave phase times of the raycast (timing build)
 cd ${GRAFT_REPO_ROOT:-.}
 touch housescan_amd/csrc/kernels_volume.hip
