@@ -170,6 +170,80 @@ def pmc_traffic(volume, total, window_first, timeout_s=150):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# work the timed region defers or leaves out: reading the scan's products out of the volume
+# ---------------------------------------------------------------------------------------------------------------------
+def readout_block(trk, n, with_download=True):
+    """After the timed frames: the deferred free-space weights written back into the volume (k_summaries<true>, what
+    every read-out does first), the TSDF zero-crossing cloud (hsk_extract_cloud: count pass, row scan, write pass, D2H)
+    and the whole volume (hsk_download_tsdf: D2H into pageable host memory) -- host wall clock around each call."""
+    trk.synchronize()
+    t0 = time.perf_counter()
+    trk.flush_weights()
+    trk.synchronize()
+    t1 = time.perf_counter()
+    cloud, total = trk.extract_cloud()
+    t2 = time.perf_counter()
+    out = {"flush_weights_ms": round((t1 - t0) * 1e3, 3), "extract_cloud_ms": round((t2 - t1) * 1e3, 3), "cloud_points": int(total),
+           "note": "host clock; flush = the free-space weights held in the lane-block summaries written back into the volume (once: the "
+                   "read-outs after it find them current); the timed frames never pay it"}
+    del cloud
+    if with_download:
+        t3 = time.perf_counter()
+        vol = trk.download_tsdf()
+        t4 = time.perf_counter()
+        out["download_tsdf_ms"] = round((t4 - t3) * 1e3, 1)
+        out["download_GBps_pageable_host"] = round(vol.nbytes / (t4 - t3) / 1e9, 2)
+        del vol
+    return out
+
+
+def angle_deg(Ra, Rb):
+    f = np.linalg.norm(Ra.astype(np.float64) - Rb.astype(np.float64))
+    return float(np.degrees(2.0 * np.arcsin(min(1.0, f / (2.0 * np.sqrt(2.0))))))
+
+
+def is_synthetic_stream(hsk, rd):
+    """does the file hold the scripted synthetic stream?  Then its ground-truth poses are known."""
+    if (rd.w, rd.hgt) != (W, H) or len(rd) < 1:
+        return False
+    last = len(rd) - 1
+    return np.array_equal(rd[0], hsk.synth_depth(hsk.synth_pose(0))) and np.array_equal(rd[last], hsk.synth_depth(hsk.synth_pose(last)))
+
+
+def record_synthetic(hsk, path, frames):
+    wr = hsk.DepthStreamWriter(path)
+    for k in range(frames):
+        wr.write(hsk.synth_depth(hsk.synth_pose(k)))
+    wr.close()
+
+
+def stream_replay(hsk, n, path, local_rank=0, first=0, count=None):
+    """a recorded HSKD stream through hsk_track_stream (host frames from the file, the frame feed inside the library,
+    one frame in flight ahead); frames/s over the whole replay and, for the synthetic stream, the trajectory error"""
+    rd = hsk.DepthStreamReader(path)
+    count = len(rd) - first if count is None else count
+    trk = hsk.KinfuTracker(n=n, device_id=local_rank)
+    trk.track_stream(rd, first, min(count, 2))   # page the library in, first-frame path
+    trk.reset()
+    t0 = time.perf_counter()
+    poses, ok = trk.track_stream(rd, first, count)
+    trk.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"volume": n, "frames": int(count), "frames_per_s_file_and_pcie_inclusive": round(count / dt, 2), "lost_frames": int((~ok[1:]).sum()),
+           "api": "hsk_track_stream (HSKD file -> pinned ring -> H2D -> tracker, one frame in flight ahead)"}
+    if is_synthetic_stream(hsk, rd):
+        gt = np.stack([hsk.synth_pose(first + k) for k in range(count)])
+        err = np.linalg.norm(poses[:, :3, 3].astype(np.float64) - gt[:, :3, 3].astype(np.float64), axis=1) * 1e3
+        ang = np.array([angle_deg(poses[k, :3, :3], gt[k, :3, :3]) for k in range(count)])
+        out["trajectory_vs_ground_truth"] = {"ate_rmse_mm": round(float(np.sqrt((err ** 2).mean())), 3), "ate_max_mm": round(float(err.max()), 3),
+                                             "final_mm": round(float(err[-1]), 3), "angle_max_deg": round(float(ang.max()), 4),
+                                             "note": "scripted synthetic stream (SURVEY.md 8(d)): yaw 12 deg, pitch 4 deg, 0.15 m circle, 10 s @ 30 Hz"}
+    rd.close()
+    trk.close()
+    return out, poses
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, sync_api=False):
     """the timed region at one GPU: warm-up, then K frames through hsk_submit_frame_dev / hsk_wait_frame"""
     trk = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=graph)
@@ -325,12 +399,24 @@ def run_single(args, hsk, torch, local_rank):
         out["pcie_inclusive_pipelined_fps"] = round(len(hf) / (t2 - t1), 2)
         out["pcie_inclusive_note"] = ("hsk_submit_frame / hsk_wait_frame with HOST frames (memcpy into a pinned ring, H2D under the previous "
                                       "frame), %d frames; worst single frame %.2f ms" % (len(hf), float(per_h.max()) * 1e3))
+    if not args.no_readout:
+        out["readout_ms"] = readout_block(trk, n)
     trk.close()
+    # ---- SURVEY.md 8(d) cfg2 / BASELINE configs[1]: the 300-frame scripted stream at 256^3, from a recorded file ----
+    if not args.no_trajectory:
+        tmpd = tempfile.mkdtemp(prefix="hsk_stream_")
+        try:
+            path = os.path.join(tmpd, "synthetic_300.hskd")
+            record_synthetic(hsk, path, 300)
+            out["trajectory_256"], _ = stream_replay(hsk, 256, path, local_rank)
+        finally:
+            shutil.rmtree(tmpd, ignore_errors=True)
     # ---- 1024^3: the HBM measurement ----
     if n == 512 and not args.no_1024:
         K2, W2 = min(K, 40), min(Wm, 5)
         tot2 = 1 + W2 + K2
         trk2, pose2, lost2, el2, _ = timed_single(hsk, torch, 1024, K2, W2, args.ahead, dev_frames[:tot2], local_rank)
+        ro2 = None if args.no_readout else readout_block(trk2, 1024)
         trk2.close()
         rep2, ms2, nf2, _, v2, _ = replay_with_events(hsk, 1024, K2, W2, frames[:tot2], dev_frames[:tot2], local_rank, pose2)
         rep2.close()
@@ -339,6 +425,8 @@ def run_single(args, hsk, torch, local_rank):
         blk.update({"frames_per_s": round(K2 / el2, 2), "steps": K2, "warmup": W2, "lost_frames": int(lost2),
                     "stage_us": {"preprocess": round(ms2[0] / nf2 * 1e3, 1), "icp": round(ms2[1] / nf2 * 1e3, 1),
                                  "integrate": round(ms2[2] / nf2 * 1e3, 1), "raycast": round(ms2[3] / nf2 * 1e3, 1)}})
+        if ro2 is not None:
+            blk["readout_ms"] = ro2
         out["roofline_1024"] = blk
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, hsk)
@@ -513,6 +601,11 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--no-1024", action="store_true", help="skip the 1024^3 roofline block")
     ap.add_argument("--no-host-frames", action="store_true", help="skip the PCIe-inclusive (host frame) figure")
+    ap.add_argument("--no-readout", action="store_true", help="skip the read-out timings (flush of the deferred weights, cloud, volume download)")
+    ap.add_argument("--no-trajectory", action="store_true", help="skip the 300-frame recorded-stream replay at 256^3 (trajectory report)")
+    ap.add_argument("--stream", default=None, metavar="FILE.hskd",
+                    help="time the replay of a recorded depth stream through hsk_track_stream instead of the synthetic in-HBM frames "
+                         "(a missing FILE is first recorded from the 300-frame synthetic stream)")
     ap.add_argument("--no-rooms", action="store_true", help="N > 1, --mode slab: skip the secondary one-room-per-GPU (weak scaling) block")
     ap.add_argument("--quick", action="store_true", help="all of the above")
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
@@ -531,6 +624,7 @@ def main():
     args = ap.parse_args()
     if args.quick:
         args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = args.no_rooms = True
+        args.no_readout = args.no_trajectory = True
 
     import torch
 
@@ -553,7 +647,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world == 1 and not os.environ.get("HSK_BENCH_FORCE_MULTI"):  # (the variable: the N > 1 flow on a world of one rank, for the tests)
+    if args.stream:
+        if not os.path.exists(args.stream):
+            record_synthetic(hsk, args.stream, 300)
+        rep, _ = stream_replay(hsk, args.volume, args.stream, local_rank)
+        out = {"metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % args.volume,
+               "value": rep["frames_per_s_file_and_pcie_inclusive"], "unit": "frames/s", "n_gpus": 1, "steps": rep["frames"], "warmup": 0,
+               "ms_per_step": round(1e3 / rep["frames_per_s_file_and_pcie_inclusive"], 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "recorded stream " + os.path.basename(args.stream),
+               "config": {"workload": "configs[2]: %d^3 scan from a RECORDED depth stream (HSKD file; host frames, file read and PCIe inside the "
+                                      "timed region -- not the HBM-resident headline figure)" % args.volume, "volume": args.volume, "image": [W, H],
+                          "icp_iters": [10, 5, 4], "parallelism": "1 gpu", "api": rep["api"]},
+               "stream": rep}
+    elif world == 1 and not os.environ.get("HSK_BENCH_FORCE_MULTI"):  # (the variable: the N > 1 flow on a world of one rank, for the tests)
         out = run_single(args, hsk, torch, local_rank)
     elif args.engine == "torch" and args.mode == "slab":  # (the harness has no rooms / pairs form)
         out = run_multi_torch(args, hsk, torch, world, rank, local_rank)

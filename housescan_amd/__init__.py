@@ -10,5 +10,7 @@ from .kinfu import (GROUP_FORCE_RCCL, GROUP_ICP_ALLREDUCE, KinfuError, KinfuGrou
                     bilateral_tables, default_config, synth_depth, synth_pose, synth_room_depth, synth_room_extents,
                     synth_room_pose)
 
-__all__ = ["KinfuError", "KinfuTracker", "KinfuGroup", "GROUP_FORCE_RCCL", "GROUP_ICP_ALLREDUCE", "default_config",
+from .products import DepthStreamReader, DepthStreamWriter  # noqa: E402  (recorded depth streams: the HSKD container)
+
+__all__ = ["DepthStreamReader", "DepthStreamWriter", "KinfuError", "KinfuTracker", "KinfuGroup", "GROUP_FORCE_RCCL", "GROUP_ICP_ALLREDUCE", "default_config",
            "synth_depth", "synth_pose", "bilateral_tables", "synth_room_depth", "synth_room_extents", "synth_room_pose"]

@@ -61,6 +61,7 @@ SYMBOLS = {
     "hsk_count_updates": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, C.POINTER(C.c_uint64)]),
     "hsk_download_tsdf": (C.c_int, [_P, _P]),
     "hsk_upload_tsdf": (C.c_int, [_P, _P]),
+    "hsk_flush_weights": (C.c_int, [_P]),
     "hsk_stored_planes": (C.c_int, [_P, _I, _I]),
     "hsk_get_pose": (C.c_int, [_P, _F]),
     "hsk_set_pose": (C.c_int, [_P, _F]),
@@ -124,6 +125,8 @@ SYMBOLS = {
     "hsk_stream_write": (C.c_int, [_P, _P]),
     "hsk_stream_read": (C.c_int, [_P, C.c_int, _P]),
     "hsk_stream_close": (C.c_int, [_P]),
+    "hsk_stream_info": (C.c_int, [_P, _I, _I, _I, _F]),
+    "hsk_track_stream": (C.c_int, [_P, _P, C.c_int, C.c_int, _F, _I]),
 }
 
 # every symbol include/hshouse.h declares (host-side room stitching)

@@ -61,6 +61,7 @@ struct hsk_ctx {
   unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
   unsigned char* d_uni = nullptr;    // lane-block summaries (kernels_volume.hip: hsk_uniform_code), one byte per 4x1x4 voxels
   size_t uni_bytes = 0;
+  bool weights_pending = false;      // an integrate has been enqueued since the summaries' weights were last written back
   size_t flags_bytes = 0;
   unsigned* d_queue = nullptr;       // integrate pass A -> pass B: count (4 words) + uncertain lane-block ids
   int2* d_zint = nullptr;            // per lane column: stored-plane range inside the padded frustum
@@ -248,6 +249,14 @@ static void free_all(hsk_ctx* k) {
   for (auto& e : k->ev_icp)
     if (e) (void)hipEventDestroy(e);
   if (k->own_stream && k->stream) (void)hipStreamDestroy(k->stream);
+}
+
+// The weights of deep free space live in the lane-block summaries until somebody reads the volume: bring the volume's
+// copies up to date (k_summaries<true>), once -- a second read-out with no integrate in between finds them current.
+static void flush_weights(hsk_ctx* k) {
+  if (!k->weights_pending) return;
+  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);
+  k->weights_pending = false;
 }
 
 static int upload_state(hsk_ctx* k) {
@@ -493,6 +502,7 @@ static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
 }
 
 static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr) {
+  k->weights_pending = true;
   launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
                    k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue, (fin && fin->slots) ? fin : nullptr,
                    k->d_uni);
@@ -597,6 +607,7 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
       k->graph_ready = true;
     }
     HIPCHK(k, hipGraphLaunch(k->gexec, s));
+    k->weights_pending = true;  // (the replayed graph integrates without passing through enqueue_integrate)
   } else {
     enqueue_tracked_frame(k, false);
   }
@@ -867,6 +878,43 @@ extern "C" int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked) {
   return HSK_OK;
 }
 
+// The recorded-stream frame feed: what the host loop around takeDepthSnapshot (HoniHelper.hs:20-36, Main.hs:1285-1290)
+// becomes when the frames come from a file.  One frame is always in flight ahead of the one being collected, so the
+// file read + the copy into the pinned staging ring + the upload of frame i + 1 run under frame i's GPU work.
+extern "C" int hsk_track_stream(hsk_ctx* k, hsk_depth_stream* s, int first, int count, float* poses_out, int* tracked_out) {
+  if (!k) return HSK_ERR_ARG;
+  if (!s) return fail(k, HSK_ERR_ARG, "stream is null");
+  int w = 0, h = 0, n = 0;
+  if (hsk_stream_info(s, &w, &h, &n, nullptr) != HSK_OK) return fail(k, HSK_ERR_ARG, "not a stream opened for reading");
+  if (w != k->cfg.width || h != k->cfg.height) return fail(k, HSK_ERR_ARG, "the stream's frame size does not match the context");
+  if (first < 0 || count < 0 || first + count > n) return fail(k, HSK_ERR_ARG, "frame range outside the stream");
+  if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
+  uint16_t* buf = (uint16_t*)malloc((size_t)w * h * 2);
+  if (!buf) return fail(k, HSK_ERR_STATE, "out of host memory");
+  int collected = 0, r = HSK_OK;
+  auto collect = [&]() -> int {
+    float pose[16];
+    int tr = 0;
+    const int rc = hsk_wait_frame(k, pose, &tr);
+    if (rc != HSK_OK) return rc;
+    if (poses_out) memcpy(poses_out + (size_t)16 * collected, pose, sizeof(pose));
+    if (tracked_out) tracked_out[collected] = tr;
+    collected += 1;
+    return HSK_OK;
+  };
+  for (int i = 0; i < count && r == HSK_OK; ++i) {
+    if (hsk_stream_read(s, first + i, buf) != HSK_OK) {
+      r = fail(k, HSK_ERR_STATE, "reading a frame from the stream failed");
+      break;
+    }
+    r = hsk_submit_frame(k, buf, w, h);  // copies the frame before it returns
+    if (r == HSK_OK && k->ring_count > 1) r = collect();
+  }
+  while (r == HSK_OK && k->ring_count > 0) r = collect();
+  free(buf);
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // stage-level entry points
 // ------------------------------------------------------------------------------------------------------
@@ -1007,9 +1055,16 @@ extern "C" int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz) {
 extern "C" int hsk_download_tsdf(hsk_ctx* k, int16_t* out) {
   if (!k || !out) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);  // the weights of deep free space live in the summaries until read
+  flush_weights(k);  // the weights of deep free space live in the summaries until read
   HIPCHK(k, hipMemcpyAsync(out, k->d_vol, k->vol_bytes, hipMemcpyDeviceToHost, k->stream));
   HIPCHK(k, hipStreamSynchronize(k->stream));
+  return HSK_OK;
+}
+extern "C" int hsk_flush_weights(hsk_ctx* k) {
+  if (!k) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  flush_weights(k);
+  HIPCHK(k, hipGetLastError());
   return HSK_OK;
 }
 extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
@@ -1072,7 +1127,7 @@ extern "C" int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size
     HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
     HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
   }
-  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);
+  flush_weights(k);
   launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
   unsigned long long total = 0;
   HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
@@ -1101,7 +1156,7 @@ extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles
   }
   TetTable tt;
   hsk_build_tet_table(&tt);
-  launch_materialize(k->stream, k->d_vol, k->vp, k->d_uni);
+  flush_weights(k);
   launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
   unsigned long long total = 0;
   HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
@@ -1247,6 +1302,7 @@ extern "C" int hsk_mgpu_frame_front(hsk_ctx* k, const void* depth_dev, int w, in
     HIPCHK(k, hipGraphInstantiate(&k->sgexec[set], k->sgraph[set], nullptr, nullptr, 0));
   }
   HIPCHK(k, hipGraphLaunch(k->sgexec[set], k->stream));
+  k->weights_pending = true;
   return HSK_OK;
 }
 

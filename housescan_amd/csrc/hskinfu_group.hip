@@ -19,6 +19,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,10 +43,10 @@ struct Rccl {
 // the process-wide RCCL entry points; an error string when the library or a symbol is missing
 Rccl* rccl(std::string* err) {
   static Rccl R;
-  static bool tried = false;
+  static std::once_flag once;
   static std::string why;
-  if (!tried) {
-    tried = true;
+  // (groups are driven from several host threads -- one per room in BASELINE configs[4] -- so the first calls may race)
+  std::call_once(once, [&]() {
     // One RCCL per process, and the one that belongs to the HIP runtime in use: (1) the copy the host names
     // (HSK_RCCL_PATH: the Python mirror sets it to torch's when it shares torch's HIP runtime -- a second copy beside
     // torch's corrupts the heap at exit), (2) a copy the process has loaded already, (3) the system's.
@@ -64,7 +66,7 @@ Rccl* rccl(std::string* err) {
       SYM(GetErrorString)
 #undef SYM
     }
-  }
+  });
   if (!why.empty()) {
     if (err) *err = why;
     return nullptr;
@@ -116,10 +118,21 @@ struct hsk_group {
   std::vector<Dev> devs;
   uint16_t* h_stage = nullptr;  // pinned ring for host frames
   unsigned stage_turn = 0;
-  int in_flight = 0;
-  std::vector<int> fifo_sync;   // per submitted frame: 1 = finished synchronously (first frame of a scan)
-  float sync_pose[16] = {};
-  int sync_tracked = 0;
+  // one entry per submitted frame, oldest first.  ready: the result is already here (the first frame of a (re)started
+  // scan completes at submission; frames that were in flight behind a lost one are collected when the scan restarts);
+  // otherwise hsk_group_wait_frame collects it from the slabs
+  struct Pending {
+    bool ready = false;
+    float pose[16] = {};
+    int tracked = 0;
+  };
+  std::deque<Pending> fifo;
+  int in_flight() const { return (int)fifo.size(); }
+  // A frame could only be enqueued on some slabs / devices (an error in the middle of group_enqueue), or the slabs
+  // disagree: their frame counts differ from here on and, with several ranks, the peers sit in a collective this rank
+  // never joined.  Every later call fails until hsk_group_reset succeeds (single process) or the group is destroyed.
+  bool poisoned = false;
+  std::string poison_why;
   std::string err;
 };
 
@@ -129,6 +142,14 @@ static thread_local std::string g_group_err;
   do {                      \
     (g)->err = (msg);       \
     return (code);          \
+  } while (0)
+#define GPOISONED(g)                                                                                                           \
+  do {                                                                                                                         \
+    if ((g)->poisoned) {                                                                                                       \
+      (g)->err = "the group is poisoned by an earlier failure in the middle of a frame (" + (g)->poison_why +                 \
+                 "): hsk_group_reset or hsk_group_destroy";                                                                   \
+      return HSK_ERR_STATE;                                                                                                    \
+    }                                                                                                                          \
   } while (0)
 #define GHIP(g, call)                                                                                  \
   do {                                                                                                 \
@@ -177,7 +198,10 @@ static int slab_halo(const hsk_config* c) {
 
 static void group_free(hsk_group* g) {
   if (!g) return;
-  Rccl* R = rccl(nullptr);
+  // a group that never built a communicator (single device, no FORCE_RCCL) must not load RCCL at teardown either
+  bool has_comm = false;
+  for (auto& d : g->devs) has_comm = has_comm || d.comm != nullptr;
+  Rccl* R = has_comm ? rccl(nullptr) : nullptr;
   for (auto& s : g->slabs) {
     if (s.k) {
       (void)hipSetDevice(g->devs[s.dev_slot].id);
@@ -401,11 +425,31 @@ static int group_icp_allreduce(hsk_group* g) {
   return HSK_OK;
 }
 
+// the oldest frame the slabs still hold -> e (every slab must report the same pose and verdict)
+static int group_collect(hsk_group* g, hsk_group::Pending& e) {
+  float pose[16], first[16];
+  int tr = 0, tr0 = 0;
+  for (size_t i = 0; i < g->slabs.size(); ++i) {
+    Slab& s = g->slabs[i];
+    GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
+    GSLAB(g, s, hsk_wait_frame(s.k, pose, &tr));
+    if (i == 0) {
+      memcpy(first, pose, sizeof(pose));
+      tr0 = tr;
+    } else if (tr != tr0 || memcmp(first, pose, sizeof(pose)) != 0) {
+      GFAIL(g, HSK_ERR_STATE, "slabs disagree on the pose: the composite is not the same on every slab");
+    }
+  }
+  memcpy(e.pose, first, sizeof(first));
+  e.tracked = tr0;
+  e.ready = true;
+  return HSK_OK;
+}
+
 // enqueue one whole frame on every device: depth upload, frame front of every slab, the two composites; frame end
-// queued (async) or, for the first frame of a scan, taken synchronously.  depth_dev: per device, or null = from host
-static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* const* depth_dev, int w, int h) {
-  if (w != g->cfg.width || h != g->cfg.height) GFAIL(g, HSK_ERR_ARG, "depth frame size does not match the group");
-  if (g->in_flight >= HSK_MAX_IN_FLIGHT) GFAIL(g, HSK_ERR_STATE, "too many frames in flight: call hsk_group_wait_frame first");
+// queued (async) or, for the first frame of a scan, taken synchronously.  depth_dev: per device, or null = from host.
+// *started: set once slab state may have changed (a failure after that leaves the slabs out of step: the caller poisons)
+static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const void* const* depth_dev, int w, int h, bool* started) {
   const size_t P = (size_t)w * h;
   const int P_i = (int)P;
   const uint16_t* src = nullptr;
@@ -417,7 +461,18 @@ static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* c
   }
   const bool restart = hsk_mgpu_restart_pending(g->slabs[0].k) == 1;
   const bool icp_ar = (g->flags & HSK_GROUP_ICP_ALLREDUCE) != 0;
-  if (restart && g->in_flight > 0) GFAIL(g, HSK_ERR_STATE, "a scan (re)starts: collect the frames in flight first");
+  *started = true;
+  if (restart) {
+    // A pipelined frame lost tracking and the caller has seen it (hsk_group_wait_frame reported tracked = 0).  Frames
+    // submitted behind it were dropped on the device; their results are collected now and parked in the FIFO, the
+    // synchronous result of the restart goes in behind them -- as hsk_submit_frame does for a single context.
+    for (auto& e : g->fifo)
+      if (!e.ready) {
+        const int r = group_collect(g, e);
+        if (r != HSK_OK) return r;
+      }
+  }
+  const bool overlap = g->in_flight() > 0 && !restart;
   for (size_t di = 0; di < g->devs.size(); ++di) {
     Dev& d = g->devs[di];
     GHIP(g, hipSetDevice(d.id));
@@ -425,7 +480,6 @@ static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* c
     // (device-visible).  With a frame still in flight the copy + preprocessing go to each slab's second stream
     // (hsk_mgpu_prefetch), beside the work the device's stream is busy with; the frame front then picks them up.
     const void* frame = src ? (const void*)src : depth_dev[di];
-    const bool overlap = g->in_flight > 0 && !restart;
     for (int si : d.slabs) {
       Slab& s = g->slabs[si];
       if (overlap) GSLAB(g, s, hsk_mgpu_prefetch(s.k, frame, w, h));
@@ -437,16 +491,13 @@ static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* c
   }
   if (restart) {
     // first frame of a (re)started scan: integrate + transformed maps only, finished synchronously
-    float pose[16];
-    int tracked = 0;
+    hsk_group::Pending e;
     for (auto& s : g->slabs) {
       GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
-      GSLAB(g, s, hsk_mgpu_frame_end(s.k, nullptr, nullptr, pose, &tracked));
+      GSLAB(g, s, hsk_mgpu_frame_end(s.k, nullptr, nullptr, e.pose, &e.tracked));
     }
-    memcpy(g->sync_pose, pose, sizeof(pose));
-    g->sync_tracked = tracked;
-    g->fifo_sync.push_back(1);
-    g->in_flight += 1;
+    e.ready = true;
+    g->fifo.push_back(e);
     return HSK_OK;
   }
   if (icp_ar) {
@@ -493,9 +544,27 @@ static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* c
     GHIP(g, hipSetDevice(d.id));
     for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_frame_end_async(g->slabs[si].k, d.kmin, d.bsum));
   }
-  g->fifo_sync.push_back(0);
-  g->in_flight += 1;
+  g->fifo.push_back(hsk_group::Pending());  // state is touched only now, after every slab has taken the frame
   return HSK_OK;
+}
+
+static void group_poison(hsk_group* g) {
+  g->poisoned = true;
+  g->poison_why = g->err;
+}
+
+static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* const* depth_dev, int w, int h) {
+  GPOISONED(g);
+  if (w != g->cfg.width || h != g->cfg.height) GFAIL(g, HSK_ERR_ARG, "depth frame size does not match the group");
+  // (the slabs' rings hold the frames not yet collected: ready entries parked in the FIFO do not count against them)
+  int uncollected = 0;
+  for (auto& e : g->fifo) uncollected += e.ready ? 0 : 1;
+  if (uncollected >= HSK_MAX_IN_FLIGHT || g->in_flight() >= 2 * HSK_MAX_IN_FLIGHT)
+    GFAIL(g, HSK_ERR_STATE, "too many frames in flight: call hsk_group_wait_frame first");
+  bool started = false;
+  const int r = group_enqueue_body(g, depth_host, depth_dev, w, h, &started);
+  if (r != HSK_OK && started) group_poison(g);
+  return r;
 }
 
 extern "C" int hsk_group_submit_frame(hsk_group* g, const uint16_t* depth, int w, int h) {
@@ -511,51 +580,44 @@ extern "C" int hsk_group_submit_frame_dev(hsk_group* g, const void* const* depth
 
 extern "C" int hsk_group_wait_frame(hsk_group* g, float pose_out[16], int* tracked) {
   if (!g) return HSK_ERR_ARG;
-  if (g->in_flight == 0) GFAIL(g, HSK_ERR_STATE, "no frame in flight");
-  const int sync = g->fifo_sync.front();
-  g->fifo_sync.erase(g->fifo_sync.begin());
-  g->in_flight -= 1;
-  if (sync) {
-    if (pose_out) memcpy(pose_out, g->sync_pose, sizeof(g->sync_pose));
-    if (tracked) *tracked = g->sync_tracked;
-    return HSK_OK;
-  }
-  float pose[16], first[16];
-  int tr = 0, tr0 = 0;
-  for (size_t i = 0; i < g->slabs.size(); ++i) {
-    Slab& s = g->slabs[i];
-    GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
-    GSLAB(g, s, hsk_wait_frame(s.k, pose, &tr));
-    if (i == 0) {
-      memcpy(first, pose, sizeof(pose));
-      tr0 = tr;
-    } else if (tr != tr0 || memcmp(first, pose, sizeof(pose)) != 0) {
-      GFAIL(g, HSK_ERR_STATE, "slabs disagree on the pose: the composite is not the same on every slab");
+  GPOISONED(g);
+  if (g->fifo.empty()) GFAIL(g, HSK_ERR_STATE, "no frame in flight");
+  hsk_group::Pending& e = g->fifo.front();
+  if (!e.ready) {
+    const int r = group_collect(g, e);
+    if (r != HSK_OK) {  // some slabs have handed the frame over, others not
+      group_poison(g);
+      return r;
     }
   }
-  if (pose_out) memcpy(pose_out, first, sizeof(first));
-  if (tracked) *tracked = tr0;
+  if (pose_out) memcpy(pose_out, e.pose, sizeof(e.pose));
+  if (tracked) *tracked = e.tracked;
+  g->fifo.pop_front();  // only now: every slab has reported
   return HSK_OK;
 }
 
 extern "C" int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked) {
   if (!g || !depth) return HSK_ERR_ARG;
-  if (g->in_flight > 0) GFAIL(g, HSK_ERR_STATE, "frames are in flight: collect them with hsk_group_wait_frame first");
+  GPOISONED(g);
+  if (g->in_flight() > 0) GFAIL(g, HSK_ERR_STATE, "frames are in flight: collect them with hsk_group_wait_frame first");
   int r = group_enqueue(g, depth, nullptr, w, h);
   if (r != HSK_OK) return r;
   return hsk_group_wait_frame(g, pose_out, tracked);
 }
 
+// Drops the frames in flight and starts the scan afresh.  Also the way out of a poisoned single-process group (every
+// slab context is reset, whatever frame it was on); a poisoned multi-rank group stays poisoned -- its peers may sit in a
+// collective -- and can only be destroyed.
 extern "C" int hsk_group_reset(hsk_group* g) {
   if (!g) return HSK_ERR_ARG;
-  while (g->in_flight > 0) {
-    int r = hsk_group_wait_frame(g, nullptr, nullptr);
-    if (r != HSK_OK) return r;
-  }
+  if (g->poisoned && g->use_rccl && g->world > 1) GPOISONED(g);
   for (auto& s : g->slabs) {
     GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
-    GSLAB(g, s, hsk_reset(s.k));
+    GSLAB(g, s, hsk_reset(s.k));  // (collects and drops the slab's frames in flight itself)
   }
+  g->fifo.clear();
+  g->poisoned = false;
+  g->poison_why.clear();
   return HSK_OK;
 }
 

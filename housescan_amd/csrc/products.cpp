@@ -384,6 +384,16 @@ extern "C" int hsk_stream_read(hsk_depth_stream* s, int index, uint16_t* depth) 
   return fread(depth, 2, px, s->f) == px ? HSK_OK : HSK_ERR_STATE;
 }
 
+extern "C" int hsk_stream_info(const hsk_depth_stream* s, int* w, int* h, int* n_frames, float intr[4]) {
+  if (!s) return HSK_ERR_ARG;
+  if (w) *w = (int)s->w;
+  if (h) *h = (int)s->h;
+  if (n_frames) *n_frames = (int)s->n;
+  if (intr)
+    for (int i = 0; i < 4; ++i) intr[i] = s->intr[i];
+  return HSK_OK;
+}
+
 extern "C" int hsk_stream_close(hsk_depth_stream* s) {
   if (!s) return HSK_ERR_ARG;
   int rc = HSK_OK;

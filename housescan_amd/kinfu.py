@@ -104,6 +104,20 @@ class KinfuTracker:
         self._ck(self.lib.hsk_wait_frame(self.h, _fp(pose), C.byref(tracked)))
         return pose.reshape(4, 4), bool(tracked.value)
 
+    def track_stream(self, reader, first=0, count=None):
+        """frames [first, first + count) of a recorded stream (products.DepthStreamReader) through the tracker, the
+        frame feed running inside the library (hsk_track_stream) -> (poses [count, 4, 4], tracked [count] bool)"""
+        if count is None:
+            count = len(reader) - first
+        poses = np.empty((count, 16), np.float32)
+        tracked = np.zeros(count, np.int32)
+        self._ck(self.lib.hsk_track_stream(self.h, reader.h, int(first), int(count), _fp(poses), tracked.ctypes.data_as(C.POINTER(C.c_int))))
+        return poses.reshape(count, 4, 4), tracked.astype(bool)
+
+    def flush_weights(self):
+        """write the deferred free-space weights back into the volume (what a read-out does first); enqueued only"""
+        self._ck(self.lib.hsk_flush_weights(self.h))
+
     def reset(self):
         self._ck(self.lib.hsk_reset(self.h))
 

@@ -103,6 +103,11 @@ int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h, const flo
 
 int hsk_download_tsdf(hsk_ctx* k, int16_t* tsdf_weight_pairs /* 2 * X*Y*stored_planes, x fastest */);
 int hsk_upload_tsdf(hsk_ctx* k, const int16_t* tsdf_weight_pairs);
+/* The weights of deep free space are kept in a side table (one byte per 16 voxels) and written back into the volume
+ * when something is about to read them: hsk_download_tsdf, hsk_extract_cloud and hsk_extract_mesh do it themselves.
+ * This call does only that write-back (enqueued; no host synchronisation) -- it changes nothing any call returns, and
+ * exists so that the deferred work can be timed on its own (bench.py: readout_ms). */
+int hsk_flush_weights(hsk_ctx* k);
 int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz);
 int hsk_get_pose(hsk_ctx* k, float pose[16]);
 int hsk_set_pose(hsk_ctx* k, const float pose[16]);
@@ -168,7 +173,15 @@ int hsk_group_reset(hsk_group* g);
 /* the tracker step of hsk_process_frame, on the sharded volume */
 int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int w, int h, float pose_out[16], int* tracked);
 /* pipelined form (as hsk_submit_frame / hsk_wait_frame): the frame and its collectives are enqueued, the pose collected
- * later, in order, at most HSK_MAX_IN_FLIGHT outstanding; the first frame of a (re)started scan completes at submission */
+ * later, in order, at most HSK_MAX_IN_FLIGHT outstanding; the first frame of a (re)started scan completes at submission.
+ * After a tracking loss the frames already in flight behind the lost one are dropped (tracked = 0); the submission
+ * that follows restarts the scan, its result is handed out behind theirs.
+ * A failure in the MIDDLE of a frame (some slabs or devices have taken it, others not) poisons the group: every later
+ * call returns HSK_ERR_STATE until hsk_group_reset succeeds (single process) or the group is destroyed (several ranks:
+ * the peers may be left in a collective).
+ * STATUS: groups of several slabs on ONE device, with and without RCCL, are tested bit-exact against a single context;
+ * groups over more than one device (ncclCommInitAll / ncclCommInitRank with world > 1) have never run on hardware --
+ * no multi-GPU box was available (tests/test_gpu_multi_device.py runs when one is). */
 int hsk_group_submit_frame(hsk_group* g, const uint16_t* depth, int w, int h);
 /* depth_dev[d]: the frame in the memory of the d-th distinct device of this process (creation order), complete and
  * valid until the frame has been waited for */
@@ -238,6 +251,13 @@ hsk_depth_stream* hsk_stream_open(const char* path, int* w, int* h, int* n_frame
 int hsk_stream_write(hsk_depth_stream* s, const uint16_t* depth);
 int hsk_stream_read(hsk_depth_stream* s, int index, uint16_t* depth);
 int hsk_stream_close(hsk_depth_stream* s);
+int hsk_stream_info(const hsk_depth_stream* s, int* w, int* h, int* n_frames, float intr[4]);
+/* The recorded-stream frame feed (BASELINE configs[2]: "scan from recorded stream"; the loop that replaces
+ * Main.hs:1285-1290 around takeDepthSnapshot, HoniHelper.hs:20-36): frames [first, first + count) of `s` through the
+ * tracker, pipelined -- frame i + 1 is read from the file and uploaded while frame i is on the GPU.  poses_out: 16 floats
+ * per frame (row-major cam->world), tracked_out: one int per frame (either may be NULL).  The context must have no frame
+ * in flight; results are exactly those of hsk_process_frame called with the same frames. */
+int hsk_track_stream(hsk_ctx* k, hsk_depth_stream* s, int first, int count, float* poses_out, int* tracked_out);
 
 #ifdef __cplusplus
 }

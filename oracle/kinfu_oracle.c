@@ -14,8 +14,26 @@
  *   - expression trees are evaluated exactly as parenthesised below.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math [-fopenmp]).
+ *
+ * ORA_LITERAL (libkinfu_oracle_literal.so; oracle/Makefile): the SAME pipeline with this build's deliberate deviations
+ * from Appendix-A-literal arithmetic taken back out -- FMA contraction allowed (-ffp-contract=fast -mfma: what nvcc does
+ * by default), one expf per bilateral tap over the exclusively clipped window with a zero centre filtered like any other
+ * (D1), plain binary64 products and sums in the ICP (no 2^-26 snap, D4), LLT Cholesky with square roots (D4), libm
+ * sinf / cosf for the pose increment, no rejection of extrapolated hit times (D3), "1 / z < 0" as the only in-front test
+ * (D6).  It is the yardstick for the north_star's "within a stated tolerance" (tools/spec_vs_literal.py,
+ * tests/test_spec_vs_literal.py): how far the bit-reproducible specification moves TSDF values and poses from the
+ * PCL-form arithmetic.  Still a recollection of PCL (parity unpinned), still test infrastructure.
  */
 #include "kinfu_oracle.h"
+
+/* ORA_LITERAL = every deviation taken back out; the single switches exist so that tools/spec_vs_literal.py can attribute
+ * the difference to its causes (one variant library per switch, oracle/Makefile: variant) */
+#ifdef ORA_LITERAL
+#define ORA_LIT_D1 1 /* bilateral: one expf per tap, exclusive window clip, zero centre filtered */
+#define ORA_LIT_D3 1 /* raycast: extrapolated hit times accepted */
+#define ORA_LIT_D4 1 /* ICP: plain binary64 sums, LLT Cholesky, libm sinf / cosf */
+#define ORA_LIT_D6 1 /* integrate: "1 / z < 0" as the in-front test */
+#endif
 
 #include <math.h>
 #include <stdlib.h>
@@ -129,8 +147,13 @@ uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], flo
         const float camx = (i00 * gx + i01 * gy) + i02 * gz;
         const float camy = (i10 * gx + i11 * gy) + i12 * gz;
         const float camz = (i20 * gx + i21 * gy) + i22 * gz;
+#ifdef ORA_LIT_D6
+        const float inv_z = 1.0f / camz;
+        if (inv_z < 0.0f) continue; /* A.4: "implemented as 1 / v_z < 0"; z = 0 or NaN falls to the range guard below */
+#else
         if (!(camz >= 1.17549435e-38f)) continue; /* in front of the camera (D6: a denormal depth counts as not in front) */
         const float inv_z = 1.0f / camz;
+#endif
         const float fu = (camx * fx) * inv_z + cx;
         const float fv = (camy * fy) * inv_z + cy;
         int u, v;
@@ -167,6 +190,7 @@ uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], flo
 /* ------------------------------------------------------------------------------------------------ */
 #define BIL_R 6
 #define BIL_LUT 512
+#ifndef ORA_LIT_D1
 static float g_ws[13][13];
 static float g_wc[BIL_LUT];
 static int g_bil_init = 0;
@@ -180,7 +204,40 @@ static void bil_init(void) {
   for (int k = 0; k < BIL_LUT; ++k) g_wc[k] = (float)exp(-(double)((float)(k * k) * c2));
   g_bil_init = 1;
 }
+#endif
 
+#ifdef ORA_LIT_D1
+/* A.3 as written: window [x - 6, min(x + 7, W - 1)) x [y - 6, min(y + 7, H - 1)) (the upper clip is EXCLUSIVE of the last
+ * column / row), one expf of the summed exponent per tap, a zero centre filtered like any other value; an empty or
+ * all-underflowed window (0 / 0) gives 0, as __float2int_rn(NaN) does */
+void ora_bilateral(const uint16_t* src, int W, int H, uint16_t* dst) {
+  const float sig_s = 4.5f, sig_c = 30.0f;
+  const float s2 = 0.5f / (sig_s * sig_s), c2 = 0.5f / (sig_c * sig_c);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int value = src[y * W + x];
+      const int tx = x - BIL_R + 13 < W - 1 ? x - BIL_R + 13 : W - 1;
+      const int ty = y - BIL_R + 13 < H - 1 ? y - BIL_R + 13 : H - 1;
+      float sum1 = 0.0f, sum2 = 0.0f;
+      for (int cy = y - BIL_R < 0 ? 0 : y - BIL_R; cy < ty; ++cy)
+        for (int cx = x - BIL_R < 0 ? 0 : x - BIL_R; cx < tx; ++cx) {
+          const int tmp = src[cy * W + cx];
+          const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+          const float color2 = (float)((value - tmp) * (value - tmp));
+          const float w = expf(-(space2 * s2 + color2 * c2));
+          sum1 += (float)tmp * w;
+          sum2 += w;
+        }
+      int res = sum2 > 0.0f ? (int)lrintf(sum1 / sum2) : 0;
+      if (res < 0) res = 0;
+      if (res > 32767) res = 32767;
+      dst[y * W + x] = (uint16_t)res;
+    }
+}
+#else
 void ora_bilateral(const uint16_t* src, int W, int H, uint16_t* dst) {
   bil_init();
 #ifdef _OPENMP
@@ -212,6 +269,7 @@ void ora_bilateral(const uint16_t* src, int W, int H, uint16_t* dst) {
       dst[y * W + x] = (uint16_t)res;
     }
 }
+#endif
 
 /* A.3 pyrDown: 5x5 window mean of depths within 3*sigma_color of the centre (integer arithmetic) */
 void ora_pyrdown(const uint16_t* src, int W, int H, uint16_t* dst) {
@@ -352,7 +410,11 @@ void ora_resize_nmap(const float* src, int W, int H, float* dst) { resize_map(sr
 /* before summation; every partial sum is then exactly representable while |sum| < 2^27, which makes   */
 /* the 27 sums independent of summation order (CPU loop == GPU tree == multi-GPU all-reduce).          */
 /* ------------------------------------------------------------------------------------------------ */
+#ifdef ORA_LIT_D4
+static inline double quant26(double x) { return x; } /* plain binary64 products (A.5: float_type = double) */
+#else
 static inline double quant26(double x) { return rint(x * 67108864.0) * (1.0 / 67108864.0); }
+#endif
 
 uint64_t ora_icp_accumulate(const float* vcur, const float* ncur, const float* vprev_g, const float* nprev_g,
                             int W, int H, float fx, float fy, float cx, float cy,
@@ -364,8 +426,9 @@ uint64_t ora_icp_accumulate(const float* vcur, const float* ncur, const float* v
   double acc[27];
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   uint64_t n_valid = 0;
-  /* the snapped sums are exact, hence independent of how the rows are split over threads */
-#ifdef _OPENMP
+  /* the snapped sums are exact, hence independent of how the rows are split over threads (the literal form's plain
+   * binary64 sums are not: it adds the pixels in image order on one thread) */
+#if defined(_OPENMP) && !defined(ORA_LIT_D4)
 #pragma omp parallel for reduction(+ : n_valid) reduction(+ : acc[:27]) schedule(static)
 #endif
   for (int y = row0; y < row1; ++y)
@@ -432,6 +495,42 @@ static int solve_lost(float x6[6]) {
   return 0;
 }
 
+#ifdef ORA_LIT_D4
+/* A.2 step (3) as written: A symmetric from the packed triangle, |det A| < 1e-15 or NaN => lost, x = A.llt().solve(b)
+ * (Cholesky A = L L^T with square roots, forward and back substitution), cast to float.  det A = (prod L_ii)^2. */
+int ora_icp_solve(const double in27[27], float x6[6]) {
+  double L[6][6];
+  double det = 1.0;
+  for (int c = 0; c < 6; ++c) {
+    double d = in27[tri_at(c, c)];
+    for (int q = 0; q < c; ++q) d -= L[c][q] * L[c][q];
+    if (!(d > 0.0)) return solve_lost(x6); /* not positive definite: Eigen's LLT would return garbage; det test below would catch most */
+    L[c][c] = sqrt(d);
+    det *= d;
+    for (int r = c + 1; r < 6; ++r) {
+      double a = in27[tri_at(c, r)];
+      for (int q = 0; q < c; ++q) a -= L[r][q] * L[c][q];
+      L[r][c] = a / L[c][c];
+    }
+  }
+  if (!(fabs(det) >= 1e-15)) return solve_lost(x6);
+  double y[6], x[6];
+  for (int r = 0; r < 6; ++r) {
+    double acc = in27[tri_at(r, 6)];
+    for (int q = 0; q < r; ++q) acc -= L[r][q] * y[q];
+    y[r] = acc / L[r][r];
+  }
+  for (int r = 5; r >= 0; --r) {
+    double acc = y[r];
+    for (int q = r + 1; q < 6; ++q) acc -= L[q][r] * x[q];
+    x[r] = acc / L[r][r];
+  }
+  for (int q = 0; q < 6; ++q)
+    if (isnan(x[q]) || !(fabs(x[q]) < 1e30)) return solve_lost(x6);
+  for (int q = 0; q < 6; ++q) x6[q] = (float)x[q];
+  return 1;
+}
+#else
 int ora_icp_solve(const double in27[27], float x6[6]) {
   double low[6][6]; /* strictly lower part of L; only [r][c] with c < r is ever read */
   double piv[6], rpiv[6];
@@ -466,6 +565,7 @@ int ora_icp_solve(const double in27[27], float x6[6]) {
   for (int q = 0; q < 6; ++q) x6[q] = (float)x[q];
   return 1;
 }
+#endif
 
 /* sin and cos of the ICP increment, bit-reproducible on every machine: Cody-Waite reduction by pi/2 in two pieces
  * (k = rint(x 2/pi), r = (x - k hi) - k lo), then the Taylor polynomials to r^15 / r^16 in Horner form, binary64:
@@ -512,10 +612,15 @@ static void mul33(const float A[9], const float B[9], float C[9]) {
 void ora_pose_update(float R[9], float t[3], const float x6[6]) {
   float sn[3], cs[3];
   for (int a = 0; a < 3; ++a) {
+#ifdef ORA_LIT_D4
+    sn[a] = sinf(x6[a]); /* Eigen's AngleAxisf: the C library's single-precision sine and cosine */
+    cs[a] = cosf(x6[a]);
+#else
     double sd, cd;
     ora_sincos((double)x6[a], &sd, &cd);
     sn[a] = (float)sd;
     cs[a] = (float)cd;
+#endif
   }
   const float about_x[9] = {1.0f, 0.0f, 0.0f, 0.0f, cs[0], -sn[0], 0.0f, sn[0], cs[0]};
   const float about_y[9] = {cs[1], 0.0f, sn[1], 0.0f, 1.0f, 0.0f, -sn[1], 0.0f, cs[1]};
@@ -651,7 +756,11 @@ void ora_raycast(const int16_t* vol, const int dims[3], const float size[3], flo
               const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
               /* deviation from A.6: reject an interpolated time outside
                * [t - step/2, t + 3 step/2]; bounds the taps to the slab halo. */
+#ifdef ORA_LIT_D3
+              if (!isnan(Ts)) { /* A.6 as written: whatever the interpolation gives (also an extrapolated time) */
+#else
               if (Ts >= time_curr - 0.5f * time_step && Ts <= time_curr + 1.5f * time_step) {
+#endif
                 const float vtx[3] = {t[0] + dir[0] * Ts, t[1] + dir[1] * Ts, t[2] + dir[2] * Ts};
                 vmap[i] = vtx[0];
                 vmap[P + i] = vtx[1];

@@ -42,14 +42,32 @@ def build_native():
     return path if os.path.exists(path) else None
 
 
+def build_literal():
+    """the Appendix-A-literal form (kinfu_oracle.c built with -DORA_LITERAL and FMA contraction allowed): the yardstick of
+    tools/spec_vs_literal.py; built on the machine that runs it"""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "literal"])
+    return os.path.join(_HERE, "_native", "libkinfu_oracle_literal.so")
+
+
+def build_variant(name, defs="", contract="off"):
+    """one deviation of the literal form at a time (tools/spec_vs_literal.py --attribute); load with lib("var:" + name)"""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "variant", "NAME=" + name, "DEFS=" + defs, "CONTRACT=" + contract])
+
+
 def lib(omp=False):
     name = "libkinfu_oracle_omp.so" if omp else "libkinfu_oracle.so"
+    if isinstance(omp, str) and omp.startswith("var:"):
+        name = "_native/libkinfu_oracle_var_%s.so" % omp[4:]
     if omp == "native":
         name = "_native/libkinfu_oracle_native.so"
+    if omp == "literal":
+        name = "_native/libkinfu_oracle_literal.so"
     if name in _libs:
         return _libs[name]
     path = os.path.join(_HERE, name)
-    if not os.path.exists(path):
+    if omp == "literal":
+        build_literal()   # (make: rebuilt when kinfu_oracle.c changed)
+    elif not os.path.exists(path):
         if omp == "native":
             if build_native() is None:
                 return lib(True)
@@ -123,10 +141,10 @@ def integrate(cfg, vol, scaled, pose, zs0=0, omp=False):
                                       cfg.W, cfg.H, *_intr(cfg), _f(R), _f(t)))
 
 
-def bilateral(cfg, depth):
+def bilateral(cfg, depth, omp=False):
     d = np.ascontiguousarray(depth, np.uint16)
     out = np.empty_like(d)
-    lib().ora_bilateral(_p(d), d.shape[1], d.shape[0], _p(out))
+    lib(omp).ora_bilateral(_p(d), d.shape[1], d.shape[0], _p(out))
     return out
 
 
@@ -169,30 +187,30 @@ def resize_nmap(nm):
     return out
 
 
-def icp_accumulate(cfg, level, vcur, ncur, vprev, nprev, pose, pose_prev, row0=0, row1=None):
+def icp_accumulate(cfg, level, vcur, ncur, vprev, nprev, pose, pose_prev, row0=0, row1=None, omp=False):
     R, t = _rt(pose)
     Rp, tp = _rt(pose_prev)
     H, W = vcur.shape[1], vcur.shape[2]
     if row1 is None:
         row1 = H
     out = np.empty(27, np.float64)
-    n = lib().ora_icp_accumulate(_f(vcur), _f(ncur), _f(vprev), _f(nprev), W, H, *_intr(cfg, level), _f(R), _f(t), _f(Rp),
+    n = lib(omp).ora_icp_accumulate(_f(vcur), _f(ncur), _f(vprev), _f(nprev), W, H, *_intr(cfg, level), _f(R), _f(t), _f(Rp),
                                  _f(tp), C.c_float(cfg.dist_thresh), C.c_float(cfg.angle_thresh), row0, row1,
                                  out.ctypes.data_as(C.POINTER(C.c_double)))
     return out, int(n)
 
 
-def icp_solve(sums27):
+def icp_solve(sums27, omp=False):
     s = np.ascontiguousarray(sums27, np.float64)
     x = np.empty(6, np.float32)
-    ok = lib().ora_icp_solve(s.ctypes.data_as(C.POINTER(C.c_double)), _f(x))
+    ok = lib(omp).ora_icp_solve(s.ctypes.data_as(C.POINTER(C.c_double)), _f(x))
     return x, bool(ok)
 
 
-def pose_update(pose, x6):
+def pose_update(pose, x6, omp=False):
     R, t = _rt(pose)
     x = np.ascontiguousarray(x6, np.float32)
-    lib().ora_pose_update(_f(R), _f(t), _f(x))
+    lib(omp).ora_pose_update(_f(R), _f(t), _f(x))
     out = np.eye(4, dtype=np.float32)
     out[:3, :3] = R.reshape(3, 3)
     out[:3, 3] = t

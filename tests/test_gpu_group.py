@@ -85,6 +85,47 @@ def test_group_rank_form_and_tracking_loss(hsk, synth_frames):
     ref.close()
 
 
+@pytest.mark.parametrize("slabs,flags", [(2, 0), (3, 1)])
+def test_group_pipelined_loss_restarts_behind_the_frames_in_flight(hsk, synth_frames, slabs, flags):
+    """a frame that loses tracking in the MIDDLE of a pipelined stream (one frame always submitted ahead): the frame in
+    flight behind it is dropped on the device, the next submission restarts the scan and parks its synchronous result
+    behind it -- the same sequence of poses and verdicts as hsk_submit_frame / hsk_wait_frame on one context, the same
+    volume, and the stream tracks on afterwards"""
+    n = 64
+    zero = np.zeros_like(synth_frames(0)[1])
+    seq = [synth_frames(k)[1] for k in range(4)] + [zero] + [synth_frames(k)[1] for k in range(4, 11)]
+
+    def pipelined(t):
+        res = []
+        t.submit_frame(seq[0])
+        for d in seq[1:]:
+            t.submit_frame(d)
+            res.append(t.wait_frame())
+        res.append(t.wait_frame())
+        return res
+
+    ref = hsk.KinfuTracker(n=n)
+    want = pipelined(ref)
+    grp = hsk.KinfuGroup(hsk.default_config(n), device_ids=[0] * slabs, flags=flags)
+    got = pipelined(grp)
+    verdicts = [ok for _, ok in want]
+    assert verdicts[:4] == [False, True, True, True] and verdicts[4:7] == [False, False, False] and all(verdicts[7:]), verdicts
+    for i, ((p, ok), (pr, okr)) in enumerate(zip(got, want)):
+        assert ok == okr, i
+        assert_same_bits(p, pr, f"pipelined group pose step {i} around a lost frame ({slabs} slabs, flags {flags})")
+    assert_same_bits(grp.download_tsdf(), ref.download_tsdf(), "group tsdf after a pipelined loss and restart")
+    # an error in the middle of a call (here: a frame of the wrong size is refused BEFORE anything is enqueued) leaves the
+    # group usable; too many submissions are refused without side effects as well
+    with pytest.raises(hsk.KinfuError, match="size"):
+        grp.submit_frame(np.zeros((10, 10), np.uint16))
+    p, ok = grp.process_frame(synth_frames(11)[1])
+    pr, okr = ref.process_frame(synth_frames(11)[1])
+    assert ok == okr
+    assert_same_bits(p, pr, "group pose after a refused submission")
+    grp.close()
+    ref.close()
+
+
 def test_c_harness_drives_the_library_without_python(hsk, synth_frames, tmp_path):
     """tests/abi_harness.c: a C program linked against libhskinfu (no Python, no torch in that process) runs 4 frames
     through one context and through a two-slab group; its poses equal the ones this process gets"""
