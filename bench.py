@@ -127,46 +127,72 @@ def raycast_algorithmic_bytes(volume, trk, pose):
 # ---------------------------------------------------------------------------------------------------------------------
 # HBM traffic of the integrate stage from PMC counters, collected by child processes of this run
 # ---------------------------------------------------------------------------------------------------------------------
-def pmc_traffic(volume, total, window_first, timeout_s=150):
-    """FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes: they do not fit one) over a replay of the same frames by
-    tools/replay_frames.py; mean over the integrate launches of the timed window.  gfx950: FETCH_SIZE counts 64 B per
-    128-B request on wide streams, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.  KiB units."""
+def pmc_counters(volume, total, passes, timeout_s=240):
+    """rocprofv3 --pmc passes (one child run of tools/replay_frames.py each, over the same frames as the timed region);
+    returns {kernel name: {counter: [value per launch]}} or (None, reason)"""
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
     per = {}
     tmp = tempfile.mkdtemp(prefix="hsk_pmc_")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "tools", "replay_frames.py"), str(volume), str(total)]
+        for i, ctrs in enumerate(passes):
+            out = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", out, "--", sys.executable,
+                                                   os.path.join(ROOT, "tools", "replay_frames.py"), str(volume), str(total)]
             try:
                 subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=timeout_s, check=True)
             except (subprocess.SubprocessError, OSError) as e:
-                return None, f"rocprofv3 --pmc {ctr} failed: {type(e).__name__}"
+                return None, f"rocprofv3 --pmc {ctrs} failed: {type(e).__name__}"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                return None, f"rocprofv3 --pmc {ctr} wrote no counter file"
-            rows = {}
+                return None, f"rocprofv3 --pmc {ctrs} wrote no counter file"
             for r in csv.DictReader(open(files[0])):
-                name = r["Kernel_Name"]
-                if name.startswith("void k_integrate<false") or name.startswith("void k_integrate_detail2<false") or \
-                        name.startswith("k_column_zrange"):
-                    rows.setdefault(name.split("(")[0], []).append(float(r["Counter_Value"]))
-            per[ctr] = rows
-        kib = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
-        for ctr, rows in per.items():
-            for name, vals in rows.items():
-                win = vals[window_first:total]   # one launch per frame, frame 0 included: index = frame number
-                kib[ctr] += float(np.mean(win)) if win else 0.0
-        fetch, write = kib["FETCH_SIZE"] * 1024 * 2, kib["WRITE_SIZE"] * 1024
-        return int(fetch + write), {"fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
-                                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of tools/replay_frames.py over the "
-                                              "same frames as the timed region; mean per frame of the three integrate kernels"}
+                name = r["Kernel_Name"].split("(")[0]
+                per.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        return per, None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false>", "void k_integrate_detail2<false>")
+
+
+def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
+    """HBM-side bytes of the integrate stage per frame: FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes: they do not
+    fit one), mean over the launches of the timed window.  gfx950: FETCH_SIZE counts 64 B per 128-B request on wide
+    streams, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.  KiB units.  Also returns the
+    raycast's counters (its 4-B gathers are an access width the guide calls uncalibrated: raw and doubled both given)."""
+    passes = ["FETCH_SIZE", "WRITE_SIZE"] + (["TCC_HIT_sum TCC_MISS_sum"] if with_raycast else [])
+    per, why = pmc_counters(volume, total, passes, timeout_s)
+    if per is None:
+        return None, why, None
+
+    def mean(kernel, ctr, first, last):
+        vals = per.get(kernel, {}).get(ctr, [])[first:last]
+        return float(np.mean(vals)) if vals else 0.0
+    # one launch of each integrate kernel per frame, frame 0 included: index = frame number
+    kernels = {}
+    fetch = write = 0.0
+    for name in INTEGRATE_KERNELS:
+        f = mean(name, "FETCH_SIZE", window_first, total) * 1024 * 2
+        w = mean(name, "WRITE_SIZE", window_first, total) * 1024
+        kernels[name.replace("void ", "")] = {"fetch_bytes_corrected_x2": int(f), "write_bytes": int(w)}
+        fetch += f
+        write += w
+    info = {"fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write), "per_kernel": kernels,
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, child runs of tools/replay_frames.py over the same frames as the "
+                      "timed region; mean per frame of the three integrate kernels"}
+    ray = None
+    if with_raycast:   # the raycast runs from frame 1 on: launch index = frame - 1
+        rk = "void k_raycast<false>"
+        fr = mean(rk, "FETCH_SIZE", window_first - 1, total - 1) * 1024
+        hit, miss = mean(rk, "TCC_HIT_sum", window_first - 1, total - 1), mean(rk, "TCC_MISS_sum", window_first - 1, total - 1)
+        ray = {"fetch_bytes_raw": int(fr), "fetch_bytes_x2": int(2 * fr), "write_bytes": int(mean(rk, "WRITE_SIZE", window_first - 1, total - 1) * 1024),
+               "l2_requests_hit": int(hit), "l2_requests_miss": int(miss), "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None,
+               "note": "FETCH_SIZE of 4-B gathers is uncalibrated on gfx950 (exactly half on 16-B/lane streams): the true figure lies between raw and x2"}
+    return int(fetch + write), info, ray
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -319,15 +345,22 @@ def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
         "bound": "hbm",
         "kernel": "integrate stage: k_column_zrange + k_integrate<false> (pass A) + k_integrate_detail2<false> (pass B), one event pair",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
+        "traffic": traffic, "hbm_GBps": None if traffic is None else round(traffic / t_int / 1e9, 1),
+        "hbm_frac": None if traffic is None else round(traffic / t_int / 1e9 / HBM_PEAK_GBS, 4),
+        "frac_note": "achieved / frac: ALGORITHMIC bytes (SURVEY.md 8(d): 8 B x V_upd + 2 B x W x H) over the stage's time -- an effective rate: the "
+                     "lane-block summaries record deep-free-space weight updates in one byte per 16 voxels instead of moving the voxels, so the "
+                     "bytes that really cross the memory side are `traffic`, and hbm_GBps / hbm_frac = traffic over the same time",
+        "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
         "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
         "window": "the frames of the timed region, replayed with HIP events between the stages (non-pipelined replay: preprocessing on the "
                   "main stream, the frame's last ICP solve in a launch of its own)",
         "sweep_GBps_upper_bound_bytes_not_algorithmic": round(8.0 * n ** 3 / t_int / 1e9, 1),
-        "cache_note": ("%d^3 x 4 B = %d MiB volume, of which a frame rewrites %.0f MiB; the Infinity Cache holds 256 MiB, so part of the "
-                       "touched set stays MALL-resident from frame to frame: partly cache-resident, not a pure HBM measurement "
-                       "(roofline_1024 is)" % (n, n ** 3 * 4 >> 20, touched_mib)) if n ** 3 * 4 <= (1 << 30) else
-                      ("%d^3 x 4 B = %d MiB volume, a frame rewrites %.0f MiB: far beyond the 256 MiB Infinity Cache => HBM measurement"
+        "cache_note": ("%d^3 x 4 B = %d MiB volume; the update rule rewrites %.0f MiB of it per frame, of which the kernels move only the part "
+                       "near surfaces through memory (traffic); the Infinity Cache holds 256 MiB, so part of that stays MALL-resident from "
+                       "frame to frame: not a pure HBM measurement (roofline_1024's working set is)" % (n, n ** 3 * 4 >> 20, touched_mib))
+                      if n ** 3 * 4 <= (1 << 30) else
+                      ("%d^3 x 4 B = %d MiB volume; the update rule rewrites %.0f MiB of it per frame (algorithmic), the kernels move `traffic` "
+                       "bytes of it through memory: both far beyond the 256 MiB Infinity Cache, so traffic / time is an HBM rate"
                        % (n, n ** 3 * 4 >> 20, touched_mib)),
     }
     if traffic_info is not None:
@@ -361,9 +394,9 @@ def run_single(args, hsk, torch, local_rank):
     }
     # ---- stage times + roofline of the dominant kernel group (integrate) ----
     rep, ms, nf, icp_ms, v_mean, _ = replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, pose)
-    traffic, tinfo = (None, "skipped (--no-traffic)")
+    traffic, tinfo, ray_pmc = (None, "skipped (--no-traffic)", None)
     if not args.no_traffic:
-        traffic, tinfo = pmc_traffic(n, total, 1 + Wm)
+        traffic, tinfo, ray_pmc = pmc_traffic(n, total, 1 + Wm)
     out["roofline"] = roofline_block(n, ms, nf, v_mean, traffic, tinfo if isinstance(tinfo, dict) else None)
     if traffic is None:
         out["roofline"]["traffic_note"] = str(tinfo)
@@ -376,6 +409,8 @@ def run_single(args, hsk, torch, local_rank):
                               "note": "latency-bound (19 dependent launches): microseconds per iteration, not a roofline fraction"}
     t_ray = ms[3] / nf * 1e-3
     out["raycast"] = {"rays_per_s": round(W * H / t_ray, 0), "us": round(t_ray * 1e6, 1)}
+    if ray_pmc is not None:
+        out["raycast"]["traffic"] = ray_pmc
     if not args.no_cpu_baseline:
         b_ray, n_steps, hits = raycast_algorithmic_bytes(n, rep, rep.get_pose())
         out["raycast"].update({"algorithmic_bytes": b_ray, "GBps": round(b_ray / t_ray / 1e9, 1), "march_steps_oracle": n_steps, "hit_rays": hits,
@@ -420,8 +455,10 @@ def run_single(args, hsk, torch, local_rank):
         trk2.close()
         rep2, ms2, nf2, _, v2, _ = replay_with_events(hsk, 1024, K2, W2, frames[:tot2], dev_frames[:tot2], local_rank, pose2)
         rep2.close()
-        blk = roofline_block(1024, ms2, nf2, v2, None, None)
-        blk["traffic_note"] = "not collected for this block"
+        tr2, ti2, _ = (None, "skipped (--no-traffic)", None) if args.no_traffic else pmc_traffic(1024, tot2, 1 + W2, with_raycast=False)
+        blk = roofline_block(1024, ms2, nf2, v2, tr2, ti2 if isinstance(ti2, dict) else None)
+        if tr2 is None:
+            blk["traffic_note"] = str(ti2)
         blk.update({"frames_per_s": round(K2 / el2, 2), "steps": K2, "warmup": W2, "lost_frames": int(lost2),
                     "stage_us": {"preprocess": round(ms2[0] / nf2 * 1e3, 1), "icp": round(ms2[1] / nf2 * 1e3, 1),
                                  "integrate": round(ms2[2] / nf2 * 1e3, 1), "raycast": round(ms2[3] / nf2 * 1e3, 1)}})

@@ -1195,6 +1195,22 @@ extern "C" int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_
   }
   return HSK_OK;
 }
+// lane-blocks (4 x 1 x 4 voxels) the last integrate's classification pass handed to its per-voxel pass
+extern "C" int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries) {
+  if (!k || !n_entries) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const size_t words = 256 * 64;  // HSK_NQUEUES counters, one per 256-B line (kernels_volume.hip)
+  unsigned* h = (unsigned*)malloc(words * 4);
+  if (!h) return fail(k, HSK_ERR_STATE, "out of host memory");
+  hipError_t e = hipMemcpyAsync(h, k->d_queue, words * 4, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  uint64_t n = 0;
+  for (size_t q = 0; q < 256; ++q) n += h[q * 64];
+  free(h);
+  HIPCHK(k, e);
+  *n_entries = n;
+  return HSK_OK;
+}
 extern "C" int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]) {
   if (!k || !sum_ms) return HSK_ERR_ARG;
   for (int i = 0; i < HSK_NLEVELS; ++i) sum_ms[i] = k->icp_level_ms[i];

@@ -134,6 +134,12 @@ class KinfuTracker:
         self._ck(self.lib.hsk_count_updates(self.h, d.ctypes.data, d.shape[1], d.shape[0], _fp(p), C.byref(n)))
         return n.value
 
+    def integrate_queue_entries(self):
+        """lane-blocks the last integrate's classification pass handed to its per-voxel pass"""
+        n = C.c_uint64()
+        self._ck(self.lib.hsk_integrate_queue_entries(self.h, C.byref(n)))
+        return n.value
+
     def raycast(self, pose, want_keys=False):
         p = np.ascontiguousarray(pose, np.float32).reshape(16)
         v = np.empty((3, self.hgt, self.w), np.float32)

@@ -206,6 +206,9 @@ int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int
 /* while profiling at level 2: time of the ICP iterations of each pyramid level, summed over the same frames as hsk_stage_ms (read it
  * before resetting that); index = level, 0 = finest.  Divide by frames x icp_iters[level] for the time of an iteration. */
 int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]);
+/* lane-blocks (4 x 1 x 4 voxels) the last integrate's classification pass could not settle and handed to its per-voxel
+ * pass (a measure of the classification's slack: bench.py reports it beside V_upd); synchronises the context's stream */
+int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries);
 int hsk_bilateral_tables(float ws[169], float wc[512]);
 /* Exhaustive self-test, on the GPU itself, of the exact-arithmetic shortcuts the kernels use for the specification's
  * correctly rounded 1/x, sqrt(x) and a/n (hardware approximation + one fused correction step; hsk_dev.h): every binary32

@@ -8,6 +8,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cores():
+    """the cores this process may really use: its affinity mask cut down to the container's CPU quota (cgroup cpu.max).
+    The GPU boxes show 256 CPUs behind a 16-core quota: the OpenMP oracle on 256 threads burns the quota on spinning
+    barriers and everything in the container -- single-threaded code too -- is throttled (a 3-minute suite took 19)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# before libgomp is loaded by the oracle's OpenMP build
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cores()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
