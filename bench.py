@@ -313,12 +313,14 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
     rep_poses = {}
     sample = list(range(1 + Wm, total, max(1, K // 10)))
     p = None
+    entries = []
     for i in range(total):
         if i == 1 + Wm:
             rep.stage_ms(reset=True)  # warm-up frames are not part of the timed region
         p, _ = rep.process_frame_dev(dev_frames[i].data_ptr())
         if i in sample:
             rep_poses[i] = p.copy()
+            entries.append(rep.integrate_queue_entries())   # lane-blocks pass A handed to pass B in this frame
     ms, nf = rep.stage_ms(reset=True)
     rep.set_profiling(False)
     if final_pose is not None:
@@ -333,6 +335,7 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
     _, nf2 = rep.stage_ms(reset=True)
     rep.set_profiling(False)
     icp_ms = [v * nf / max(1, nf2) for v in icp_sum]   # scaled to the nf frames the caller divides by
+    replay_with_events.queue_entries = float(np.mean(entries)) if entries else None
     return rep, ms, nf, icp_ms, float(np.mean(vupd)), p
 
 
@@ -351,6 +354,7 @@ def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
                      "lane-block summaries record deep-free-space weight updates in one byte per 16 voxels instead of moving the voxels, so the "
                      "bytes that really cross the memory side are `traffic`, and hbm_GBps / hbm_frac = traffic over the same time",
         "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
+        "pass_b_queue_entries_mean": None if getattr(replay_with_events, "queue_entries", None) is None else int(replay_with_events.queue_entries),
         "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
         "window": "the frames of the timed region, replayed with HIP events between the stages (non-pipelined replay: preprocessing on the "
                   "main stream, the frame's last ICP solve in a launch of its own)",
