@@ -506,14 +506,16 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
             first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
         else:
             flags = hsk.GROUP_ICP_ALLREDUCE if args.icp == "allreduce" else 0
+            if args.exchange == "direct" and args.icp != "allreduce":   # (the all-reduced ICP exists in the RCCL form only)
+                flags |= hsk.GROUP_DIRECT | hsk.GROUP_PROFILE
             if mode == "pairs":
                 # BASELINE configs[4]: one room per PAIR of GPUs -- a two-slab group with its own two-rank communicator
                 pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
-                ids = [hsk.KinfuGroup.unique_id() if rank % 2 == 0 else None]
+                ids = [os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id() if rank % 2 == 0 else None]
                 dist.broadcast_object_list(ids, src=2 * room, group=pgs[room])
                 trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank % 2, world=2, comm_id=ids[0], flags=flags)
             else:
-                ids = [hsk.KinfuGroup.unique_id() if rank == 0 else None]
+                ids = [(os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
             submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
@@ -535,11 +537,20 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
         lost += (not ok)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        prof = None
+        if mode != "rooms" and (flags & hsk.GROUP_PROFILE):
+            ms, front, cnt = trk.exchange_ms()
+            if cnt:
+                prof = {"exchange_us": round(1e3 * ms / cnt, 1), "slab_work_us": round(1e3 * front / cnt, 1), "frames": int(cnt),
+                        "note": "rank 0's device, HIP events: slab work = ICP + integrate + slab-local raycast of a frame; exchange = key push, "
+                                "MIN, winners' push and the waits for the peers (one-hop peer writes + stream wait / write-value flags)"}
+        timed.profile = prof
         trk.close()
         del dev_frames, dev_all
         return elapsed, lost, pose, poses_gt[total - 1], (world if mode == "rooms" else (world // 2 if mode == "pairs" else 1))
 
     elapsed, lost, pose, gt, rooms = timed(args.mode)
+    stage_prof = getattr(timed, "profile", None)
     out = {
         "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
         "value": round(rooms * K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -552,11 +563,16 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
                    "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
                    "parallelism": ("slab%d-icp-%s" % (world, args.icp)) if args.mode == "slab" else
                                   ("rooms%d" % world if args.mode == "rooms" else "pairs%d-icp-%s" % (rooms, args.icp)),
+                   "exchange": None if args.mode == "rooms" else
+                               ("direct: one-hop peer writes + stream wait / write-value flags (HSK_GROUP_DIRECT, no RCCL)"
+                                if args.exchange == "direct" and args.icp != "allreduce" else "RCCL: all-reduce(MIN) of the keys, all-reduce(SUM) of the winners' bits"),
                    "api": "hsk_submit_frame_dev / hsk_wait_frame" if args.mode == "rooms" else
-                          "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI; RCCL inside the library), 1 frame in flight ahead"},
+                          "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI), 1 frame in flight ahead"},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
                      "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
     }
+    if stage_prof:
+        out["stage_us"] = stage_prof
     if args.mode == "slab" and not args.no_rooms:
         # the same GPUs on the path's other partition (BASELINE configs[4]-shaped): an independent room per GPU, no
         # data-path collective -- weak scaling, next to the strong-scaling slab figure above
@@ -655,10 +671,13 @@ def main():
     ap.add_argument("--mode", choices=["slab", "rooms", "pairs"], default="slab",
                     help="N > 1: z-slabs of ONE volume (strong scaling), one room per GPU, or one room per GPU pair (configs[4])")
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
+    ap.add_argument("--exchange", choices=["direct", "rccl"], default="direct",
+                    help="N > 1 slabs, group engine: the per-frame composites as one-hop peer writes (default) or as two RCCL all-reduces")
     ap.add_argument("--engine", choices=["group", "torch"], default="group",
                     help="N > 1 slabs: hsk_group_* (C ABI, RCCL inside the library) or the Python harness over torch.distributed")
     ap.add_argument("--backend", default="nccl", help="--engine torch: torch.distributed backend (nccl = RCCL; gloo for the check below)")
-    ap.add_argument("--share-gpu", action="store_true", help="--engine torch: all ranks on device 0 (logic check on a one-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks on device 0 (logic check on a one-GPU box): --engine torch over gloo, or the group engine with --exchange direct")
     ap.add_argument("--allow-exp", action="store_true",
                     help="measure a library built with other than the default flags or from other sources (the A/B scripts under tools/); "
                          "the line then carries \"experimental_build\": true and is not a result")

@@ -80,6 +80,7 @@ SYMBOLS = {
     "hsk_mgpu_integrate": (C.c_int, [_P]),
     "hsk_mgpu_raycast_local": (C.c_int, [_P, _P]),
     "hsk_mgpu_raycast_resolve": (C.c_int, [_P, _P, _P]),
+    "hsk_mgpu_raycast_push": (C.c_int, [_P, _P, C.POINTER(_P), C.c_int]),
     "hsk_mgpu_frame_end": (C.c_int, [_P, _P, _P, _F, _I]),
     "hsk_mgpu_frame_index": (C.c_int, [_P]),
     "hsk_mgpu_frame_end_async": (C.c_int, [_P, _P, _P]),
@@ -103,6 +104,7 @@ SYMBOLS = {
     "hsk_group_submit_frame": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "hsk_group_submit_frame_dev": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     "hsk_group_wait_frame": (C.c_int, [_P, _F, _I]),
+    "hsk_group_exchange_ms": (C.c_int, [_P, _D, _D, C.POINTER(C.c_ulonglong)]),
     "hsk_group_n_slabs": (C.c_int, [_P]),
     "hsk_group_slab": (_P, [_P, C.c_int]),
     "hsk_group_download_tsdf": (C.c_int, [_P, _P]),

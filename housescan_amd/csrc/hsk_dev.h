@@ -91,6 +91,13 @@ struct RingOut {
   unsigned* seq;
 };
 
+// destinations of a direct (peer-write) exchange: one buffer per device of the group
+#define HSK_PUSH_MAX 16
+struct PushDests {
+  int* p[HSK_PUSH_MAX];
+  int n;
+};
+
 #define HSK_NANF (__builtin_nanf(""))
 
 static __device__ __forceinline__ bool hsk_isnan(float x) { return x != x; }

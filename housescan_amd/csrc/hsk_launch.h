@@ -22,6 +22,8 @@ bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H);
 void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                     int* bits, int P);
 void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vmap, float* nmap, int P);
+void launch_resolve_push(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
+                         const PushDests& dst, int P);
 void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,
                     unsigned long long* row_offset, unsigned long long* total, float* xyz, unsigned long long cap,
                     int pass);

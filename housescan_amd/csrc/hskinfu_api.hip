@@ -1371,6 +1371,17 @@ extern "C" int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, vo
   return HSK_OK;
 }
 
+// direct exchange: this slab's winning pixels straight into every device's composite buffer (dest_bits[d]: int32[6 P],
+// device-accessible from this context's device -- local, peer-enabled or IPC-mapped memory)
+extern "C" int hsk_mgpu_raycast_push(hsk_ctx* k, const void* keys_min_dev, void* const* dest_bits, int n_dest) {
+  if (!k || !keys_min_dev || !dest_bits || n_dest < 1 || n_dest > HSK_PUSH_MAX) return HSK_ERR_ARG;
+  PushDests d;
+  d.n = n_dest;
+  for (int i = 0; i < HSK_PUSH_MAX; ++i) d.p[i] = i < n_dest ? (int*)dest_bits[i] : nullptr;
+  launch_resolve_push(k->stream, k->d_keys, (const int*)keys_min_dev, k->d_vmod[0], k->d_nmod[0], d, k->lv[0].W * k->lv[0].H);
+  return HSK_OK;
+}
+
 // 1 when the next frame starts (or restarts) the scan: frame 0, or tracking was lost by a pipelined frame.  Such a frame
 // has no ICP and no composite: hsk_mgpu_frame_begin / hsk_mgpu_frame_front, then the synchronous hsk_mgpu_frame_end.
 extern "C" int hsk_mgpu_restart_pending(const hsk_ctx* k) { return k ? (k->frame == 0 || k->pending_reset) : -1; }

@@ -13,6 +13,10 @@
 // needs none.  One stream per device carries its slabs' kernels and its collectives, so stream order is the only
 // synchronisation on the frame path.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -87,6 +91,38 @@ __global__ void k_add_into_f64(double* __restrict__ acc, const double* __restric
   if (i < n) acc[i] = acc[i] + x[i];  // exact: the ICP products are multiples of 2^-26
 }
 
+// direct exchange, step 1: a slab's step keys into its slot of every device's gather buffer (peer-mapped memory)
+#define HSK_GROUP_MAX_DEV 16
+#define HSK_PUSH_MAX_HOST 16  // hsk_mgpu_raycast_push takes at most this many destinations (hsk_dev.h: HSK_PUSH_MAX)
+struct KeyDests {
+  int* p[HSK_GROUP_MAX_DEV];
+  int n;
+};
+__global__ void k_push_keys(const int* __restrict__ keys, KeyDests dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = keys[i];
+  for (int d = 0; d < dst.n; ++d) dst.p[d][i] = v;
+}
+// ... step 2: MIN over the slots of all slabs (this device's copy of the gather buffer)
+__global__ void k_min_slots(const int* __restrict__ slots, int n_slots, int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int m = slots[i];
+  for (int s = 1; s < n_slots; ++s) m = min(m, slots[(size_t)s * n + i]);
+  out[i] = m;
+}
+
+// shared page of the direct exchange: flags F1 / F2 [destination device][source device] (frame sequence numbers, written
+// by hipStreamWriteValue32 on the source's stream, waited for by hipStreamWaitValue32 on the destination's), and, in the
+// rank form, the bootstrap area through which the processes of one node hand each other their hipIpc memory handles
+struct DirectPage {
+  unsigned f1[HSK_GROUP_MAX_DEV][HSK_GROUP_MAX_DEV];
+  unsigned f2[HSK_GROUP_MAX_DEV][HSK_GROUP_MAX_DEV];
+  volatile int ready[HSK_GROUP_MAX_DEV], attached[HSK_GROUP_MAX_DEV];
+  hipIpcMemHandle_t kg[HSK_GROUP_MAX_DEV], cm[HSK_GROUP_MAX_DEV];
+};
+
 struct Slab {
   hsk_ctx* k = nullptr;
   int dev_slot = 0;       // index into Group::devs
@@ -104,6 +140,13 @@ struct Dev {
   double* sums = nullptr;     // double[27]
   ncclComm_t comm = nullptr;
   std::vector<int> slabs;     // indices into Group::slabs
+  // direct exchange
+  int gidx = 0;               // this device's number among ALL devices of the group (rank form: the rank)
+  int* kg = nullptr;          // gather buffer: step keys of every slab of the group, int32[n_slabs_total][P]
+  int* cm = nullptr;          // composite: vertex / normal bit patterns of the winners, int32[6 P]
+  int* kg_of[HSK_GROUP_MAX_DEV] = {};  // every device's gather buffer / composite as THIS device addresses it
+  int* cm_of[HSK_GROUP_MAX_DEV] = {};
+  hipEvent_t ev_s0 = nullptr, ev_x0 = nullptr, ev_x1 = nullptr;  // HSK_GROUP_PROFILE: frame start, exchange start / end
 };
 
 }  // namespace
@@ -134,6 +177,17 @@ struct hsk_group {
   bool poisoned = false;
   std::string poison_why;
   std::string err;
+  // direct exchange (HSK_GROUP_DIRECT)
+  bool direct = false;
+  int n_dev_total = 1;             // devices of the whole group (rank form: world)
+  unsigned seq = 0;                // exchanges enqueued so far (the value the flags are raised to)
+  DirectPage* page = nullptr;      // host view of the shared page
+  DirectPage* page_dev[HSK_GROUP_MAX_DEV] = {};  // ... as each LOCAL device addresses it (index: slot in devs)
+  bool page_is_shm = false;
+  std::vector<void*> ipc_opened;   // peer buffers opened through hipIpcOpenMemHandle (rank form)
+  double exch_ms = 0.0, front_ms = 0.0;  // HSK_GROUP_PROFILE
+  unsigned long long exch_frames = 0;
+  bool exch_pending = false;
 };
 
 static thread_local std::string g_group_err;
@@ -212,8 +266,14 @@ static void group_free(hsk_group* g) {
       hsk_destroy(s.k);
     }
   }
+  for (void* p : g->ipc_opened) (void)hipIpcCloseMemHandle(p);
   for (auto& d : g->devs) {
     (void)hipSetDevice(d.id);
+    if (d.kg) (void)hipFree(d.kg);
+    if (d.cm) (void)hipFree(d.cm);
+    if (d.ev_s0) (void)hipEventDestroy(d.ev_s0);
+    if (d.ev_x0) (void)hipEventDestroy(d.ev_x0);
+    if (d.ev_x1) (void)hipEventDestroy(d.ev_x1);
     if (d.comm && R) (void)R->CommDestroy(d.comm);
     if (d.kmin) (void)hipFree(d.kmin);
     if (d.bsum) (void)hipFree(d.bsum);
@@ -221,7 +281,126 @@ static void group_free(hsk_group* g) {
     if (d.stream) (void)hipStreamDestroy(d.stream);
   }
   if (g->h_stage) (void)hipHostFree(g->h_stage);
+  if (g->page) {
+    if (g->page_is_shm) {
+      (void)hipHostUnregister(g->page);
+      (void)munmap(g->page, sizeof(DirectPage));
+    } else {
+      (void)hipHostFree(g->page);
+    }
+  }
   delete g;
+}
+
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// Direct exchange: buffers, the shared flag page, and every device's view of every other device's buffers.  Single
+// process: peer access between the group's devices.  Rank form (comm_id != null): the processes of ONE node meet in a
+// POSIX shared-memory page named after comm_id, hand each other hipIpc handles of their two buffers and map them.
+static int direct_setup(hsk_group* g, const void* comm_id) {
+  const size_t P = (size_t)g->cfg.width * g->cfg.height;
+  const bool ranks = comm_id != nullptr && g->world > 1;
+  g->n_dev_total = ranks ? g->world : (int)g->devs.size();
+  if (g->n_dev_total > HSK_GROUP_MAX_DEV || g->n_dev_total > HSK_PUSH_MAX_HOST) GFAIL(g, HSK_ERR_ARG, "direct exchange: too many devices");
+  for (size_t di = 0; di < g->devs.size(); ++di) {
+    Dev& d = g->devs[di];
+    int can = 0;
+    GHIP(g, hipSetDevice(d.id));
+    GHIP(g, hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, d.id));
+    if (!can) GFAIL(g, HSK_ERR_STATE, "direct exchange: this device has no stream wait-value operations (use the RCCL form)");
+    d.gidx = ranks ? g->rank0 : (int)di;
+    GHIP(g, hipMalloc((void**)&d.kg, (size_t)g->n_slabs_total * P * 4));
+    GHIP(g, hipMalloc((void**)&d.cm, 6 * P * 4));
+    GHIP(g, hipMemset(d.kg, 0, (size_t)g->n_slabs_total * P * 4));
+    GHIP(g, hipMemset(d.cm, 0, 6 * P * 4));
+    if (g->flags & HSK_GROUP_PROFILE) {
+      GHIP(g, hipEventCreate(&d.ev_s0));
+      GHIP(g, hipEventCreate(&d.ev_x0));
+      GHIP(g, hipEventCreate(&d.ev_x1));
+    }
+  }
+  if (ranks) {
+    char name[64];
+    const unsigned char* b = (const unsigned char*)comm_id;
+    int o = snprintf(name, sizeof(name), "/hskx_");
+    for (int i = 0; i < 16; ++i) o += snprintf(name + o, sizeof(name) - (size_t)o, "%02x", (unsigned)(b[i] ^ b[16 + i] ^ b[32 + i] ^ b[48 + i]));
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) GFAIL(g, HSK_ERR_STATE, "direct exchange: shm_open failed");
+    if (ftruncate(fd, (off_t)sizeof(DirectPage)) != 0) {
+      close(fd);
+      GFAIL(g, HSK_ERR_STATE, "direct exchange: ftruncate failed");
+    }
+    void* m = mmap(nullptr, sizeof(DirectPage), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) GFAIL(g, HSK_ERR_STATE, "direct exchange: mmap failed");
+    g->page = (DirectPage*)m;
+    g->page_is_shm = true;
+    GHIP(g, hipHostRegister(m, sizeof(DirectPage), hipHostRegisterMapped | hipHostRegisterPortable));
+    Dev& own = g->devs[0];
+    GHIP(g, hipHostGetDevicePointer((void**)&g->page_dev[0], m, 0));
+    GHIP(g, hipDeviceSynchronize());  // the memsets above: the buffers are handed out complete
+    GHIP(g, hipIpcGetMemHandle(&g->page->kg[own.gidx], own.kg));
+    GHIP(g, hipIpcGetMemHandle(&g->page->cm[own.gidx], own.cm));
+    __sync_synchronize();
+    g->page->ready[own.gidx] = 1;
+    const double t0 = now_s();
+    for (int r = 0; r < g->world; ++r)
+      while (!g->page->ready[r]) {
+        if (now_s() - t0 > 120.0) GFAIL(g, HSK_ERR_STATE, "direct exchange: a rank did not show up within 120 s");
+        usleep(200);
+      }
+    __sync_synchronize();
+    for (int r = 0; r < g->world; ++r) {
+      if (r == own.gidx) {
+        own.kg_of[r] = own.kg;
+        own.cm_of[r] = own.cm;
+        continue;
+      }
+      void *pk = nullptr, *pc = nullptr;
+      GHIP(g, hipIpcOpenMemHandle(&pk, g->page->kg[r], hipIpcMemLazyEnablePeerAccess));
+      g->ipc_opened.push_back(pk);
+      GHIP(g, hipIpcOpenMemHandle(&pc, g->page->cm[r], hipIpcMemLazyEnablePeerAccess));
+      g->ipc_opened.push_back(pc);
+      own.kg_of[r] = (int*)pk;
+      own.cm_of[r] = (int*)pc;
+    }
+    __sync_synchronize();
+    g->page->attached[own.gidx] = 1;
+    for (int r = 0; r < g->world; ++r)
+      while (!g->page->attached[r]) {
+        if (now_s() - t0 > 120.0) GFAIL(g, HSK_ERR_STATE, "direct exchange: a rank did not attach within 120 s");
+        usleep(200);
+      }
+    if (own.gidx == 0) (void)shm_unlink(name);  // everybody holds a mapping: the name can go
+    return HSK_OK;
+  }
+  void* m = nullptr;
+  GHIP(g, hipHostMalloc(&m, sizeof(DirectPage), hipHostMallocPortable | hipHostMallocMapped));
+  memset(m, 0, sizeof(DirectPage));
+  g->page = (DirectPage*)m;
+  for (size_t a = 0; a < g->devs.size(); ++a) {
+    Dev& da = g->devs[a];
+    GHIP(g, hipSetDevice(da.id));
+    GHIP(g, hipHostGetDevicePointer((void**)&g->page_dev[a], m, 0));
+    for (size_t bi = 0; bi < g->devs.size(); ++bi) {
+      Dev& db = g->devs[bi];
+      if (a != bi) {
+        int can = 0;
+        GHIP(g, hipDeviceCanAccessPeer(&can, da.id, db.id));
+        if (!can) GFAIL(g, HSK_ERR_STATE, "direct exchange: the devices of the group cannot access each other's memory");
+        const hipError_t e = hipDeviceEnablePeerAccess(db.id, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) GHIP(g, e);
+        (void)hipGetLastError();
+      }
+      da.kg_of[db.gidx] = db.kg;
+      da.cm_of[db.gidx] = db.cm;
+    }
+  }
+  return HSK_OK;
 }
 
 // slabs [first, first + n_local) of n_total on device_ids[]; communicator of `world` ranks, this process's devices being
@@ -297,7 +476,16 @@ static int group_build(const hsk_config* c, int n_total, int first, int n_local,
     g->err = "hsk_group_create: pinned staging";
     return bail(HSK_ERR_HIP);
   }
-  g->use_rccl = world > 1 || (flags & HSK_GROUP_FORCE_RCCL);
+  g->direct = (flags & HSK_GROUP_DIRECT) != 0;
+  if (g->direct) {
+    if (flags & HSK_GROUP_ICP_ALLREDUCE) {
+      g->err = "hsk_group_create: HSK_GROUP_DIRECT carries the composites only; the all-reduced ICP needs the RCCL form";
+      return bail(HSK_ERR_ARG);
+    }
+    const int r = direct_setup(g, comm_id);
+    if (r != HSK_OK) return bail(r);
+  }
+  g->use_rccl = !g->direct && (world > 1 || (flags & HSK_GROUP_FORCE_RCCL));
   if (g->use_rccl) {
     std::string why;
     Rccl* R = rccl(&why);
@@ -350,16 +538,24 @@ extern "C" int hsk_group_unique_id(void* id128) {
   if (!id128) return HSK_ERR_ARG;
   std::string why;
   Rccl* R = rccl(&why);
-  if (!R) {
-    g_group_err = why;
+  if (R) {
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) {
+      g_group_err = "ncclGetUniqueId failed";
+      return HSK_ERR_HIP;
+    }
+    memcpy(id128, &id, sizeof(id));
+    return HSK_OK;
+  }
+  // no RCCL in this process: 128 random bytes name a direct-exchange group (HSK_GROUP_DIRECT) just as well
+  unsigned char* out = (unsigned char*)id128;
+  FILE* f = fopen("/dev/urandom", "rb");
+  const size_t got = f ? fread(out, 1, 128, f) : 0;
+  if (f) fclose(f);
+  if (got != 128) {
+    g_group_err = why + "; and /dev/urandom is not readable";
     return HSK_ERR_STATE;
   }
-  ncclUniqueId id;
-  if (R->GetUniqueId(&id) != ncclSuccess) {
-    g_group_err = "ncclGetUniqueId failed";
-    return HSK_ERR_HIP;
-  }
-  memcpy(id128, &id, sizeof(id));
   return HSK_OK;
 }
 
@@ -476,6 +672,19 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
   for (size_t di = 0; di < g->devs.size(); ++di) {
     Dev& d = g->devs[di];
     GHIP(g, hipSetDevice(d.id));
+    if (d.ev_s0 && di == 0 && !restart) {
+      if (g->exch_pending) {  // the previous frame's times: read before the events are reused
+        float a = 0.0f, b = 0.0f;
+        if (hipEventSynchronize(d.ev_x1) == hipSuccess && hipEventElapsedTime(&a, d.ev_s0, d.ev_x0) == hipSuccess &&
+            hipEventElapsedTime(&b, d.ev_x0, d.ev_x1) == hipSuccess) {
+          g->front_ms += a;
+          g->exch_ms += b;
+          g->exch_frames += 1;
+        }
+        g->exch_pending = false;
+      }
+      GHIP(g, hipEventRecord(d.ev_s0, d.stream));
+    }
     // the frame as every slab of this device reads it: the caller's device buffer, or the pinned staging slot itself
     // (device-visible).  With a frame still in flight the copy + preprocessing go to each slab's second stream
     // (hsk_mgpu_prefetch), beside the work the device's stream is busy with; the frame front then picks them up.
@@ -511,6 +720,53 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
         GSLAB(g, s, hsk_mgpu_raycast_local(s.k, s.keys));
       }
     }
+  }
+  if (g->direct) {
+    // One-hop exchange (SURVEY.md 8(e) "xGMI fit").  Step 1: every slab's keys into its slot of EVERY device's gather
+    // buffer, then the flag "device d's keys of exchange seq are in place" raised at every other device.
+    g->seq += 1;
+    const unsigned seq = g->seq;
+    const int nd = g->n_dev_total;
+    for (size_t di = 0; di < g->devs.size(); ++di) {
+      Dev& d = g->devs[di];
+      GHIP(g, hipSetDevice(d.id));
+      if (d.ev_x0 && di == 0) GHIP(g, hipEventRecord(d.ev_x0, d.stream));
+      for (int si : d.slabs) {
+        Slab& s = g->slabs[si];
+        KeyDests kd;
+        kd.n = nd;
+        for (int r = 0; r < HSK_GROUP_MAX_DEV; ++r) kd.p[r] = r < nd ? d.kg_of[r] + (size_t)s.index * P : nullptr;
+        hipLaunchKernelGGL(k_push_keys, dim3((P_i + 255) / 256), dim3(256), 0, d.stream, s.keys, kd, P_i);
+      }
+      for (int r = 0; r < nd; ++r)
+        if (r != d.gidx) GHIP(g, hipStreamWriteValue32(d.stream, &g->page_dev[di]->f1[r][d.gidx], seq, 0));
+    }
+    // Step 2: once every other device's keys have arrived: the MIN over all slots, locally; the winner of a pixel stores
+    // its vertex / normal bits into every device's composite; flag "device d's winners are in place".
+    for (size_t di = 0; di < g->devs.size(); ++di) {
+      Dev& d = g->devs[di];
+      GHIP(g, hipSetDevice(d.id));
+      for (int r = 0; r < nd; ++r)
+        if (r != d.gidx) GHIP(g, hipStreamWaitValue32(d.stream, &g->page_dev[di]->f1[d.gidx][r], seq, hipStreamWaitValueGte, 0xffffffffu));
+      hipLaunchKernelGGL(k_min_slots, dim3((P_i + 255) / 256), dim3(256), 0, d.stream, d.kg, g->n_slabs_total, P_i, d.kmin);
+      for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_raycast_push(g->slabs[si].k, d.kmin, (void* const*)d.cm_of, nd));
+      for (int r = 0; r < nd; ++r)
+        if (r != d.gidx) GHIP(g, hipStreamWriteValue32(d.stream, &g->page_dev[di]->f2[r][d.gidx], seq, 0));
+    }
+    // Step 3: once every other device's winners have arrived: adopt the composite, rebuild the pyramid, report.
+    for (size_t di = 0; di < g->devs.size(); ++di) {
+      Dev& d = g->devs[di];
+      GHIP(g, hipSetDevice(d.id));
+      for (int r = 0; r < nd; ++r)
+        if (r != d.gidx) GHIP(g, hipStreamWaitValue32(d.stream, &g->page_dev[di]->f2[d.gidx][r], seq, hipStreamWaitValueGte, 0xffffffffu));
+      if (d.ev_x1 && di == 0) {
+        GHIP(g, hipEventRecord(d.ev_x1, d.stream));
+        g->exch_pending = true;
+      }
+      for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_frame_end_async(g->slabs[si].k, d.kmin, d.cm));
+    }
+    g->fifo.push_back(hsk_group::Pending());
+    return HSK_OK;
   }
   // composite 1: the first event along every ray
   for (auto& d : g->devs) {
@@ -618,6 +874,17 @@ extern "C" int hsk_group_reset(hsk_group* g) {
   g->fifo.clear();
   g->poisoned = false;
   g->poison_why.clear();
+  return HSK_OK;
+}
+
+// HSK_GROUP_PROFILE: on the group's first local device, per tracked frame: the slab's own work (ICP + integrate + slab
+// raycast: frame start -> exchange start) and the exchange (steps 1..3, waits for the peers included), summed over the
+// frames whose times have been read so far (the last submitted frame's are read at the next submission)
+extern "C" int hsk_group_exchange_ms(hsk_group* g, double* sum_ms, double* front_sum_ms, unsigned long long* n_frames) {
+  if (!g) return HSK_ERR_ARG;
+  if (sum_ms) *sum_ms = g->exch_ms;
+  if (front_sum_ms) *front_sum_ms = g->front_ms;
+  if (n_frames) *n_frames = g->exch_frames;
   return HSK_OK;
 }
 

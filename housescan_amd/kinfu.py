@@ -254,6 +254,8 @@ class KinfuTracker:
 
 GROUP_FORCE_RCCL = 1
 GROUP_ICP_ALLREDUCE = 2
+GROUP_DIRECT = 4      # composites as a one-hop exchange over peer-mapped memory (no RCCL)
+GROUP_PROFILE = 8     # events round the exchange (exchange_ms)
 
 
 class KinfuGroup:
@@ -325,6 +327,13 @@ class KinfuGroup:
 
     def n_slabs(self):
         return self.lib.hsk_group_n_slabs(self.h)
+
+    def exchange_ms(self):
+        """GROUP_PROFILE: (summed ms of the per-frame exchange, summed ms of the slab work before it, frames counted) on
+        the first local device"""
+        ms, front, n = C.c_double(), C.c_double(), C.c_ulonglong()
+        self._ck(self.lib.hsk_group_exchange_ms(self.h, C.byref(ms), C.byref(front), C.byref(n)))
+        return ms.value, front.value, n.value
 
     def slab(self, i):
         """a borrowed KinfuTracker view of slab i (owned by the group: never close it)"""

@@ -141,6 +141,10 @@ int hsk_mgpu_icp_replicated(hsk_ctx* k); /* the whole 19-iteration ICP on this r
 int hsk_mgpu_integrate(hsk_ctx* k);
 int hsk_mgpu_raycast_local(hsk_ctx* k, void* keys_dev /* int32[h*w] */);    /* slab-local march */
 int hsk_mgpu_raycast_resolve(hsk_ctx* k, const void* keys_min_dev, void* maps_bits_dev /* int32[6*h*w] */);
+/* direct exchange (no collective): where this slab won the pixel (keys_min == its own key, a hit), the bit patterns of its
+ * vertex / normal go straight into each of the n_dest (<= 16) composite buffers dest_bits[d] (int32[6*h*w], memory this
+ * context's device can write: its own, a peer's with access enabled, or an IPC-mapped one); nothing is written elsewhere */
+int hsk_mgpu_raycast_push(hsk_ctx* k, const void* keys_min_dev, void* const* dest_bits, int n_dest);
 int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const void* maps_bits_dev, float pose_out[16], int* tracked);
 int hsk_mgpu_frame_index(const hsk_ctx* k);
 /* pipelined form of the frame end: queues the pose read-back instead of waiting; collect with hsk_wait_frame (in order,
@@ -160,6 +164,16 @@ typedef struct hsk_group hsk_group;
 #define HSK_GROUP_FORCE_RCCL 1     /* run the collectives through RCCL even when the group has a single device / rank */
 #define HSK_GROUP_ICP_ALLREDUCE 2  /* row-shard the ICP over the slabs and all-reduce its 27 sums every iteration
                                       (default: every slab runs the whole ICP on the composited maps, no collective) */
+#define HSK_GROUP_DIRECT 4         /* the per-frame composites as a ONE-HOP exchange over peer-mapped memory instead of
+                                      two all-reduces: every slab stores its step keys into a slot of every device's
+                                      gather buffer, each device takes the MIN locally, the winner of a pixel stores its
+                                      vertex / normal bits into every device's composite (24 B per won pixel and peer
+                                      instead of a 7.4 MB all-reduce); stream wait / write-value operations on a shared
+                                      flag page order the steps -- no RCCL, no spinning kernel.  Single process: peer
+                                      access between the devices; rank form: hipIpc memory handles and a POSIX shared-
+                                      memory page named after comm_id (one node).  Not with HSK_GROUP_ICP_ALLREDUCE. */
+#define HSK_GROUP_PROFILE 8        /* HSK_GROUP_DIRECT: HIP events round the slab work and the exchange of every frame
+                                      (hsk_group_exchange_ms) */
 /* single process: slab s lives on device_ids[s] (a device may be named several times); the distinct devices form one
  * communicator.  c->device_id, own_z0, own_z1, halo and use_graph are set by the library. */
 int hsk_group_create(const hsk_config* c, int n_slabs, const int* device_ids, int flags, hsk_group** out);
@@ -187,6 +201,9 @@ int hsk_group_submit_frame(hsk_group* g, const uint16_t* depth, int w, int h);
  * valid until the frame has been waited for */
 int hsk_group_submit_frame_dev(hsk_group* g, const void* const* depth_dev, int w, int h);
 int hsk_group_wait_frame(hsk_group* g, float pose_out[16], int* tracked);
+/* HSK_GROUP_PROFILE: summed over n_frames tracked frames, on this process's first device: the exchange (waits for the peers
+ * included) and the slab's own work before it (ICP + integrate + slab-local raycast) */
+int hsk_group_exchange_ms(hsk_group* g, double* sum_ms, double* front_sum_ms, unsigned long long* n_frames);
 int hsk_group_n_slabs(const hsk_group* g);            /* slabs held by this process */
 hsk_ctx* hsk_group_slab(hsk_group* g, int i);         /* for hsk_download_map, hsk_extract_cloud, ... on one slab */
 /* the planes this process owns, at their place in a full 2 * X * Y * Z array (other planes are left untouched) */

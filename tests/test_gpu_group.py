@@ -191,3 +191,105 @@ def test_config5_four_rooms_each_a_two_slab_group_from_four_threads(hsk, synth_f
             assert_same_bits(p, pr, f"room {r} frame {k}: pair of slabs, four rooms at once, vs one context alone")
         assert_same_bits(groups[r].download_tsdf(full), want[r][1], f"room {r} tsdf")
         groups[r].close()
+
+
+# ---- the direct (one-hop, no RCCL) exchange: HSK_GROUP_DIRECT -------------------------------------------------------
+def _pipelined(t, frames):
+    res = []
+    t.submit_frame(frames[0])
+    for d in frames[1:]:
+        t.submit_frame(d)
+        res.append(t.wait_frame())
+    res.append(t.wait_frame())
+    return res
+
+
+@pytest.mark.parametrize("slabs,n", [(2, 64), (3, 64), (8, 256)])
+def test_direct_exchange_single_process(hsk, synth_frames, slabs, n):
+    """peer-write exchange with the slabs of one process (here all on device 0: the same kernels and stream wait / write
+    operations as between devices): poses, volume and model maps equal a single context's, pipelined, with a lost frame"""
+    zero = np.zeros_like(synth_frames(0)[1])
+    frames = [synth_frames(k)[1] for k in range(5)] + [zero] + [synth_frames(k)[1] for k in range(5, 10)]
+    ref = hsk.KinfuTracker(n=n)
+    want = _pipelined(ref, frames)
+    grp = hsk.KinfuGroup(hsk.default_config(n), device_ids=[0] * slabs, flags=hsk.GROUP_DIRECT | hsk.GROUP_PROFILE)
+    got = _pipelined(grp, frames)
+    for i, ((p, ok), (pr, okr)) in enumerate(zip(got, want)):
+        assert ok == okr, i
+        assert_same_bits(p, pr, f"direct exchange, {slabs} slabs: pose step {i}")
+    assert_same_bits(grp.download_tsdf(), ref.download_tsdf(), "direct exchange: tsdf")
+    for i in range(slabs):
+        for level in range(3):
+            assert_same_bits(grp.slab(i).download_map(2, level), ref.download_map(2, level), f"direct: slab {i} model vmap {level}")
+            assert_same_bits(grp.slab(i).download_map(3, level), ref.download_map(3, level), f"direct: slab {i} model nmap {level}")
+    ms, front, cnt = grp.exchange_ms()
+    assert cnt >= 6 and ms > 0.0 and front > 0.0
+    print(f"\ndirect exchange, {slabs} slabs on one device at {n}^3: {1e3 * ms / cnt:.1f} us per frame (slab work before it {1e3 * front / cnt:.1f} us)")
+    with pytest.raises(hsk.KinfuError, match="DIRECT"):
+        hsk.KinfuGroup(hsk.default_config(n), device_ids=[0, 0], flags=hsk.GROUP_DIRECT | hsk.GROUP_ICP_ALLREDUCE)
+    grp.close()
+    ref.close()
+
+
+DIRECT_RANK_SCRIPT = """
+import os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r})
+import housescan_amd as hsk
+rank, world, idfile, n = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+uid = open(idfile, "rb").read()
+grp = hsk.KinfuGroup(hsk.default_config(n, device_id=0), rank=rank, world=world, comm_id=uid, flags=hsk.GROUP_DIRECT)
+zero = np.zeros((480, 640), np.uint16)
+frames = [hsk.synth_depth(hsk.synth_pose(k)) for k in range(5)] + [zero] + [hsk.synth_depth(hsk.synth_pose(k)) for k in range(5, 10)]
+grp.submit_frame(frames[0])
+out = []
+for d in frames[1:]:
+    grp.submit_frame(d)
+    out.append(grp.wait_frame())
+out.append(grp.wait_frame())
+for p, ok in out:
+    print("pose", int(ok), np.ascontiguousarray(p, np.float32).tobytes().hex())
+np.save(idfile + ".vol%d.npy" % rank, grp.download_tsdf())
+grp.close()
+print("done")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_exchange_between_processes_sharing_the_gpu(hsk, synth_frames, tmp_path, world):
+    """the RANK form of the group across OS processes (one slab each; here they share device 0, which RCCL refuses --
+    "Duplicate GPU detected" -- and the direct form does not): hipIpc-mapped peer buffers, the POSIX shared-memory flag page,
+    stream waits on flags another process raises.  Every rank must report the single context's poses; the ranks' owned
+    planes together are the single context's volume."""
+    import sys
+    n = 64
+    idfile = str(tmp_path / "comm_id")
+    open(idfile, "wb").write(os.urandom(128))
+    script = DIRECT_RANK_SCRIPT.format(root=ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), str(world), idfile, str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and so.strip().endswith("done"), (r, se[-3000:])
+    zero = np.zeros_like(synth_frames(0)[1])
+    frames = [synth_frames(k)[1] for k in range(5)] + [zero] + [synth_frames(k)[1] for k in range(5, 10)]
+    ref = hsk.KinfuTracker(n=n)
+    want = _pipelined(ref, frames)
+    for r, (so, _) in enumerate(outs):
+        rows = [ln.split() for ln in so.splitlines() if ln.startswith("pose ")]
+        assert len(rows) == len(want)
+        for k, (row, (pr, okr)) in enumerate(zip(rows, want)):
+            assert int(row[1]) == int(okr), (r, k)
+            assert bytes.fromhex(row[2]) == np.ascontiguousarray(pr, np.float32).tobytes(), f"rank {r} pose step {k}"
+    got = np.load(idfile + ".vol0.npy")
+    for r in range(1, world):
+        got = got | np.load(idfile + ".vol%d.npy" % r)   # each rank fills only the planes it owns
+    assert_same_bits(got, ref.download_tsdf(), "the ranks' owned planes together")
+    ref.close()

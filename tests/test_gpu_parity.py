@@ -952,6 +952,16 @@ def test_bench_two_ranks_match_one(tmp_path):
                          "--icp", icp] + common)
         assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["tracking"]["lost_frames"] == 0
         assert two["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"], icp
+    # ... and the default engine (hsk_group_* in the rank form) with its direct exchange: two OS processes, a slab each,
+    # peer buffers through hipIpc handles, flags on a shared page -- what `bench.py --gpus N` runs on an N-GPU node
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), "bench.py", "--gpus", "2", "--share-gpu", "--exchange", "direct"] + common)
+    assert two["n_gpus"] == 2 and two["config"]["exchange"].startswith("direct") and two["tracking"]["lost_frames"] == 0
+    assert two["stage_us"]["exchange_us"] > 0 and two["stage_us"]["slab_work_us"] > 0
+    assert two["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"]
 
 
 def test_bench_group_engine_world_of_one(tmp_path):
