@@ -3,6 +3,15 @@
 // with its wavefront reduction and on-device 6x6 solve (A.5).
 #pragma clang fp contract(off)
 #include "hsk_dev.h"
+#ifdef HSK_ICP_TIMING
+// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration; defined before
+// hsk_icp_dev.h is first seen (through hsk_launch.h), so that the solve step's inner stamps exist too
+__device__ unsigned long long g_icp_times[20 * 256 * 10];
+extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
+}
+#define ICP_STAMP(k) do { if (threadIdx.x == 0 && g_icp_iter < 20 && blockIdx.x < 256) g_icp_times[(g_icp_iter * 256 + blockIdx.x) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #include "hsk_launch.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -347,17 +356,6 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
 // ------------------------------------------------------------------------------------------------------
 // ICP_PX pixels per lane (template): loads batched so that the dependent chain is 2 memory round trips
 #ifndef ICP_BLOCK
-#ifdef HSK_ICP_TIMING
-// timing build (tools/icp_timing.sh): s_memrealtime (100 MHz) stamps of every block of every iteration
-__device__ unsigned long long g_icp_times[20 * 256 * 10];
-extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_times), (size_t)n * 8);
-}
-#define ICP_STAMP(k) do { if (threadIdx.x == 0 && g_icp_iter < 20 && blockIdx.x < 256) g_icp_times[(g_icp_iter * 256 + blockIdx.x) * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ICP_STAMP(k) do { } while (0)
-#endif
-#include "hsk_icp_dev.h"
 #define ICP_BLOCK 256
 #endif
 #define ICP_SH_ROWS ((ICP_BLOCK / 64) > 8 ? (ICP_BLOCK / 64) : 8)  // LDS rows: one per wave, at least the 8 slices of the shard reduction
