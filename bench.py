@@ -314,14 +314,21 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
     sample = list(range(1 + Wm, total, max(1, K // 10)))
     p = None
     entries = []
+    per_frame = []   # stage times of every timed frame (the library sums them; read and reset after each frame)
     for i in range(total):
         if i == 1 + Wm:
             rep.stage_ms(reset=True)  # warm-up frames are not part of the timed region
         p, _ = rep.process_frame_dev(dev_frames[i].data_ptr())
+        if i >= 1 + Wm:
+            m1, n1 = rep.stage_ms(reset=True)
+            if n1 == 1:
+                per_frame.append(m1)
         if i in sample:
             rep_poses[i] = p.copy()
             entries.append(rep.integrate_queue_entries())   # lane-blocks pass A handed to pass B in this frame
-    ms, nf = rep.stage_ms(reset=True)
+    per_frame = np.array(per_frame) if per_frame else np.zeros((1, 4))
+    ms, nf = [float(v) for v in per_frame.sum(axis=0)], len(per_frame)
+    replay_with_events.per_frame_us = per_frame * 1e3
     rep.set_profiling(False)
     if final_pose is not None:
         assert np.array_equal(p, final_pose), "the replay must reproduce the timed run's final pose bit for bit"
@@ -404,9 +411,14 @@ def run_single(args, hsk, torch, local_rank):
     out["roofline"] = roofline_block(n, ms, nf, v_mean, traffic, tinfo if isinstance(tinfo, dict) else None)
     if traffic is None:
         out["roofline"]["traffic_note"] = str(tinfo)
+    pf = replay_with_events.per_frame_us
     out["stage_us"] = {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1), "integrate": round(ms[2] / nf * 1e3, 1),
                        "raycast": round(ms[3] / nf * 1e3, 1),
-                       "note": "means over the %d frames of the timed region, replayed with HIP events between the stages" % nf}
+                       "median": {k: round(float(np.median(pf[:, j])), 1) for j, k in enumerate(("preprocess", "icp", "integrate", "raycast"))},
+                       "p10": {k: round(float(np.percentile(pf[:, j], 10)), 1) for j, k in enumerate(("preprocess", "icp", "integrate", "raycast"))},
+                       "p90": {k: round(float(np.percentile(pf[:, j], 90)), 1) for j, k in enumerate(("preprocess", "icp", "integrate", "raycast"))},
+                       "note": "means (top level), medians and percentiles over the %d frames of the timed region, replayed with HIP events between "
+                               "the stages" % nf}
     iters = [10, 5, 4]
     out["icp_us_per_iter"] = {"fine_640x480": round(icp_ms[0] / nf / iters[0] * 1e3, 2), "mid_320x240": round(icp_ms[1] / nf / iters[1] * 1e3, 2),
                               "coarse_160x120": round(icp_ms[2] / nf / iters[2] * 1e3, 2),
@@ -448,6 +460,9 @@ def run_single(args, hsk, torch, local_rank):
             path = os.path.join(tmpd, "synthetic_300.hskd")
             record_synthetic(hsk, path, 300)
             out["trajectory_256"], _ = stream_replay(hsk, 256, path, local_rank)
+            if not args.no_cpu_baseline:   # the CPU restatement beside configs[1]'s size too (a short sample)
+                cb = cpu_baseline(256, hsk, budget_s=4.0)
+                out["trajectory_256"]["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
         finally:
             shutil.rmtree(tmpd, ignore_errors=True)
     # ---- 1024^3: the HBM measurement ----
@@ -511,13 +526,34 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
             if mode == "pairs":
                 # BASELINE configs[4]: one room per PAIR of GPUs -- a two-slab group with its own two-rank communicator
                 pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
-                ids = [os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id() if rank % 2 == 0 else None]
-                dist.broadcast_object_list(ids, src=2 * room, group=pgs[room])
-                trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank % 2, world=2, comm_id=ids[0], flags=flags)
+                g_rank, g_world, g_src, g_pg = rank % 2, 2, 2 * room, pgs[room]
             else:
-                ids = [(os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                trk = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=rank, world=world, comm_id=ids[0], flags=flags)
+                g_rank, g_world, g_src, g_pg = rank, world, 0, None
+
+            def make_group(fl):
+                """the group of this rank under flags fl; every rank of the group learns whether ALL of them got theirs"""
+                ids = [(os.urandom(128) if (fl & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == g_src else None]
+                dist.broadcast_object_list(ids, src=g_src, group=g_pg)
+                try:
+                    t, why = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=g_rank, world=g_world, comm_id=ids[0], flags=fl), None
+                except hsk.KinfuError as e:
+                    t, why = None, str(e)
+                ok = torch.tensor([0 if t is None else 1])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=g_pg)
+                return t, why, bool(ok.item())
+
+            trk, why, ok_all = make_group(flags)
+            timed.exchange_used = "direct" if (flags & hsk.GROUP_DIRECT) else "rccl"
+            if not ok_all and (flags & hsk.GROUP_DIRECT):
+                # the one-hop form could not be set up on this node (no peer access / IPC / stream memory operations):
+                # fall back to the RCCL collectives, all ranks together
+                if trk is not None:
+                    trk.close()
+                flags &= ~(hsk.GROUP_DIRECT | hsk.GROUP_PROFILE)
+                timed.exchange_used = "rccl (direct exchange unavailable: %s)" % (why or "a peer rank failed")
+                trk, why, ok_all = make_group(flags)
+            if not ok_all:
+                raise SystemExit("bench.py: the slab group could not be created: %s" % (why or "a peer rank failed"))
             submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
 
             def first(i):
@@ -565,7 +601,8 @@ def run_multi(args, hsk, torch, world, rank, local_rank):
                                   ("rooms%d" % world if args.mode == "rooms" else "pairs%d-icp-%s" % (rooms, args.icp)),
                    "exchange": None if args.mode == "rooms" else
                                ("direct: one-hop peer writes + stream wait / write-value flags (HSK_GROUP_DIRECT, no RCCL)"
-                                if args.exchange == "direct" and args.icp != "allreduce" else "RCCL: all-reduce(MIN) of the keys, all-reduce(SUM) of the winners' bits"),
+                                if getattr(timed, "exchange_used", "") == "direct" else
+                                "RCCL: all-reduce(MIN) of the keys, all-reduce(SUM) of the winners' bits [%s]" % getattr(timed, "exchange_used", "rccl")),
                    "api": "hsk_submit_frame_dev / hsk_wait_frame" if args.mode == "rooms" else
                           "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI), 1 frame in flight ahead"},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
