@@ -12,6 +12,7 @@ size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (kernels_vol
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni);  // before anything reads weights
 size_t integrate_queue_words(const VolParams& vp);
+size_t integrate_zint_entries(const VolParams& vp);  // column z ranges + workgroup z ranges (launch_integrate's zint)
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);

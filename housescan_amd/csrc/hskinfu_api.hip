@@ -424,7 +424,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   CK(hipMalloc((void**)&k->d_uni, k->uni_bytes));
   // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of pass A's tiles
   CK(hipMalloc((void**)&k->d_queue, integrate_queue_words(vp) * sizeof(unsigned)));
-  CK(hipMalloc((void**)&k->d_zint, (size_t)(vp.X / 4) * vp.Y * sizeof(int2)));
+  CK(hipMalloc((void**)&k->d_zint, integrate_zint_entries(vp) * sizeof(int2)));
   CK(hipMalloc((void**)&k->d_counter, 16));
   {
     float ws[169], wc[512];

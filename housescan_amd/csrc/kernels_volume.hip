@@ -129,7 +129,8 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
                                 int2* __restrict__ zint, int dil_blocks, const float* __restrict__ tmax,
                                 const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th,
-                                unsigned* __restrict__ qcount, IcpFinal fin, TrackState* __restrict__ st_out) {
+                                unsigned* __restrict__ qcount, IcpFinal fin, TrackState* __restrict__ st_out,
+                                int2* __restrict__ wgz) {
   // fin.slots != null: the frame's ICP has left its last solve to this launch (launch_icp_fused).  The first wave of
   // EVERY block reads the sharded sums of the last iteration and solves (deterministic: all blocks get the same pose),
   // the block then works with that pose; block 0 also publishes it -- what k_icp_final does in a launch of its own.
@@ -176,48 +177,73 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
       dtab[i] = make_float2(mx, mn);
     }
   }
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // One block = the x-y footprint of one pass-A workgroup (16 lane columns by 16 rows), so that the block can also leave
+  // that workgroup's z range: pass A's workgroups of the chunks outside it (half of its waves lie outside the frustum)
+  // then leave on one scalar load instead of a vector load per lane and a wave-wide reduction.
+  __shared__ int wg_lo[4], wg_hi[4];
   const int ncol = vp.X / 4;
-  if (c >= ncol * vp.Y) return;
-  const int y = c / ncol, x0 = (c - y * ncol) * 4;
-  // (a lost frame keeps the previous pose in st; the solve's own estimate is then meaningless, and nothing integrates)
-  const bool own = fin.slots != nullptr && !fin_pose.lost;
-  const float* __restrict__ Rm = own ? fin_pose.R : st->R;
-  const float* __restrict__ tm = own ? fin_pose.t : st->t;
-  const float tx = tm[0], ty = tm[1], tz = tm[2];
-  const float i00 = Rm[0], i01 = Rm[3], i02 = Rm[6];
-  const float i10 = Rm[1], i11 = Rm[4], i12 = Rm[7];
-  const float i20 = Rm[2], i21 = Rm[5], i22 = Rm[8];
-  const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
-  float glo = 1e30f, ghi = -1e30f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
-    const float ax = i00 * gx + i01 * gy, ay = i10 * gx + i11 * gy, az = i20 * gx + i21 * gy;
-    float lo = -1e30f, hi = 1e30f;
-    clip_interval(az, i22, lo, hi);
-    const float ul = 1.5f + in.cx, uh = ((float)W + 0.5f) - in.cx;
-    const float vl = 1.5f + in.cy, vh = ((float)H + 0.5f) - in.cy;
-    clip_interval(ax * in.fx + ul * az, i02 * in.fx + ul * i22, lo, hi);
-    clip_interval(uh * az - ax * in.fx, uh * i22 - i02 * in.fx, lo, hi);
-    clip_interval(ay * in.fy + vl * az, i12 * in.fy + vl * i22, lo, hi);
-    clip_interval(vh * az - ay * in.fy, vh * i22 - i12 * in.fy, lo, hi);
-    if (lo <= hi) {
-      glo = fminf(glo, lo);
-      ghi = fmaxf(ghi, hi);
-    }
-  }
+  const int gxn = (vp.X + 63) / 64, gyn = (vp.Y + 15) / 16;
+  const bool fp_block = (int)blockIdx.x < gxn * gyn;
+  const int fby = (int)blockIdx.x / gxn, fbx = (int)blockIdx.x - fby * gxn;
+  const int y = fby * 16 + (int)(threadIdx.x >> 4), lc = fbx * 16 + (int)(threadIdx.x & 15);
+  const bool col_ok = fp_block && y < vp.Y && lc < ncol;
+  const int x0 = lc * 4;
   int zl = 0x7fffffff, zh = -0x7fffffff;
-  if (glo <= ghi) {
-    // gz = (z + 0.5) * cell_z - tz  =>  z = (gz + tz) / cell_z - 0.5; pad by 2 planes for float error
-    const float inv_cz = __builtin_amdgcn_rcpf(vp.cell[2]);
-    const float fl = (glo + tz) * inv_cz - 2.5f, fh = (ghi + tz) * inv_cz + 1.5f;
-    const int a = fl < -1e9f ? -1000000000 : (fl > 1e9f ? 1000000000 : (int)floorf(fl));
-    const int b = fh < -1e9f ? -1000000000 : (fh > 1e9f ? 1000000000 : (int)ceilf(fh));
-    zl = a - vp.zs0;
-    zh = b - vp.zs0;
+  if (col_ok) {
+    // (a lost frame keeps the previous pose in st; the solve's own estimate is then meaningless, and nothing integrates)
+    const bool own = fin.slots != nullptr && !fin_pose.lost;
+    const float* __restrict__ Rm = own ? fin_pose.R : st->R;
+    const float* __restrict__ tm = own ? fin_pose.t : st->t;
+    const float tx = tm[0], ty = tm[1], tz = tm[2];
+    const float i00 = Rm[0], i01 = Rm[3], i02 = Rm[6];
+    const float i10 = Rm[1], i11 = Rm[4], i12 = Rm[7];
+    const float i20 = Rm[2], i21 = Rm[5], i22 = Rm[8];
+    const float gy = ((float)y + 0.5f) * vp.cell[1] - ty;
+    float glo = 1e30f, ghi = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - tx;
+      const float ax = i00 * gx + i01 * gy, ay = i10 * gx + i11 * gy, az = i20 * gx + i21 * gy;
+      float lo = -1e30f, hi = 1e30f;
+      clip_interval(az, i22, lo, hi);
+      const float ul = 1.5f + in.cx, uh = ((float)W + 0.5f) - in.cx;
+      const float vl = 1.5f + in.cy, vh = ((float)H + 0.5f) - in.cy;
+      clip_interval(ax * in.fx + ul * az, i02 * in.fx + ul * i22, lo, hi);
+      clip_interval(uh * az - ax * in.fx, uh * i22 - i02 * in.fx, lo, hi);
+      clip_interval(ay * in.fy + vl * az, i12 * in.fy + vl * i22, lo, hi);
+      clip_interval(vh * az - ay * in.fy, vh * i22 - i12 * in.fy, lo, hi);
+      if (lo <= hi) {
+        glo = fminf(glo, lo);
+        ghi = fmaxf(ghi, hi);
+      }
+    }
+    if (glo <= ghi) {
+      // gz = (z + 0.5) * cell_z - tz  =>  z = (gz + tz) / cell_z - 0.5; pad by 2 planes for float error
+      const float inv_cz = __builtin_amdgcn_rcpf(vp.cell[2]);
+      const float fl = (glo + tz) * inv_cz - 2.5f, fh = (ghi + tz) * inv_cz + 1.5f;
+      const int a = fl < -1e9f ? -1000000000 : (fl > 1e9f ? 1000000000 : (int)floorf(fl));
+      const int b = fh < -1e9f ? -1000000000 : (fh > 1e9f ? 1000000000 : (int)ceilf(fh));
+      zl = a - vp.zs0;
+      zh = b - vp.zs0;
+    }
+    zint[(size_t)y * ncol + lc] = make_int2(zl, zh);
   }
-  zint[c] = make_int2(zl, zh);
+  if (fp_block) {  // block-uniform
+    int lo = zl, hi = zh;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, 64));
+      hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      wg_lo[threadIdx.x >> 6] = lo;
+      wg_hi[threadIdx.x >> 6] = hi;
+      wgz[(size_t)gxn * gyn + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = make_int2(lo, hi);  // this wave's footprint (16 lane columns x 4 rows)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      wgz[blockIdx.x] = make_int2(min(min(wg_lo[0], wg_lo[1]), min(wg_lo[2], wg_lo[3])), max(max(wg_hi[0], wg_hi[1]), max(wg_hi[2], wg_hi[3])));
+  }
 }
 
 // per-lane, z-invariant terms of one column group (4 x-adjacent voxels): the group centre's R^T (gx, gy, 0), x / y terms
@@ -524,7 +550,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
                                                    const float2* __restrict__ qtab, double* __restrict__ icp_slot0,
-                                                   unsigned char* __restrict__ uni, IntegrateConst k) {
+                                                   unsigned char* __restrict__ uni, IntegrateConst k, const int2* __restrict__ wgz) {
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
   // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
   if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -556,17 +582,22 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
   unsigned long long cnt = 0;
   const int zbeg = blockIdx.z * zchunk;
   const int zend = min(zbeg + zchunk, vp.nzs);
+  {
+    // the z range of this workgroup's whole x-y footprint (k_column_zrange): a chunk outside it holds nothing to do for any
+    // lane -- half of pass A's workgroups, which thus leave on one scalar load
+    const int2 wz = wgz[byr * gridDim.x + bxr];
+    if (zbeg > wz.y || zend - 1 < wz.x) return;
+  }
+  // ... and of this wave's own footprint (16 lane columns x 4 rows): the wave-uniform loop bounds, without a wave-wide
+  // reduction of the lanes' ranges (min over lanes of max(zl, zbeg) = max(min zl, zbeg)); a wave with nothing to do
+  // leaves here, its lanes' ranges never loaded
+  const int2 wv = wgz[(size_t)gridDim.x * gridDim.y + (size_t)(byr * gridDim.x + bxr) * 4 + (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y)];
+  const int wl = max(wv.x, zbeg), wh = min(wv.y, zend - 1);
   int zl = 0x7fffffff, zh = -0x7fffffff;  // this lane's stored-plane range inside the padded frustum
-  if (active) {
+  if (wl <= wh && active) {
     const int2 zr = zint[(size_t)y * (vp.X / 4) + (x0 >> 2)];  // computed once per frame by k_column_zrange
     zl = max(zr.x, zbeg);
     zh = min(zr.y, zend - 1);
-  }
-  int wl = zl, wh = zh;  // wave-uniform loop bounds
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    wl = min(wl, __shfl_xor(wl, o, 64));
-    wh = max(wh, __shfl_xor(wh, o, 64));
   }
   PA_STAMP(1);
   if (wl <= wh) {
@@ -947,6 +978,9 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
   hipLaunchKernelGGL(k_tile_window, dim3((4 * fw * fh + 255) / 256, 9), dim3(256), 0, s, qtab, 2 * fw, 2 * fh, fwin + (size_t)9 * fw * fh);
 }
 
+// entries of the z-range tables: one int2 per lane column, then one per pass-A workgroup footprint (64 x 16 voxels), then
+// one per wave footprint (64 x 4 voxels: four per workgroup)
+size_t integrate_zint_entries(const VolParams& vp) { return (size_t)(vp.X / 4) * vp.Y + (size_t)5 * ((vp.X + 63) / 64) * ((vp.Y + 15) / 16); }
 // words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
 size_t integrate_queue_words(const VolParams& vp) {
   const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
@@ -967,12 +1001,13 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   // each) -- pass A reads the window forms
   const float2* ftab = (const float2*)(tmax + 4 * tw * th) + (size_t)5 * fw * fh;
   const float2* qtab = ftab + (size_t)9 * fw * fh;
-  const int col_blocks = (ncols + 255) / 256, dil_blocks = (tw * th + 255) / 256;
+  const int col_blocks = ((vp.X + 63) / 64) * ((vp.Y + 15) / 16), dil_blocks = (tw * th + 255) / 256;  // one block per pass-A footprint
   unsigned* qcount = queue;  // HSK_NQUEUES counters, one per 256-B line, cleared by k_column_zrange
   const IcpFinal none = {nullptr, nullptr, 0};
   const IcpFinal fin = (icp_final && !count_only) ? *icp_final : none;
+  int2* wgz = zint + ncols;  // behind the column table: one entry per pass-A workgroup footprint (integrate_zint_entries)
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, dil_blocks,
-                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount, fin, const_cast<TrackState*>(st));
+                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount, fin, const_cast<TrackState*>(st), wgz);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
@@ -986,12 +1021,12 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
                        zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr,
-                       (unsigned char*)nullptr, kc);
+                       (unsigned char*)nullptr, kc, wgz);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   } else {
     hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, uni, kc);
+                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, uni, kc, wgz);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
                        flags, zint, qdata, qcount, qcap);
   }

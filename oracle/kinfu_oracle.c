@@ -20,7 +20,7 @@
  * by default), one expf per bilateral tap over the exclusively clipped window with a zero centre filtered like any other
  * (D1), plain binary64 products and sums in the ICP (no 2^-26 snap, D4), LLT Cholesky with square roots (D4), libm
  * sinf / cosf for the pose increment, no rejection of extrapolated hit times (D3), "1 / z < 0" as the only in-front test
- * (D6).  It is the yardstick for the north_star's "within a stated tolerance" (tools/spec_vs_literal.py,
+ * (D6), and integrate's camera coordinates advanced incrementally along z as upstream does (A.4's closing note).  It is the yardstick for the north_star's "within a stated tolerance" (tools/spec_vs_literal.py,
  * tests/test_spec_vs_literal.py): how far the bit-reproducible specification moves TSDF values and poses from the
  * PCL-form arithmetic.  Still a recollection of PCL (parity unpinned), still test infrastructure.
  */
@@ -33,6 +33,7 @@
 #define ORA_LIT_D3 1 /* raycast: extrapolated hit times accepted */
 #define ORA_LIT_D4 1 /* ICP: plain binary64 sums, LLT Cholesky, libm sinf / cosf */
 #define ORA_LIT_D6 1 /* integrate: "1 / z < 0" as the in-front test */
+#define ORA_LIT_INC 1 /* integrate: camera coordinates advanced incrementally along z (A.4's closing note) */
 #endif
 
 #include <math.h>
@@ -120,6 +121,61 @@ void ora_scale_depth(const uint16_t* depth, int W, int H, float fx, float fy, fl
 /* ------------------------------------------------------------------------------------------------ */
 /* A.4 integrate (tsdf23), direct (non-incremental) form                                             */
 /* ------------------------------------------------------------------------------------------------ */
+#ifdef ORA_LIT_INC
+/* A.4 as upstream walks it: one (x, y) column at a time, z innermost; the camera-space x and y (pre-multiplied by fx, fy)
+ * and the depth term are ADVANCED by float additions from plane to plane instead of being formed from the voxel index --
+ * differences of an ulp or so, which flip a round-to-nearest pixel now and then (SURVEY.md A.4's closing note: "count and
+ * report such voxels").  The in-front test is upstream's "1 / z < 0"; the update rule is the same. */
+uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], float tau, int zs0, int nzs,
+                       const float* scaled, int W, int H, float fx, float fy, float cx, float cy,
+                       const float R[9], const float t[3]) {
+  const int X = dims[0], Y = dims[1];
+  const float cellx = size[0] / (float)dims[0], celly = size[1] / (float)dims[1], cellz = size[2] / (float)dims[2];
+  const float tau_inv = 1.0f / tau;
+  const float i00 = R[0], i01 = R[3], i02 = R[6], i10 = R[1], i11 = R[4], i12 = R[7], i20 = R[2], i21 = R[5], i22 = R[8];
+  uint64_t n_upd = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : n_upd) schedule(static)
+#endif
+  for (int y = 0; y < Y; ++y)
+    for (int x = 0; x < X; ++x) {
+      const float gx = ((float)x + 0.5f) * cellx - t[0];
+      const float gy = ((float)y + 0.5f) * celly - t[1];
+      float gz = ((float)zs0 + 0.5f) * cellz - t[2];
+      const float part_norm = gx * gx + gy * gy;
+      float vx = (i00 * gx + i01 * gy + i02 * gz) * fx;
+      float vy = (i10 * gx + i11 * gy + i12 * gz) * fy;
+      const float vz = i20 * gx + i21 * gy + i22 * gz;
+      float z_scaled = 0.0f;
+      const float dx = i02 * cellz * fx, dy = i12 * cellz * fy;
+      for (int zz = 0; zz < nzs; ++zz, gz += cellz, z_scaled += cellz, vx += dx, vy += dy) {
+        const float inv_z = 1.0f / (vz + i22 * z_scaled);
+        if (inv_z < 0.0f) continue;
+        int u, v;
+        if (!rint_guard(vx * inv_z + cx, &u) || !rint_guard(vy * inv_z + cy, &v)) continue;
+        if (u < 0 || v < 0 || u >= W || v >= H) continue;
+        const float Ds = scaled[v * W + u];
+        const float sdf = Ds - sqrtf(gz * gz + part_norm);
+        if (Ds != 0.0f && sdf >= -tau) {
+          float F = sdf * tau_inv;
+          F = F < 1.0f ? F : 1.0f;
+          int16_t* vox = vol + 2 * (((size_t)zz * Y + y) * X + x);
+          const float Fp = (float)vox[0] / 32767.0f, Wp = (float)vox[1];
+          const float Fn = (Fp * Wp + F) / (Wp + 1.0f);
+          int wn = vox[1] + 1;
+          if (wn > ORA_MAX_WEIGHT) wn = ORA_MAX_WEIGHT;
+          int fixed = (int)(Fn * 32767.0f);
+          if (fixed > ORA_DIVISOR) fixed = ORA_DIVISOR;
+          if (fixed < -ORA_DIVISOR) fixed = -ORA_DIVISOR;
+          vox[0] = (int16_t)fixed;
+          vox[1] = (int16_t)wn;
+          ++n_upd;
+        }
+      }
+    }
+  return n_upd;
+}
+#else
 uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], float tau, int zs0, int nzs,
                        const float* scaled, int W, int H, float fx, float fy, float cx, float cy,
                        const float R[9], const float t[3]) {
@@ -183,6 +239,7 @@ uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], flo
   }
   return n_upd;
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------------ */
 /* A.3 bilateral filter: 13x13, sigma_space 4.5 px, sigma_color 30 mm                                 */

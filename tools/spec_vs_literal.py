@@ -119,7 +119,8 @@ VARIANTS = [("fma", "", "fast", "FMA contraction allowed, nothing else (gcc -ffp
             ("d1", "-DORA_LIT_D1", "off", "D1: bilateral with one expf per tap, exclusive window clip, zero centre filtered"),
             ("d3", "-DORA_LIT_D3", "off", "D3: extrapolated raycast hit times accepted"),
             ("d4", "-DORA_LIT_D4", "off", "D4: plain binary64 ICP sums, LLT Cholesky, libm sinf / cosf"),
-            ("d6", "-DORA_LIT_D6", "off", "D6: 1 / z < 0 as integrate's in-front test")]
+            ("d6", "-DORA_LIT_D6", "off", "D6: 1 / z < 0 as integrate's in-front test"),
+            ("inc", "-DORA_LIT_INC", "off", "integrate: camera coordinates advanced incrementally along z (A.4's closing note; includes D6)")]
 
 
 def attribute_section(n, frames, hsk, O, log=None):
