@@ -230,15 +230,21 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
   }
   if (fp_block) {  // block-uniform
     int lo = zl, hi = zh;
+    // ... and the range EVERY column of the wave's footprint covers (largest lower end, smallest upper end; columns
+    // outside the volume do not count): a chunk inside it needs no per-lane ranges at all
+    int lo_all = col_ok ? zl : -0x7fffffff, hi_all = col_ok ? zh : 0x7fffffff;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       lo = min(lo, __shfl_xor(lo, o, 64));
       hi = max(hi, __shfl_xor(hi, o, 64));
+      lo_all = max(lo_all, __shfl_xor(lo_all, o, 64));
+      hi_all = min(hi_all, __shfl_xor(hi_all, o, 64));
     }
     if ((threadIdx.x & 63) == 0) {
       wg_lo[threadIdx.x >> 6] = lo;
       wg_hi[threadIdx.x >> 6] = hi;
-      wgz[(size_t)gxn * gyn + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = make_int2(lo, hi);  // this wave's footprint (16 lane columns x 4 rows)
+      // this wave's footprint (16 lane columns x 4 rows): union of its columns' ranges, then their intersection
+      ((int4*)(wgz + (((size_t)gxn * gyn + 1) & ~(size_t)1)))[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = make_int4(lo, hi, lo_all, hi_all);
     }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -591,10 +597,18 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
   // ... and of this wave's own footprint (16 lane columns x 4 rows): the wave-uniform loop bounds, without a wave-wide
   // reduction of the lanes' ranges (min over lanes of max(zl, zbeg) = max(min zl, zbeg)); a wave with nothing to do
   // leaves here, its lanes' ranges never loaded
-  const int2 wv = wgz[(size_t)gridDim.x * gridDim.y + (size_t)(byr * gridDim.x + bxr) * 4 + (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y)];
+  const int4 wv = ((const int4*)(wgz + (((size_t)gridDim.x * gridDim.y + 1) & ~(size_t)1)))[(size_t)(byr * gridDim.x + bxr) * 4 +
+                                                                                          (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y)];
   const int wl = max(wv.x, zbeg), wh = min(wv.y, zend - 1);
   int zl = 0x7fffffff, zh = -0x7fffffff;  // this lane's stored-plane range inside the padded frustum
-  if (wl <= wh && active) {
+  if (wv.z <= zbeg && wv.w >= zend - 1) {
+    // every column of the wave covers the whole chunk (the interior of the frustum: most working waves): no lane needs
+    // its own range
+    if (active) {
+      zl = zbeg;
+      zh = zend - 1;
+    }
+  } else if (wl <= wh && active) {
     const int2 zr = zint[(size_t)y * (vp.X / 4) + (x0 >> 2)];  // computed once per frame by k_column_zrange
     zl = max(zr.x, zbeg);
     zh = min(zr.y, zend - 1);
@@ -979,8 +993,11 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
 }
 
 // entries of the z-range tables: one int2 per lane column, then one per pass-A workgroup footprint (64 x 16 voxels), then
-// one per wave footprint (64 x 4 voxels: four per workgroup)
-size_t integrate_zint_entries(const VolParams& vp) { return (size_t)(vp.X / 4) * vp.Y + (size_t)5 * ((vp.X + 63) / 64) * ((vp.Y + 15) / 16); }
+// an int4 per wave footprint (64 x 4 voxels: four per workgroup)
+size_t integrate_zint_entries(const VolParams& vp) {
+  const size_t fp = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16);
+  return (size_t)(vp.X / 4) * vp.Y + ((fp + 1) & ~(size_t)1) + 8 * fp;  // (the wave table is int4: kept 16-B aligned)
+}
 // words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
 size_t integrate_queue_words(const VolParams& vp) {
   const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
