@@ -134,32 +134,49 @@ uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], flo
   const float tau_inv = 1.0f / tau;
   const float i00 = R[0], i01 = R[3], i02 = R[6], i10 = R[1], i11 = R[4], i12 = R[7], i20 = R[2], i21 = R[5], i22 = R[8];
   uint64_t n_upd = 0;
+  /* (walked plane by plane for the memory's sake: the per-column accumulators are kept in arrays, the terms that are the
+   * same for every column -- gz, z_scaled -- as scalars; the additions are the ones the column-wise loop would make) */
+  const size_t ncol = (size_t)X * Y;
+  float* acc = (float*)malloc(ncol * 4 * sizeof(float)); /* vx, vy (advanced), vz, part_norm (fixed) per column */
+  float *avx = acc, *avy = acc + ncol, *avz = acc + 2 * ncol, *apn = acc + 3 * ncol;
+  const float gz0 = ((float)zs0 + 0.5f) * cellz - t[2];
+  const float dx = i02 * cellz * fx, dy = i12 * cellz * fy;
 #ifdef _OPENMP
-#pragma omp parallel for reduction(+ : n_upd) schedule(static)
+#pragma omp parallel for schedule(static)
 #endif
   for (int y = 0; y < Y; ++y)
     for (int x = 0; x < X; ++x) {
       const float gx = ((float)x + 0.5f) * cellx - t[0];
       const float gy = ((float)y + 0.5f) * celly - t[1];
-      float gz = ((float)zs0 + 0.5f) * cellz - t[2];
-      const float part_norm = gx * gx + gy * gy;
-      float vx = (i00 * gx + i01 * gy + i02 * gz) * fx;
-      float vy = (i10 * gx + i11 * gy + i12 * gz) * fy;
-      const float vz = i20 * gx + i21 * gy + i22 * gz;
-      float z_scaled = 0.0f;
-      const float dx = i02 * cellz * fx, dy = i12 * cellz * fy;
-      for (int zz = 0; zz < nzs; ++zz, gz += cellz, z_scaled += cellz, vx += dx, vy += dy) {
-        const float inv_z = 1.0f / (vz + i22 * z_scaled);
+      const size_t c = (size_t)y * X + x;
+      avx[c] = (i00 * gx + i01 * gy + i02 * gz0) * fx;
+      avy[c] = (i10 * gx + i11 * gy + i12 * gz0) * fy;
+      avz[c] = i20 * gx + i21 * gy + i22 * gz0;
+      apn[c] = gx * gx + gy * gy;
+    }
+  float gz = gz0, z_scaled = 0.0f;
+  for (int zz = 0; zz < nzs; ++zz, gz += cellz, z_scaled += cellz) {
+    const float zterm = i22 * z_scaled, gz2 = gz * gz;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : n_upd) schedule(static)
+#endif
+    for (int y = 0; y < Y; ++y)
+      for (int x = 0; x < X; ++x) {
+        const size_t c = (size_t)y * X + x;
+        const float vx = avx[c], vy = avy[c];
+        avx[c] = vx + dx; /* the advance of the loop header: made whether or not the voxel is updated */
+        avy[c] = vy + dy;
+        const float inv_z = 1.0f / (avz[c] + zterm);
         if (inv_z < 0.0f) continue;
         int u, v;
         if (!rint_guard(vx * inv_z + cx, &u) || !rint_guard(vy * inv_z + cy, &v)) continue;
         if (u < 0 || v < 0 || u >= W || v >= H) continue;
         const float Ds = scaled[v * W + u];
-        const float sdf = Ds - sqrtf(gz * gz + part_norm);
+        const float sdf = Ds - sqrtf(gz2 + apn[c]);
         if (Ds != 0.0f && sdf >= -tau) {
           float F = sdf * tau_inv;
           F = F < 1.0f ? F : 1.0f;
-          int16_t* vox = vol + 2 * (((size_t)zz * Y + y) * X + x);
+          int16_t* vox = vol + 2 * ((size_t)zz * ncol + c);
           const float Fp = (float)vox[0] / 32767.0f, Wp = (float)vox[1];
           const float Fn = (Fp * Wp + F) / (Wp + 1.0f);
           int wn = vox[1] + 1;
@@ -172,7 +189,8 @@ uint64_t ora_integrate(int16_t* vol, const int dims[3], const float size[3], flo
           ++n_upd;
         }
       }
-    }
+  }
+  free(acc);
   return n_upd;
 }
 #else
