@@ -11,8 +11,17 @@ trk = hsk.KinfuTracker(n=int(sys.argv[1]) if len(sys.argv) > 1 else 512, use_gra
 for k in range(40):
     trk.process_frame(hsk.synth_depth(hsk.synth_pose(k)))
 lib = C.CDLL(_lib.LIB_PATH)
-t = np.zeros((4800, 6), np.uint64)
-rc = lib.hsk_debug_rc_times(C.c_void_p(t.ctypes.data), 4800 * 6)
+tall = np.zeros((8192, 6), np.uint64)
+rc = lib.hsk_debug_rc_times(C.c_void_p(tall.ctypes.data), 8192 * 6)
+t = tall[:4800].copy()
+helpers = tall[4800:4800 + 1024]
+hl = helpers[helpers[:, 3] > 0]
+if len(hl):   # helper waves of the splitting raycast (workgroups behind the tiles' own)
+    h0 = tall[:4800, 0].min()
+    hs = hl[:, :4].astype(np.float64) / 100.0
+    print("helper waves that marched: %d; start %.1f..%.1f us, life mean %.1f max %.1f, end mean %.1f max %.1f; trips mean %.0f" % (
+        len(hl), (hs[:, 0] - h0 / 100.0).min(), (hs[:, 0] - h0 / 100.0).max(), (hs[:, 3] - hs[:, 0]).mean(), (hs[:, 3] - hs[:, 0]).max(),
+        (hs[:, 3] - h0 / 100.0).mean(), (hs[:, 3] - h0 / 100.0).max(), hl[:, 4].mean()))
 trips, gtrips = t[:, 4].astype(np.int64), t[:, 5].astype(np.int64)
 t = t[:, :4].astype(np.float64) / 100.0   # s_memrealtime ticks at 100 MHz -> us
 t0 = t[:, 0].min()
