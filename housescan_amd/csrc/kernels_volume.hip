@@ -22,7 +22,7 @@
 #define HSK_NQUEUES 256       // uncertain lane-blocks are spread over this many queues (pass A -> pass B)
 #define HSK_QCOUNT_STRIDE 64  // words between two queue counters (256 B: one counter per memory-side atomic line)
 #ifndef INTEGRATE_WPE
-#define INTEGRATE_WPE 6  // waves per SIMD the register allocator must leave room for (79 VGPRs, no spills)
+#define INTEGRATE_WPE 6  // waves per SIMD the register allocator must leave room for (pass A takes 48 VGPRs today: 8 waves fit)
 #endif
 #ifndef INTEGRATE_ZCHUNK
 #define INTEGRATE_ZCHUNK 8
