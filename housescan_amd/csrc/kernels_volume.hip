@@ -914,6 +914,16 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
 #define DETAIL2_GX 5  // DETAIL2_GX x 256 queues x 4 waves: one resident round of the chip at 8 waves per SIMD
 #endif
 
+#ifdef HSK_PB_TIMING
+// timing build (tools/pb_timing.sh): per wave of pass B, s_memrealtime stamps: start, prologue done, after each trip (up to 4)
+__device__ unsigned long long g_pb_times[8192 * 8];
+extern "C" int hsk_debug_pb_times(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pb_times), (size_t)n * 8);
+}
+#define PB_STAMP(k) do { if (!COUNT_ONLY && lane == 0 && pb_wave < 8192u) g_pb_times[pb_wave * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PB_STAMP(k) do { } while (0)
+#endif
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* __restrict__ vol, const float* __restrict__ scaled,
                                                                         const TrackState* __restrict__ st, VolParams vp, int W,
@@ -924,6 +934,13 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* _
                                                                         const unsigned* __restrict__ qcount, unsigned qcap) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
+#ifdef HSK_PB_TIMING
+  const unsigned pb_wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (!COUNT_ONLY && lane == 0 && pb_wave < 8192u)
+    for (int q = 0; q < 8; ++q) g_pb_times[pb_wave * 8 + q] = 0ull;
+  int pb_trip = 0;
+#endif
+  PB_STAMP(0);
   // The HSK_NQUEUES queues are walked as ONE list (their lengths differ by 1.6x: a grid that strides over each queue
   // by itself ends with the longest queue's last round, a third of the chip idle).  Every block scans the 256 counters
   // once (LDS prefix array); an entry's queue is then found by bisection.
@@ -949,6 +966,7 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* _
   const unsigned n = pre[HSK_NQUEUES];
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned long long cnt = 0;
+  PB_STAMP(1);
   const DetailPose P = detail_pose(st);
   const int qx = vp.X / 4;
   auto entry_at = [&](unsigned g) -> unsigned {  // g-th entry of the concatenated queues (0 beyond the end)
@@ -971,6 +989,11 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* _
     const int x0 = (int)(lb % (unsigned)qx) * 4, y = (int)((lb / (unsigned)qx) % (unsigned)vp.Y);
     const int zb = (int)(lb / ((unsigned)qx * (unsigned)vp.Y)) * 4;
     cnt += detail_entry<COUNT_ONLY, DETAIL2_U>(id >> 28, x0, y, zb, vol, scaled, P, vp, W, H, in, flags);
+#ifdef HSK_PB_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pb_trip < 5) PB_STAMP(2 + pb_trip);
+    ++pb_trip;
+#endif
   }
   if (COUNT_ONLY) {
 #pragma unroll
