@@ -1252,6 +1252,16 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #endif                  // waves of a 640x480 frame spread evenly over the SIMDs.  Measured 512^3 / 1024^3 (us): 64 threads
                         // 99 / 124, 128: 107 / 126, 256: 99 / 131, 512: 107 / 142.  With 512-thread blocks and a 32 KiB
                         // bitfield 88 of the 256 CUs got a third block and the kernel waited for them (raycast_analysis.md).
+#ifndef RC_WPE
+#define RC_WPE 5  // waves per SIMD the register allocator must leave room for (96 VGPRs): the 4800 tiles of a 640x480 frame are all resident at five (5120 slots), and six would cost spills
+#endif
+#ifndef RC_PRIO
+#define RC_PRIO 0
+#endif
+#ifndef RC_EXT
+#define RC_EXT 3       // further clear super-bricks a crossing may run on through
+#endif
+#define RC_SKIP_MAX (64.0f * (RC_EXT + 1))  // most steps crossed at once
 #ifndef RC_SKIP
 #define RC_SKIP 3      // fewest steps worth crossing at once inside a clear super-brick
 #endif
@@ -1259,15 +1269,109 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #define RC_GROUP 4     // march steps located and gathered together (k_raycast)
 #endif
 #define RC_STAGE_MAX 4  // 16-B loads per thread: 4 KiB / (64 x 16 B); larger bitfields take the loop below
-template <bool SLAB>  // SLAB: this context stores / owns only part of the z range (multi-GPU)
-__global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__ vol, const TrackState* __restrict__ st,
-                                                 VolParams vp, int W, int H, Intr in, float* __restrict__ vmap,
-                                                 float* __restrict__ nmap, int* __restrict__ keys,
-                                                 const unsigned* __restrict__ flags, int flag_words, MapPyramid pyr,
-                                                 RingOut ring) {
+// minimum over the 64 lanes of a wave whose lanes are ALL active, as a wave-uniform value: four DPP steps inside each row of
+// 16 lanes, two row broadcasts, one v_readlane (six ds_bpermute round trips through the LDS crossbar before)
+static __device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror: every lane holds its row's minimum
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// What the kernel needs only AFTER the march (the maps it writes, the pyramid levels): kept out of the march loop's
+// scalar registers.  The compiler loads every kernel argument it uses in the entry block and keeps it there; the march
+// loop already needs ~100 SGPRs (uniform volume constants plus a saved lane mask per level of divergent control flow),
+// so the 16 that these pointers took were spilled into VGPR lanes (v_writelane / v_readlane inside the loop, and VGPRs
+// the loop does not have: it sits at the 80-register edge of six waves per SIMD).  They are therefore the LAST member
+// of the argument block and read through the kernarg segment pointer after the loop.
+struct RcTail {
+  float* vmap;
+  float* nmap;
+  int* keys;
+  MapPyramid pyr;
+  int W, H;
+};
+struct RcArgs {
+  const short2* vol;
+  const TrackState* st;
+  VolParams vp;
+  int W, H;
+  Intr in;
+  const unsigned* flags;
+  int flag_words;
+  RingOut ring;
+  RcTail tail;   // never touched by name inside the kernel
+  RaySplit rs;   // nor this (SPLIT only): every use fetches the fields it needs
+};
+#ifndef RC_WPE_SPLIT
+#define RC_WPE_SPLIT 5
+#endif
+#ifndef RC_SPLIT_TRIPS
+#define RC_SPLIT_TRIPS 56  // a tile whose wave made more trips than this asks for a helper in the next launch
+#endif
+// a member of the argument block fetched where it is used (see RcTail)
+#define RC_ARG(type, member) (*(const type*)(rc_kernarg() + offsetof(RcArgs, member)))
+static __device__ __forceinline__ const char* rc_kernarg() {
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  return ka;
+}
+// SLAB: this context stores / owns only part of the z range (multi-GPU).
+// SPLIT: the launch ends with its longest waves -- grazing rays over floor and ceiling, 80-100 trips of ~1 us each, a
+// dependent chain that a lone wave cannot issue faster (profiles/r02/raycast_split_experiment.md) -- while the chip has
+// been idle for a third of the launch.  A chain only gets shorter by being cut: a tile whose wave was long in the
+// PREVIOUS launch gets a second, helper wave in this one (workgroups behind the tiles' own; at most HSK_RS_MAX), which
+// marches the same 64 rays from the step at which the tile's wave was half-way through its trips last time (the ray
+// parameter there by the same float additions, the near sample being the far sample of the step before) and leaves key,
+// vertex and normal in a side buffer.  The tile's own wave, once past that step, looks whether the helper has finished
+// (never waits for it): if so its still-marching rays adopt the helper's results -- exactly what they would have found
+// themselves, both being the same deterministic march -- and if not it simply goes on.  Nothing but the tiles that asked
+// pays anything, and the results are bit-identical whichever wave gets there first.
+template <bool SLAB, bool SPLIT>
+__global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_raycast(RcArgs a) {
+  const short2* __restrict__ vol = a.vol;
+  const TrackState* __restrict__ st = a.st;
+  const VolParams& vp = a.vp;
+  const int W = a.W, H = a.H;
+  const Intr& in = a.in;
+  const unsigned* __restrict__ flags = a.flags;
+  const int flag_words = a.flag_words;
+  const RingOut& ring = a.ring;
+#if RC_PRIO
+  asm volatile("s_cmp_lt_u32 %0, %1\n\ts_cbranch_scc0 1f\n\ts_setprio 3\n\ts_branch 2f\n1:\n\ts_cmp_lt_u32 %0, %2\n\ts_cbranch_scc0 2f\n\ts_setprio 1\n2:"
+               :: "s"(blockIdx.x), "s"(RC_PRIO * 80), "s"(2 * RC_PRIO * 80) : "scc");
+#endif
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];
+  static_assert(!SPLIT || RC_BLOCK == 64, "helper waves are single-wave workgroups");
+  int tile_sel = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  bool helper = false, helped = false;
+  unsigned my_slot = 0u;
+  int split_at = 0;
+  if (SPLIT) {
+    const RaySplit rs = RC_ARG(RaySplit, rs);
+    const int n_tiles = ((W + 7) >> 3) * ((H + 7) >> 3);
+    if (blockIdx.x == 0 && threadIdx.x == 0) rs.count[(rs.gen + 1u) % 3u] = 0u;  // the list the NEXT launch appends to
+    if (tile_sel >= n_tiles) {
+      const unsigned e = (unsigned)(tile_sel - n_tiles), from = (rs.gen + 2u) % 3u;  // the previous launch's list
+      if (e >= min(rs.count[from], (unsigned)HSK_RS_MAX)) return;
+      tile_sel = (int)rs.list[from * HSK_RS_MAX + e];
+      helper = true;
+      my_slot = e;
+      split_at = rs.split_step[tile_sel];
+      if (split_at < 1) return;
+    } else {
+      if (rs.stamp[tile_sel] == rs.gen - 1u) {
+        my_slot = rs.slot_of[tile_sel];
+        split_at = rs.split_step[tile_sel];
+        helped = split_at >= 1 && my_slot < (unsigned)HSK_RS_MAX;
+      }
+    }
+  }
 #ifdef HSK_RC_TIMING
   const int tile_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1298,7 +1402,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   const int lane = threadIdx.x & 63;
 #endif
   RC_STAMP(1);
-  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int tile = tile_sel;
   const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
   // Tile rows are dispatched from the top and bottom edges of the image inwards (0, last, 1, last - 1, ...): the rays of
   // the border rows meet floor and ceiling at grazing angles and march longest, and a wave dispatched last onto a SIMD
@@ -1308,7 +1412,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   const int ty = (ty_lin & 1) ? (tiles_y - 1 - (ty_lin >> 1)) : (ty_lin >> 1);
   const int x = (tile % tiles_x) * 8 + (lane & 7);
   const int y = ty * 8 + (lane >> 3);
-  if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0 && !helper) {
     // the tracker state is final once the ICP has ended (nothing after it writes it): report it to the host now, also
     // for a lost or dropped frame, which returns just below
     const unsigned n = *ring.seq;
@@ -1320,10 +1424,13 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     __threadfence_system();     // the state words reach the host before the mark that announces them
     __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (x >= W || y >= H) return;  // (with a fused pyramid every tile is complete: launch_raycast checks W, H % 8)
+  // Lanes outside the image (a ragged last tile) and lanes whose ray misses the volume stay in the wave as rays that have
+  // ended: every lane is then active at the top of the march loop, which lets its wave-wide decisions use DPP
+  // reductions read from a fixed lane, and takes one level of divergent control flow out of the loop.
+  const bool in_img = x < W && y < H;
   if (st->lost) return;
   const size_t P = (size_t)W * H;
-  const size_t i = (size_t)y * W + x;
+  const size_t i = in_img ? (size_t)y * W + x : 0;
   float vx = HSK_NANF, vy = HSK_NANF, vz = HSK_NANF, nx = HSK_NANF, ny = HSK_NANF, nz = HSK_NANF;
   int key = HSK_KEY_NONE_I;
 
@@ -1345,7 +1452,10 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   float t_start = fmaxf(fmaxf(tmin0, tmin1), tmin2);
   const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
   t_start = fmaxf(t_start, 0.0f);
-  if (t_start < t_exit) {
+  bool take = false;         // SPLIT: this lane's result is its helper's (it was still marching when the helper had finished)
+  unsigned trips_w = 0u;     // ... trips of the wave's march
+  int step_w = 0;            // ... step this lane's march got to
+  {
     const float ic0 = 1.0f / vp.cell[0], ic1 = 1.0f / vp.cell[1], ic2 = 1.0f / vp.cell[2];
     const int bs = vp.bshift;
     const int bxn = vp.X >> bs, byn = vp.Y >> bs;
@@ -1353,6 +1463,11 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     const float max_time = 3.0f * ((vp.size[0] + vp.size[1]) + vp.size[2]);
     float time_curr = t_start;
     int step = 0;
+    if (SPLIT && helper) {
+      // the ray parameter the march has at step split_at: the same additions, one after another
+      for (int s_ = 0; s_ < split_at && time_curr < max_time; ++s_) time_curr = time_curr + time_step;
+      step = split_at;
+    }
     // near sample of step 0: the entry voxel, clamped into the grid (A.6)
     int qx = vox_fast(t0 + d0 * time_curr, vp.cell[0], ic0);
     int qy = vox_fast(t1 + d1 * time_curr, vp.cell[1], ic1);
@@ -1396,7 +1511,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
       return (unsigned)gx < (unsigned)vp.X && (unsigned)gy < (unsigned)vp.Y && (unsigned)gz < (unsigned)vp.Z;
     };
 #ifdef HSK_RC_TIMING
-    unsigned trips = 0, gtrips = 0;
+    unsigned trips = 0, gtrips = 0;        // acted steps; acted steps that compared voxels (per lane)
+    unsigned it_all = 0, it_skip = 0, it_empty = 0;  // loop iterations; crossings; regular trips in which no lane gathered (wave)
 #endif
     // The march advances RC_GROUP steps per trip.  A step that lies next to a flagged brick needs its two voxels, and a
     // wave whose lanes reach such bricks at different steps used to stop for a memory round trip (~0.9 us under load) at
@@ -1406,7 +1522,22 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     // one batch -- the same voxels the step-by-step march reads, no others -- and the steps are then acted on in order
     // with the values in registers: one round trip per RC_GROUP steps instead of up to RC_GROUP.  Same decisions, same
     // ray parameters ((time_curr + time_step) + time_step ...), so the maps are bit-identical.
-    bool ended = false;
+    bool ended = !(in_img && t_start < t_exit);
+    if (SPLIT && helper) {
+      // the near sample of step split_at is the far sample of the step before: the voxel of the sample at time_curr, by the
+      // march's own rule; a ray that has left the grid by then ended earlier in the tile's own wave
+      int hx, hy, hz;
+      const bool inside = time_curr < max_time && far_voxel(time_curr, hx, hy, hz);
+      if (inside) {
+        px = hx; py = hy; pz = hz;
+        fl_prev = flag_at(px, py, pz);
+      }
+      first = false;
+      ended = ended || !inside;
+    }
+    unsigned trips_n = 0u;   // SPLIT: trips of this wave (the cost the next launch's helper decision goes by)
+    const int look_from = (SPLIT && helped) ? split_at : 0x7fffffff;  // ... first step at which the helper's result applies
+    bool adopted = false;    // ... left the loop because the helper has finished: the still-marching lanes take its results
     // Crossing clear super-bricks: when the near sample of EVERY marching lane of the wave sits in a super-brick (4^3
     // bricks) none of whose bricks has held a negative TSDF, and every lane's ray stays inside its super-brick for the
     // next RC_SKIP steps with two steps to spare, none of those steps can gather or end -- their only effect is to
@@ -1414,13 +1545,28 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
     // sample once.  The decision is wave-wide (the 64 rays of an 8x8 tile are a few centimetres apart, so they cross the
     // same super-bricks together; per-lane skipping made every trip pay for both paths: raycast_analysis.md).
     const bool can_skip = !SLAB && hsk_super_ok(vp);
-    const int ss = bs + HSK_SUPER_SHIFT, sxn = hsk_super_dim(vp.X, bs), syn = hsk_super_dim(vp.Y, bs);
+    const int ss = bs + HSK_SUPER_SHIFT, sxn = hsk_super_dim(vp.X, bs), syn = hsk_super_dim(vp.Y, bs), szn = hsk_super_dim(vp.Z, bs);
     const float s_edge0 = (float)(1 << ss) * vp.cell[0], s_edge1 = (float)(1 << ss) * vp.cell[1], s_edge2 = (float)(1 << ss) * vp.cell[2];
     const float id0 = 1.0f / d0, id1 = 1.0f / d1, id2 = 1.0f / d2;
     const float inv_step = 1.0f / time_step;
     // (a wave-wide loop: lanes whose ray has ended idle inside it, so that the wave-wide minimum below can use shuffles)
     while (__ballot(!ended && time_curr < max_time) != 0ull) {
+      if (SPLIT) {
+        ++trips_n;
+        // Every fourth trip, once no marching lane is short of the helper's first step (the lanes march in lockstep, so it
+        // is all of them or none): has the helper finished?  The look is a memory round trip, never a wait.
+        if (look_from != 0x7fffffff && (trips_n & 3u) == 0u && __ballot(!ended && time_curr < max_time && step < look_from) == 0ull) {
+          const unsigned d = __hip_atomic_load(RC_ARG(unsigned*, rs.done) + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)__builtin_amdgcn_readfirstlane((int)d) == RC_ARG(unsigned, rs.gen)) {
+            adopted = true;
+            break;
+          }
+        }
+      }
       const bool act = !ended && time_curr < max_time;
+#ifdef HSK_RC_TIMING
+      ++it_all;
+#endif
       if (can_skip) {
         const int s0 = px >> ss, s1 = py >> ss, s2 = pz >> ss;
         const int sbit = (s2 * syn + s1) * sxn + s0;
@@ -1430,17 +1576,47 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
         int n = 0;
         if (__ballot(act && !clear) == 0ull) {
           // ray parameter at which the ray leaves the super-brick (approximate; two spare steps absorb the error)
-          const float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * s_edge0 - t0) * id0;
-          const float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * s_edge1 - t1) * id1;
-          const float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * s_edge2 - t2) * id2;
-          const float room = (fminf(fminf(e0, e1), e2) - time_curr) * inv_step - 2.0f;
-          n = !act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, 64.0f) : 0);
+          float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * s_edge0 - t0) * id0;
+          float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * s_edge1 - t1) * id1;
+          float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * s_edge2 - t2) * id2;
+          float te = fminf(fminf(e0, e1), e2);
+#if RC_EXT > 0
+          // ... and on through up to RC_EXT further super-bricks while they are clear too (open air: the regular trip that
+          // used to carry the march across every face between two clear super-bricks is most of what a room costs).  The
+          // next super-brick is the one behind the face the ray leaves by; that is certain only when the runner-up face
+          // lies at least two steps later (near an edge or corner the float exit times may order wrongly, and the ray
+          // could cut through a third, flagged super-brick): otherwise the crossing ends here, as before.
+          {
+            int c0 = s0, c1 = s1, c2 = s2;
+            bool live = act;
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) n = min(n, __shfl_xor(n, o, 64));
+            for (int k = 0; k < RC_EXT; ++k) {
+              const bool a0 = e0 <= e1 && e0 <= e2, a1 = !a0 && e1 <= e2, a2 = !a0 && !a1;
+              const float second = a0 ? fminf(e1, e2) : (a1 ? fminf(e0, e2) : fminf(e0, e1));
+              const int n0 = c0 + (a0 ? (d0 > 0.0f ? 1 : -1) : 0), n1 = c1 + (a1 ? (d1 > 0.0f ? 1 : -1) : 0),
+                        n2 = c2 + (a2 ? (d2 > 0.0f ? 1 : -1) : 0);
+              live = live && (second - te >= 2.0f * time_step) && (unsigned)n0 < (unsigned)sxn && (unsigned)n1 < (unsigned)syn &&
+                     (unsigned)n2 < (unsigned)szn;
+              const int nb = live ? (n2 * syn + n1) * sxn + n0 : 0;
+              live = live && !((lflags[flag_words + (nb >> 5)] >> (nb & 31)) & 1u);
+              if (live) {
+                c0 = n0; c1 = n1; c2 = n2;
+                e0 = a0 ? e0 + s_edge0 * fabsf(id0) : e0;
+                e1 = a1 ? e1 + s_edge1 * fabsf(id1) : e1;
+                e2 = a2 ? e2 + s_edge2 * fabsf(id2) : e2;
+                te = fminf(fminf(e0, e1), e2);
+              }
+            }
+          }
+#endif
+          const float room = (te - time_curr) * inv_step - 2.0f;
+          n = wave_min_i32(!act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, RC_SKIP_MAX) : 0));
         }
         if (n >= RC_SKIP && n != 0x7fffffff) {  // wave-uniform
           float tc = time_curr;
-          for (int i = 0; i < n; ++i) tc = tc + time_step;
+          int i_ = 0;
+          for (; i_ + 4 <= n; i_ += 4) tc = (((tc + time_step) + time_step) + time_step) + time_step;  // (the march's own additions, in order)
+          for (; i_ < n; ++i_) tc = tc + time_step;
           int nx_, ny_, nz_;
           const bool fine = !act || (far_voxel(tc, nx_, ny_, nz_) && tc < max_time);
           if (__ballot(!fine) == 0ull) {
@@ -1451,6 +1627,9 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
               first = false;
               fl_prev = flag_at(px, py, pz);
             }
+#ifdef HSK_RC_TIMING
+            ++it_skip;
+#endif
             continue;
           }
         }
@@ -1460,6 +1639,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
       int vx_[RC_GROUP], vy_[RC_GROUP], vz_[RC_GROUP];
       bool okv[RC_GROUP], need[RC_GROUP];
       unsigned fl[RC_GROUP];
+      bool all_alive;
       {
         float tc = time_curr;
         bool alive = true;
@@ -1476,56 +1656,81 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
           fprev = fl[g];
           tc = tt[g];
         }
+        all_alive = alive;
+      }
+      bool any_need = false;
+#pragma unroll
+      for (int g = 0; g < RC_GROUP; ++g) any_need = any_need || need[g];
+      // Most trips outside the clear super-bricks still compare nothing (a flagged super-brick is mostly unflagged
+      // bricks): when every marching lane's RC_GROUP steps stay inside the grid, before max_time and away from flagged
+      // bricks, acting on them one by one comes to this.
+      if (__ballot(!(all_alive && !any_need)) == 0ull) {
+        px = vx_[RC_GROUP - 1]; py = vy_[RC_GROUP - 1]; pz = vz_[RC_GROUP - 1];
+        first = false;
+        fl_prev = fl[RC_GROUP - 1];
+        time_curr = tt[RC_GROUP - 1];
+        step += RC_GROUP;
+#ifdef HSK_RC_TIMING
+        trips += RC_GROUP;
+        ++it_empty;
+#endif
+        continue;
       }
       int raw[RC_GROUP + 1];  // raw[0]: the near sample of the first step; raw[g + 1]: the far sample of step g
 #pragma unroll
       for (int g = 0; g <= RC_GROUP; ++g) raw[g] = 0;
-      bool any_need = false;
-#pragma unroll
-      for (int g = 0; g < RC_GROUP; ++g) any_need = any_need || need[g];
       if (any_need) {
         if (need[0]) raw[0] = raw_at(vol, vp, px, py, pz);
 #pragma unroll
         for (int g = 0; g < RC_GROUP; ++g)
           if (need[g] || (g + 1 < RC_GROUP && need[g + 1])) raw[g + 1] = raw_at(vol, vp, vx_[g], vy_[g], vz_[g]);
       }
+      // Acting on the RC_GROUP steps in order, without branches: a step halts the lane when the march is past max_time, the
+      // far sample lies outside the grid (the ray ends), or the two voxels show a back face or a zero crossing; the steps
+      // before the first halt advance the lane.  (With a divergent branch and a break per step this was 85 instructions a
+      // step, most of them lane-mask bookkeeping; the same decisions as selects are 15.)
+      {
+        bool run = true, e_out = false, e_back = false, e_cross = false;
+        int adv = 0;
 #pragma unroll
-      for (int g = 0; g < RC_GROUP; ++g) {
-        if (ended || !(time_curr < max_time)) break;
+        for (int g = 0; g < RC_GROUP; ++g) {
+          const float tcur = g == 0 ? time_curr : tt[g - 1];
+          const bool on = run && (tcur < max_time);
+          const bool back = need[g] && raw[g] < 0 && raw[g + 1] > 0;
+          const bool cross = need[g] && raw[g] > 0 && raw[g + 1] < 0;
+          e_out = e_out || (on && !okv[g]);
+          e_back = e_back || (on && okv[g] && back);
+          e_cross = e_cross || (on && okv[g] && cross);
+          run = on && okv[g] && !back && !cross;
+          // the far sample of an advancing step is the next step's near sample
+          px = run ? vx_[g] : px;
+          py = run ? vy_[g] : py;
+          pz = run ? vz_[g] : pz;
+          fl_prev = run ? fl[g] : fl_prev;
+          time_curr = run ? tt[g] : time_curr;
+          adv += run ? 1 : 0;
 #ifdef HSK_RC_TIMING
-        ++trips;
+          trips += on ? 1 : 0;
+          gtrips += (on && okv[g] && need[g]) ? 1 : 0;
 #endif
-        if (!okv[g]) {
-          ended = true;
-          break;
         }
-        const int cxv = px, cyv = py, czv = pz;  // near sample of this step (inside the grid)
-        const bool was_first = first;
-        px = vx_[g]; py = vy_[g]; pz = vz_[g];   // the far sample is the next step's near sample
-        first = false;
-        fl_prev = fl[g];
-        if (need[g]) {
-#ifdef HSK_RC_TIMING
-          ++gtrips;
-#endif
-          const int raw_prev = raw[g], raw_far = raw[g + 1];
-          if (raw_prev < 0 && raw_far > 0) {  // back face
-            key = (step << 1) | 1;
-            ended = true;
-            break;
-          }
-          if (raw_prev > 0 && raw_far < 0) {  // zero crossing: refined below with every lane of the wave
-            crossing = true;
-            nux = was_first ? qx : cxv;
-            nuy = was_first ? qy : cyv;
-            nuz = was_first ? qz : czv;
-            ended = true;
-            break;
-          }
+        const bool was_first = first && adv == 0;
+        first = first && adv == 0;
+        step += adv;
+        if (e_back) key = (step << 1) | 1;
+        if (e_cross) {  // zero crossing: refined below with every lane of the wave; (px, py, pz) is the near sample of its step
+          crossing = true;
+          nux = was_first ? qx : px;
+          nuy = was_first ? qy : py;
+          nuz = was_first ? qz : pz;
         }
-        time_curr = tt[g];
-        ++step;
+        ended = ended || e_out || e_back || e_cross;
       }
+    }
+    if (SPLIT) {
+      take = adopted && !ended && time_curr < max_time;  // lanes whose result is the helper's
+      trips_w = trips_n;
+      step_w = step;
     }
     // Deferred hit processing: lanes hit at different steps, and refining inside the loop would run these
     // (memory-latency-bound) taps once per distinct step.  Here the wave runs them once, loads batched.
@@ -1533,14 +1738,18 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
 #ifdef HSK_RC_TIMING
     {
       // wave totals: the longest lane's trips, and the number of lanes-trips with gathers (max over lanes)
-      unsigned tmax = trips, gmax = gtrips;
+      unsigned tmax = trips, gmax = gtrips, ia = it_all, is = it_skip, ie = it_empty;
       for (int o = 32; o > 0; o >>= 1) {
         tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o, 64));
         gmax = max(gmax, (unsigned)__shfl_xor((int)gmax, o, 64));
+        ia = max(ia, (unsigned)__shfl_xor((int)ia, o, 64));
+        is = max(is, (unsigned)__shfl_xor((int)is, o, 64));
+        ie = max(ie, (unsigned)__shfl_xor((int)ie, o, 64));
       }
-      if (lane == 0 && tile_id < 8192) {
+      if (lane == (int)__builtin_ctzll(__ballot(true)) && tile_id < 8192) {
         g_rc_times[tile_id * 6 + 4] = tmax;
-        g_rc_times[tile_id * 6 + 5] = gmax;
+        g_rc_times[tile_id * 6 + 5] = (unsigned long long)(gmax & 0xffffu) | ((unsigned long long)(ia & 0xffffu) << 16) |
+                                      ((unsigned long long)(is & 0xffffu) << 32) | ((unsigned long long)(ie & 0xffffu) << 48);
       }
     }
 #endif
@@ -1570,13 +1779,83 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
       }
     }
   }
-  vmap[i] = vx;
-  vmap[P + i] = vy;
-  vmap[2 * P + i] = vz;
-  nmap[i] = nx;
-  nmap[P + i] = ny;
-  nmap[2 * P + i] = nz;
-  if (keys) keys[i] = key;
+  if (SPLIT) {
+    const RaySplit rs = RC_ARG(RaySplit, rs);
+    int smax = step_w, tmax = (int)trips_w, any_take = take ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      smax = max(smax, __shfl_xor(smax, o, 64));
+      tmax = max(tmax, __shfl_xor(tmax, o, 64));
+      any_take = max(any_take, __shfl_xor(any_take, o, 64));
+    }
+    if (helper) {
+      // the helper's rays: results into its slot (the trips it took in lane 0's spare word), then the mark that they are
+      // complete (release: the tile's own wave may be looking from another XCD, whose cache plain stores would not reach
+      // inside a launch)
+      int* __restrict__ r = rs.result + ((size_t)my_slot * 64 + lane) * 8;
+      __hip_atomic_store(r + 0, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 1, __float_as_int(vx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 2, __float_as_int(vy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 3, __float_as_int(vz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 4, __float_as_int(nx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 5, __float_as_int(ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 6, __float_as_int(nz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r + 7, tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_store(&rs.done[tile], rs.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      RC_STAMP(3);
+      return;
+    }
+    // What this tile cost, for the next launch: its own trips plus its helper's.  When they were many it asks for a helper
+    // again, which starts where the two waves would have shared the trips evenly: grazing rays do not cross clear
+    // super-bricks, so the later trips are RC_GROUP steps each.  (Any start is correct; this one balances.)
+    const int* __restrict__ r = rs.result + ((size_t)my_slot * 64 + lane) * 8;
+    if (lane == 0) {
+      const int t_help = any_take ? __hip_atomic_load(r + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      if (tmax + t_help > RC_SPLIT_TRIPS) {
+        int at_step = any_take ? split_at + ((t_help - tmax) / 2) * RC_GROUP : smax - (tmax / 2) * RC_GROUP;
+        at_step = max(at_step, 1);
+        const unsigned at = atomicAdd(&rs.count[rs.gen % 3u], 1u);
+        if (at < (unsigned)HSK_RS_MAX) {
+          rs.list[(rs.gen % 3u) * HSK_RS_MAX + at] = (unsigned)tile;
+          rs.slot_of[tile] = at;
+          rs.split_step[tile] = at_step;
+          rs.stamp[tile] = rs.gen;
+        }
+      }
+    }
+#ifdef HSK_RC_TIMING
+    if (lane == 0 && any_take && tile_id < 8192) g_rc_times[tile_id * 6 + 4] |= 1ull << 32;  // this tile adopted its helper's results
+#endif
+    if (take) {
+      // the helper has marched this ray from split_at on, and this lane had found nothing before that step: the helper's
+      // result is its result
+      key = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vx = __int_as_float(__hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      vy = __int_as_float(__hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      vz = __int_as_float(__hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      nx = __int_as_float(__hip_atomic_load(r + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      ny = __int_as_float(__hip_atomic_load(r + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      nz = __int_as_float(__hip_atomic_load(r + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
+  // the tail of the argument block, fetched now (the empty asm hides where the pointer comes from, so the loads cannot
+  // be moved up across the march)
+  const RcTail tl = RC_ARG(RcTail, tail);
+  float* __restrict__ vmap = tl.vmap;
+  float* __restrict__ nmap = tl.nmap;
+  int* __restrict__ keys = tl.keys;
+  const MapPyramid pyr = tl.pyr;
+  if (in_img) {
+    vmap[i] = vx;
+    vmap[P + i] = vy;
+    vmap[2 * P + i] = vz;
+    nmap[i] = nx;
+    nmap[P + i] = ny;
+    nmap[2 * P + i] = nz;
+    if (keys) keys[i] = key;
+  }
   RC_STAMP(3);
   if (!SLAB && pyr.v1) {
     // Model pyramid (resizeVMap / resizeNMap, A.3) from the wave's own 8x8 tile: level 1 is the 2x2 mean held by
@@ -1601,8 +1880,30 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(const short2* __restrict__
   }
 }
 
+// device words of the helper-wave bookkeeping (RaySplit), and the struct over one zeroed allocation of that size
+size_t raycast_split_words(int W, int H) {
+  const size_t tiles = (size_t)((W + 7) / 8) * ((H + 7) / 8);
+  return 5 * tiles + 3 * (size_t)HSK_RS_MAX + 4 + (size_t)HSK_RS_MAX * 64 * 8;
+}
+RaySplit raycast_split_view(void* base, int W, int H, unsigned gen) {
+  const size_t tiles = (size_t)((W + 7) / 8) * ((H + 7) / 8);
+  unsigned* w = (unsigned*)base;
+  RaySplit r;
+  r.stamp = w;
+  r.slot_of = w + tiles;
+  r.split_step = (int*)(w + 2 * tiles);
+  r.prev_trips = w + 3 * tiles;
+  r.done = w + 4 * tiles;
+  r.list = w + 5 * tiles;
+  r.count = r.list + 3 * (size_t)HSK_RS_MAX;
+  r.result = (int*)(r.count + 4);
+  r.gen = gen;
+  return r;
+}
+
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring) {
+                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring,
+                    const RaySplit* split) {
   const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
   dim3 block(RC_BLOCK);
   dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
@@ -1610,12 +1911,30 @@ void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const 
   const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
   const MapPyramid none = {nullptr, nullptr, nullptr, nullptr};
   const RingOut quiet = {nullptr, nullptr, nullptr};
+  RcArgs a;
+  a.vol = (const short2*)vol;
+  a.st = st;
+  a.vp = vp;
+  a.W = W;
+  a.H = H;
+  a.in = in;
+  a.flags = flags;
+  a.flag_words = words;
+  a.ring = (!slab && ring) ? *ring : quiet;
+  a.tail.vmap = vmap;
+  a.tail.nmap = nmap;
+  a.tail.keys = keys;
+  a.tail.pyr = (!slab && pyramid) ? *pyramid : none;
+  a.tail.W = W;
+  a.tail.H = H;
+  const RaySplit off = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+  a.rs = (!slab && split) ? *split : off;
   if (slab)
-    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, (const short2*)vol, st, vp, W, H, in, vmap, nmap,
-                       keys, flags, words, none, quiet);
+    hipLaunchKernelGGL((k_raycast<true, false>), grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
+  else if (a.rs.stamp && RC_BLOCK == 64 && (W % 8) == 0 && (H % 8) == 0)
+    hipLaunchKernelGGL((k_raycast<false, true>), dim3(tiles + HSK_RS_MAX), block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
   else
-    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, (const short2*)vol, st, vp, W, H, in, vmap,
-                       nmap, keys, flags, words, pyramid ? *pyramid : none, ring ? *ring : quiet);
+    hipLaunchKernelGGL((k_raycast<false, false>), grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
 }
 // the fused pyramid needs complete 8x8 tiles and a single-device volume
 bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H) {

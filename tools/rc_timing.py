@@ -22,7 +22,16 @@ if len(hl):   # helper waves of the splitting raycast (workgroups behind the til
     print("helper waves that marched: %d; start %.1f..%.1f us, life mean %.1f max %.1f, end mean %.1f max %.1f; trips mean %.0f" % (
         len(hl), (hs[:, 0] - h0 / 100.0).min(), (hs[:, 0] - h0 / 100.0).max(), (hs[:, 3] - hs[:, 0]).mean(), (hs[:, 3] - hs[:, 0]).max(),
         (hs[:, 3] - h0 / 100.0).mean(), (hs[:, 3] - h0 / 100.0).max(), hl[:, 4].mean()))
-trips, gtrips = t[:, 4].astype(np.int64), t[:, 5].astype(np.int64)
+adopted = (t[:, 4] >> np.uint64(32)).astype(np.int64) & 1
+print("tiles that adopted their helper's results:", int(adopted.sum()))
+trips = (t[:, 4] & np.uint64(0xffffffff)).astype(np.int64)
+gtrips = (t[:, 5] & np.uint64(0xffff)).astype(np.int64)
+it_all = ((t[:, 5] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64)
+it_skip = ((t[:, 5] >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)
+it_empty = ((t[:, 5] >> np.uint64(48)) & np.uint64(0xffff)).astype(np.int64)
+it_reg = it_all - it_skip
+print("loop iterations per wave: mean %.1f p90 %.0f max %d = crossings %.1f + regular trips %.1f (of which no lane gathered: %.1f)" % (
+    it_all.mean(), np.percentile(it_all, 90), it_all.max(), it_skip.mean(), it_reg.mean(), it_empty.mean()))
 t = t[:, :4].astype(np.float64) / 100.0   # s_memrealtime ticks at 100 MHz -> us
 t0 = t[:, 0].min()
 stage, march, refine, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
@@ -40,5 +49,8 @@ print("trips: mean %.0f p50 %.0f p90 %.0f max %d; gather-trips mean %.0f max %d"
 A = np.stack([trips, gtrips, np.ones_like(trips)], axis=1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, march, rcond=None)
 print("march us ~ %.3f * trips + %.3f * gather_trips + %.1f" % tuple(coef))
+A2 = np.stack([it_skip, it_reg - it_empty, it_empty, np.ones_like(trips)], axis=1).astype(np.float64)
+c2, *_ = np.linalg.lstsq(A2, march, rcond=None)
+print("march us ~ %.2f * crossings + %.2f * gathering trips + %.2f * empty trips + %.1f" % tuple(c2))
 late = t[:, 2] - t0 > 70
 print("waves whose march ends after 70 us: %d, their trips mean %.0f gather-trips mean %.0f" % (late.sum(), trips[late].mean() if late.any() else 0, gtrips[late].mean() if late.any() else 0))
