@@ -98,21 +98,6 @@ struct PushDests {
   int n;
 };
 
-// Raycast: helper waves for the tiles whose march was long in the previous launch (k_raycast<false, true>).  All arrays
-// live in one device allocation of the context; `gen` counts the launches (>= 1).  Null `stamp`: no splitting.
-#define HSK_RS_MAX 1024  // helper workgroups per launch (tiles that may ask for one)
-struct RaySplit {
-  unsigned* stamp;       // [tiles] launch in which the tile asked for a helper (the helper runs in the NEXT launch)
-  unsigned* slot_of;     // [tiles] its place in that launch's list = the helper's result slot
-  int* split_step;       // [tiles] march step at which its helper starts
-  unsigned* prev_trips;  // [tiles] trips of the tile's wave in the previous launch
-  unsigned* done;        // [tiles] launch whose helper result is complete
-  unsigned* list;        // [3][HSK_RS_MAX] tiles that asked, by launch % 3
-  unsigned* count;       // [3]
-  int* result;           // [HSK_RS_MAX][64][8]: key, vertex, normal of the helper's 64 rays
-  unsigned gen;
-};
-
 #define HSK_NANF (__builtin_nanf(""))
 
 static __device__ __forceinline__ bool hsk_isnan(float x) { return x != x; }

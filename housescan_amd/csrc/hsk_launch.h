@@ -18,9 +18,7 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
                     float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid = nullptr,
-                    const RingOut* ring = nullptr, const RaySplit* split = nullptr);
-size_t raycast_split_words(int W, int H);                                    // helper-wave bookkeeping of k_raycast (RaySplit)
-RaySplit raycast_split_view(void* base, int W, int H, unsigned gen);         // ... over one zeroed allocation of that size
+                    const RingOut* ring = nullptr);
 bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H);
 void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                     int* bits, int P);

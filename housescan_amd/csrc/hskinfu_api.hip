@@ -58,8 +58,6 @@ struct hsk_ctx {
   float h_ws[169] = {};  // bilateral spatial weights (host copy: passed to the kernel by value)
   float* d_wc = nullptr;
   int* d_keys = nullptr;
-  void* d_raysplit = nullptr;        // raycast: helper-wave bookkeeping (RaySplit), zeroed at creation
-  unsigned ray_gen = 0;              // ... launches of the splitting raycast so far
   unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
   unsigned char* d_uni = nullptr;    // lane-block summaries (kernels_volume.hip: hsk_uniform_code), one byte per 4x1x4 voxels
   size_t uni_bytes = 0;
@@ -233,7 +231,6 @@ static void free_all(hsk_ctx* k) {
   F(k->d_wc);
   F(k->d_keys);
   F(k->d_flags);
-  F(k->d_raysplit);
   F(k->d_uni);
   F(k->d_zint);
   F(k->d_queue);
@@ -423,8 +420,6 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     return bail(HSK_ERR_ARG);
   }
   CK(hipMalloc((void**)&k->d_flags, k->flags_bytes));
-  CK(hipMalloc(&k->d_raysplit, raycast_split_words(c->width, c->height) * 4));
-  CK(hipMemset(k->d_raysplit, 0, raycast_split_words(c->width, c->height) * 4));
   k->uni_bytes = uniform_bytes(vp);
   CK(hipMalloc((void**)&k->d_uni, k->uni_bytes));
   // integrate queues: 256 counters on their own 256-B lines + 256 queues, each sized for its share of pass A's tiles
@@ -522,13 +517,8 @@ static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys, bool report = fals
   if (raycast_can_fuse_pyramid(k->vp, k->lv[0].W, k->lv[0].H)) {
     // the raycast writes levels 1 and 2 of the model maps from its own tiles: no second launch, no re-read
     const MapPyramid pyr = {k->d_vmod[1], k->d_nmod[1], k->d_vmod[2], k->d_nmod[2]};
-    // helper waves for the tiles that marched long in the previous frame (k_raycast<false, true>): eager launches only --
-    // the launch number is a kernel argument, which a captured graph would freeze
-    RaySplit split;
-    const bool use_split = !k->cfg.use_graph && keys == nullptr && getenv("HSK_RAYCAST_SPLIT") != nullptr;
-    if (use_split) split = raycast_split_view(k->d_raysplit, k->lv[0].W, k->lv[0].H, ++k->ray_gen);
     launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys, k->d_flags,
-                   &pyr, rp, use_split ? &split : nullptr);
+                   &pyr, rp);
     return;
   }
   launch_raycast(s, k->d_vol, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->d_vmod[0], k->d_nmod[0], keys, k->d_flags,

@@ -1259,7 +1259,7 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #define RC_PRIO 0
 #endif
 #ifndef RC_EXT
-#define RC_EXT 3       // further clear super-bricks a crossing may run on through
+#define RC_EXT 2       // further clear super-bricks a crossing may run on through
 #endif
 #define RC_SKIP_MAX (64.0f * (RC_EXT + 1))  // most steps crossed at once
 #ifndef RC_SKIP
@@ -1304,14 +1304,7 @@ struct RcArgs {
   int flag_words;
   RingOut ring;
   RcTail tail;   // never touched by name inside the kernel
-  RaySplit rs;   // nor this (SPLIT only): every use fetches the fields it needs
 };
-#ifndef RC_WPE_SPLIT
-#define RC_WPE_SPLIT 5
-#endif
-#ifndef RC_SPLIT_TRIPS
-#define RC_SPLIT_TRIPS 56  // a tile whose wave made more trips than this asks for a helper in the next launch
-#endif
 // a member of the argument block fetched where it is used (see RcTail)
 #define RC_ARG(type, member) (*(const type*)(rc_kernarg() + offsetof(RcArgs, member)))
 static __device__ __forceinline__ const char* rc_kernarg() {
@@ -1320,18 +1313,8 @@ static __device__ __forceinline__ const char* rc_kernarg() {
   return ka;
 }
 // SLAB: this context stores / owns only part of the z range (multi-GPU).
-// SPLIT: the launch ends with its longest waves -- grazing rays over floor and ceiling, 80-100 trips of ~1 us each, a
-// dependent chain that a lone wave cannot issue faster (profiles/r02/raycast_split_experiment.md) -- while the chip has
-// been idle for a third of the launch.  A chain only gets shorter by being cut: a tile whose wave was long in the
-// PREVIOUS launch gets a second, helper wave in this one (workgroups behind the tiles' own; at most HSK_RS_MAX), which
-// marches the same 64 rays from the step at which the tile's wave was half-way through its trips last time (the ray
-// parameter there by the same float additions, the near sample being the far sample of the step before) and leaves key,
-// vertex and normal in a side buffer.  The tile's own wave, once past that step, looks whether the helper has finished
-// (never waits for it): if so its still-marching rays adopt the helper's results -- exactly what they would have found
-// themselves, both being the same deterministic march -- and if not it simply goes on.  Nothing but the tiles that asked
-// pays anything, and the results are bit-identical whichever wave gets there first.
-template <bool SLAB, bool SPLIT>
-__global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_raycast(RcArgs a) {
+template <bool SLAB>
+__global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
   const short2* __restrict__ vol = a.vol;
   const TrackState* __restrict__ st = a.st;
   const VolParams& vp = a.vp;
@@ -1347,31 +1330,6 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];
-  static_assert(!SPLIT || RC_BLOCK == 64, "helper waves are single-wave workgroups");
-  int tile_sel = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  bool helper = false, helped = false;
-  unsigned my_slot = 0u;
-  int split_at = 0;
-  if (SPLIT) {
-    const RaySplit rs = RC_ARG(RaySplit, rs);
-    const int n_tiles = ((W + 7) >> 3) * ((H + 7) >> 3);
-    if (blockIdx.x == 0 && threadIdx.x == 0) rs.count[(rs.gen + 1u) % 3u] = 0u;  // the list the NEXT launch appends to
-    if (tile_sel >= n_tiles) {
-      const unsigned e = (unsigned)(tile_sel - n_tiles), from = (rs.gen + 2u) % 3u;  // the previous launch's list
-      if (e >= min(rs.count[from], (unsigned)HSK_RS_MAX)) return;
-      tile_sel = (int)rs.list[from * HSK_RS_MAX + e];
-      helper = true;
-      my_slot = e;
-      split_at = rs.split_step[tile_sel];
-      if (split_at < 1) return;
-    } else {
-      if (rs.stamp[tile_sel] == rs.gen - 1u) {
-        my_slot = rs.slot_of[tile_sel];
-        split_at = rs.split_step[tile_sel];
-        helped = split_at >= 1 && my_slot < (unsigned)HSK_RS_MAX;
-      }
-    }
-  }
 #ifdef HSK_RC_TIMING
   const int tile_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1402,7 +1360,7 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
   const int lane = threadIdx.x & 63;
 #endif
   RC_STAMP(1);
-  const int tile = tile_sel;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
   // Tile rows are dispatched from the top and bottom edges of the image inwards (0, last, 1, last - 1, ...): the rays of
   // the border rows meet floor and ceiling at grazing angles and march longest, and a wave dispatched last onto a SIMD
@@ -1412,7 +1370,7 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
   const int ty = (ty_lin & 1) ? (tiles_y - 1 - (ty_lin >> 1)) : (ty_lin >> 1);
   const int x = (tile % tiles_x) * 8 + (lane & 7);
   const int y = ty * 8 + (lane >> 3);
-  if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0 && !helper) {
+  if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0) {
     // the tracker state is final once the ICP has ended (nothing after it writes it): report it to the host now, also
     // for a lost or dropped frame, which returns just below
     const unsigned n = *ring.seq;
@@ -1452,9 +1410,6 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
   float t_start = fmaxf(fmaxf(tmin0, tmin1), tmin2);
   const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
   t_start = fmaxf(t_start, 0.0f);
-  bool take = false;         // SPLIT: this lane's result is its helper's (it was still marching when the helper had finished)
-  unsigned trips_w = 0u;     // ... trips of the wave's march
-  int step_w = 0;            // ... step this lane's march got to
   {
     const float ic0 = 1.0f / vp.cell[0], ic1 = 1.0f / vp.cell[1], ic2 = 1.0f / vp.cell[2];
     const int bs = vp.bshift;
@@ -1463,11 +1418,6 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
     const float max_time = 3.0f * ((vp.size[0] + vp.size[1]) + vp.size[2]);
     float time_curr = t_start;
     int step = 0;
-    if (SPLIT && helper) {
-      // the ray parameter the march has at step split_at: the same additions, one after another
-      for (int s_ = 0; s_ < split_at && time_curr < max_time; ++s_) time_curr = time_curr + time_step;
-      step = split_at;
-    }
     // near sample of step 0: the entry voxel, clamped into the grid (A.6)
     int qx = vox_fast(t0 + d0 * time_curr, vp.cell[0], ic0);
     int qy = vox_fast(t1 + d1 * time_curr, vp.cell[1], ic1);
@@ -1508,7 +1458,7 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
       gx = (int)f0;
       gy = (int)f1;
       gz = (int)f2;
-      return (unsigned)gx < (unsigned)vp.X && (unsigned)gy < (unsigned)vp.Y && (unsigned)gz < (unsigned)vp.Z;
+      return ((unsigned)gx < (unsigned)vp.X) & ((unsigned)gy < (unsigned)vp.Y) & ((unsigned)gz < (unsigned)vp.Z);  // (no short circuit: no lane-mask branch)
     };
 #ifdef HSK_RC_TIMING
     unsigned trips = 0, gtrips = 0;        // acted steps; acted steps that compared voxels (per lane)
@@ -1523,21 +1473,6 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
     // with the values in registers: one round trip per RC_GROUP steps instead of up to RC_GROUP.  Same decisions, same
     // ray parameters ((time_curr + time_step) + time_step ...), so the maps are bit-identical.
     bool ended = !(in_img && t_start < t_exit);
-    if (SPLIT && helper) {
-      // the near sample of step split_at is the far sample of the step before: the voxel of the sample at time_curr, by the
-      // march's own rule; a ray that has left the grid by then ended earlier in the tile's own wave
-      int hx, hy, hz;
-      const bool inside = time_curr < max_time && far_voxel(time_curr, hx, hy, hz);
-      if (inside) {
-        px = hx; py = hy; pz = hz;
-        fl_prev = flag_at(px, py, pz);
-      }
-      first = false;
-      ended = ended || !inside;
-    }
-    unsigned trips_n = 0u;   // SPLIT: trips of this wave (the cost the next launch's helper decision goes by)
-    const int look_from = (SPLIT && helped) ? split_at : 0x7fffffff;  // ... first step at which the helper's result applies
-    bool adopted = false;    // ... left the loop because the helper has finished: the still-marching lanes take its results
     // Crossing clear super-bricks: when the near sample of EVERY marching lane of the wave sits in a super-brick (4^3
     // bricks) none of whose bricks has held a negative TSDF, and every lane's ray stays inside its super-brick for the
     // next RC_SKIP steps with two steps to spare, none of those steps can gather or end -- their only effect is to
@@ -1551,41 +1486,33 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
     const float inv_step = 1.0f / time_step;
     // (a wave-wide loop: lanes whose ray has ended idle inside it, so that the wave-wide minimum below can use shuffles)
     while (__ballot(!ended && time_curr < max_time) != 0ull) {
-      if (SPLIT) {
-        ++trips_n;
-        // Every fourth trip, once no marching lane is short of the helper's first step (the lanes march in lockstep, so it
-        // is all of them or none): has the helper finished?  The look is a memory round trip, never a wait.
-        if (look_from != 0x7fffffff && (trips_n & 3u) == 0u && __ballot(!ended && time_curr < max_time && step < look_from) == 0ull) {
-          const unsigned d = __hip_atomic_load(RC_ARG(unsigned*, rs.done) + tile, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)__builtin_amdgcn_readfirstlane((int)d) == RC_ARG(unsigned, rs.gen)) {
-            adopted = true;
-            break;
-          }
-        }
-      }
       const bool act = !ended && time_curr < max_time;
 #ifdef HSK_RC_TIMING
       ++it_all;
 #endif
       if (can_skip) {
-        const int s0 = px >> ss, s1 = py >> ss, s2 = pz >> ss;
-        const int sbit = (s2 * syn + s1) * sxn + s0;
-        const bool clear = !((lflags[flag_words + (sbit >> 5)] >> (sbit & 31)) & 1u);
-        // (one ballot settles the common "no": the waves that graze a surface for a hundred steps -- the ones the launch
-        // ends with -- must not pay for exit distances and a wave-wide minimum at every trip)
-        int n = 0;
-        if (__ballot(act && !clear) == 0ull) {
-          // ray parameter at which the ray leaves the super-brick (approximate; two spare steps absorb the error)
-          float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * s_edge0 - t0) * id0;
-          float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * s_edge1 - t1) * id1;
-          float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * s_edge2 - t2) * id2;
+        // Steps every marching lane can cross at once at one level of the block hierarchy (sh: log2 of the block edge in
+        // voxels; xn, yn, zn: blocks per axis; woff: where the level's bits start in lflags; half: its edge is half a
+        // super-brick's): 0 unless the near sample of EVERY marching lane sits in a clear block.
+        auto crossing_steps = [&](const int sh, const int xn, const int yn, const int zn, const int woff, const bool half) -> int {
+          const int s0 = px >> sh, s1 = py >> sh, s2 = pz >> sh;
+          const int sbit = (s2 * yn + s1) * xn + s0;
+          const bool clear = !((lflags[woff + (sbit >> 5)] >> (sbit & 31)) & 1u);
+          // (one ballot settles the common "no": the waves that graze a surface for a hundred steps -- the ones the launch
+          // ends with -- must not pay for exit distances and a wave-wide minimum at every trip)
+          if (__ballot(act && !clear) != 0ull) return 0;
+          const float g0 = half ? 0.5f * s_edge0 : s_edge0, g1 = half ? 0.5f * s_edge1 : s_edge1, g2 = half ? 0.5f * s_edge2 : s_edge2;
+          // ray parameter at which the ray leaves the block (approximate; two spare steps absorb the error)
+          float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * g0 - t0) * id0;
+          float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * g1 - t1) * id1;
+          float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * g2 - t2) * id2;
           float te = fminf(fminf(e0, e1), e2);
 #if RC_EXT > 0
-          // ... and on through up to RC_EXT further super-bricks while they are clear too (open air: the regular trip that
-          // used to carry the march across every face between two clear super-bricks is most of what a room costs).  The
-          // next super-brick is the one behind the face the ray leaves by; that is certain only when the runner-up face
-          // lies at least two steps later (near an edge or corner the float exit times may order wrongly, and the ray
-          // could cut through a third, flagged super-brick): otherwise the crossing ends here, as before.
+          // ... and on through up to RC_EXT further blocks while they are clear too (open air: the regular trip that used
+          // to carry the march across every face between two clear blocks is most of what a room costs).  The next block
+          // is the one behind the face the ray leaves by; that is certain only when the runner-up face lies at least two
+          // steps later (near an edge or corner the float exit times may order wrongly, and the ray could cut through a
+          // third, flagged block): otherwise the crossing ends here.
           {
             int c0 = s0, c1 = s1, c2 = s2;
             bool live = act;
@@ -1595,23 +1522,24 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
               const float second = a0 ? fminf(e1, e2) : (a1 ? fminf(e0, e2) : fminf(e0, e1));
               const int n0 = c0 + (a0 ? (d0 > 0.0f ? 1 : -1) : 0), n1 = c1 + (a1 ? (d1 > 0.0f ? 1 : -1) : 0),
                         n2 = c2 + (a2 ? (d2 > 0.0f ? 1 : -1) : 0);
-              live = live && (second - te >= 2.0f * time_step) && (unsigned)n0 < (unsigned)sxn && (unsigned)n1 < (unsigned)syn &&
-                     (unsigned)n2 < (unsigned)szn;
-              const int nb = live ? (n2 * syn + n1) * sxn + n0 : 0;
-              live = live && !((lflags[flag_words + (nb >> 5)] >> (nb & 31)) & 1u);
+              live = live && (second - te >= 2.0f * time_step) && (unsigned)n0 < (unsigned)xn && (unsigned)n1 < (unsigned)yn &&
+                     (unsigned)n2 < (unsigned)zn;
+              const int nb = live ? (n2 * yn + n1) * xn + n0 : 0;
+              live = live && !((lflags[woff + (nb >> 5)] >> (nb & 31)) & 1u);
               if (live) {
                 c0 = n0; c1 = n1; c2 = n2;
-                e0 = a0 ? e0 + s_edge0 * fabsf(id0) : e0;
-                e1 = a1 ? e1 + s_edge1 * fabsf(id1) : e1;
-                e2 = a2 ? e2 + s_edge2 * fabsf(id2) : e2;
+                e0 = a0 ? e0 + g0 * fabsf(id0) : e0;
+                e1 = a1 ? e1 + g1 * fabsf(id1) : e1;
+                e2 = a2 ? e2 + g2 * fabsf(id2) : e2;
                 te = fminf(fminf(e0, e1), e2);
               }
             }
           }
 #endif
           const float room = (te - time_curr) * inv_step - 2.0f;
-          n = wave_min_i32(!act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, RC_SKIP_MAX) : 0));
-        }
+          return wave_min_i32(!act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, RC_SKIP_MAX) : 0));
+        };
+        int n = crossing_steps(ss, sxn, syn, szn, flag_words, false);
         if (n >= RC_SKIP && n != 0x7fffffff) {  // wave-uniform
           float tc = time_curr;
           int i_ = 0;
@@ -1650,7 +1578,8 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
           tt[g] = tc + time_step;
           okv[g] = far_voxel(tt[g], vx_[g], vy_[g], vz_[g]);
           alive = alive && okv[g];
-          fl[g] = alive ? flag_at(vx_[g], vy_[g], vz_[g]) : 0u;
+          fl[g] = flag_at(alive ? vx_[g] : 0, alive ? vy_[g] : 0, alive ? vz_[g] : 0);  // (looked up whether alive or not: no branch)
+          fl[g] = alive ? fl[g] : 0u;
           const bool owned = !SLAB || (vz_[g] >= vp.zo0 && vz_[g] < vp.zo1);
           need[g] = alive && owned && ((fprev | fl[g]) != 0u);
           fprev = fl[g];
@@ -1727,11 +1656,6 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
         ended = ended || e_out || e_back || e_cross;
       }
     }
-    if (SPLIT) {
-      take = adopted && !ended && time_curr < max_time;  // lanes whose result is the helper's
-      trips_w = trips_n;
-      step_w = step;
-    }
     // Deferred hit processing: lanes hit at different steps, and refining inside the loop would run these
     // (memory-latency-bound) taps once per distinct step.  Here the wave runs them once, loads batched.
     RC_STAMP(2);
@@ -1779,67 +1703,6 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
       }
     }
   }
-  if (SPLIT) {
-    const RaySplit rs = RC_ARG(RaySplit, rs);
-    int smax = step_w, tmax = (int)trips_w, any_take = take ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      smax = max(smax, __shfl_xor(smax, o, 64));
-      tmax = max(tmax, __shfl_xor(tmax, o, 64));
-      any_take = max(any_take, __shfl_xor(any_take, o, 64));
-    }
-    if (helper) {
-      // the helper's rays: results into its slot (the trips it took in lane 0's spare word), then the mark that they are
-      // complete (release: the tile's own wave may be looking from another XCD, whose cache plain stores would not reach
-      // inside a launch)
-      int* __restrict__ r = rs.result + ((size_t)my_slot * 64 + lane) * 8;
-      __hip_atomic_store(r + 0, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 1, __float_as_int(vx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 2, __float_as_int(vy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 3, __float_as_int(vz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 4, __float_as_int(nx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 5, __float_as_int(ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 6, __float_as_int(nz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(r + 7, tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) __hip_atomic_store(&rs.done[tile], rs.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      RC_STAMP(3);
-      return;
-    }
-    // What this tile cost, for the next launch: its own trips plus its helper's.  When they were many it asks for a helper
-    // again, which starts where the two waves would have shared the trips evenly: grazing rays do not cross clear
-    // super-bricks, so the later trips are RC_GROUP steps each.  (Any start is correct; this one balances.)
-    const int* __restrict__ r = rs.result + ((size_t)my_slot * 64 + lane) * 8;
-    if (lane == 0) {
-      const int t_help = any_take ? __hip_atomic_load(r + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      if (tmax + t_help > RC_SPLIT_TRIPS) {
-        int at_step = any_take ? split_at + ((t_help - tmax) / 2) * RC_GROUP : smax - (tmax / 2) * RC_GROUP;
-        at_step = max(at_step, 1);
-        const unsigned at = atomicAdd(&rs.count[rs.gen % 3u], 1u);
-        if (at < (unsigned)HSK_RS_MAX) {
-          rs.list[(rs.gen % 3u) * HSK_RS_MAX + at] = (unsigned)tile;
-          rs.slot_of[tile] = at;
-          rs.split_step[tile] = at_step;
-          rs.stamp[tile] = rs.gen;
-        }
-      }
-    }
-#ifdef HSK_RC_TIMING
-    if (lane == 0 && any_take && tile_id < 8192) g_rc_times[tile_id * 6 + 4] |= 1ull << 32;  // this tile adopted its helper's results
-#endif
-    if (take) {
-      // the helper has marched this ray from split_at on, and this lane had found nothing before that step: the helper's
-      // result is its result
-      key = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      vx = __int_as_float(__hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      vy = __int_as_float(__hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      vz = __int_as_float(__hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      nx = __int_as_float(__hip_atomic_load(r + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      ny = __int_as_float(__hip_atomic_load(r + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      nz = __int_as_float(__hip_atomic_load(r + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-  }
   // the tail of the argument block, fetched now (the empty asm hides where the pointer comes from, so the loads cannot
   // be moved up across the march)
   const RcTail tl = RC_ARG(RcTail, tail);
@@ -1880,30 +1743,8 @@ __global__ __launch_bounds__(RC_BLOCK, SPLIT ? RC_WPE_SPLIT : RC_WPE) void k_ray
   }
 }
 
-// device words of the helper-wave bookkeeping (RaySplit), and the struct over one zeroed allocation of that size
-size_t raycast_split_words(int W, int H) {
-  const size_t tiles = (size_t)((W + 7) / 8) * ((H + 7) / 8);
-  return 5 * tiles + 3 * (size_t)HSK_RS_MAX + 4 + (size_t)HSK_RS_MAX * 64 * 8;
-}
-RaySplit raycast_split_view(void* base, int W, int H, unsigned gen) {
-  const size_t tiles = (size_t)((W + 7) / 8) * ((H + 7) / 8);
-  unsigned* w = (unsigned*)base;
-  RaySplit r;
-  r.stamp = w;
-  r.slot_of = w + tiles;
-  r.split_step = (int*)(w + 2 * tiles);
-  r.prev_trips = w + 3 * tiles;
-  r.done = w + 4 * tiles;
-  r.list = w + 5 * tiles;
-  r.count = r.list + 3 * (size_t)HSK_RS_MAX;
-  r.result = (int*)(r.count + 4);
-  r.gen = gen;
-  return r;
-}
-
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring,
-                    const RaySplit* split) {
+                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring) {
   const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
   dim3 block(RC_BLOCK);
   dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
@@ -1927,14 +1768,10 @@ void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const 
   a.tail.pyr = (!slab && pyramid) ? *pyramid : none;
   a.tail.W = W;
   a.tail.H = H;
-  const RaySplit off = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
-  a.rs = (!slab && split) ? *split : off;
   if (slab)
-    hipLaunchKernelGGL((k_raycast<true, false>), grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
-  else if (a.rs.stamp && RC_BLOCK == 64 && (W % 8) == 0 && (H % 8) == 0)
-    hipLaunchKernelGGL((k_raycast<false, true>), dim3(tiles + HSK_RS_MAX), block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
+    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
   else
-    hipLaunchKernelGGL((k_raycast<false, false>), grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
+    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
 }
 // the fused pyramid needs complete 8x8 tiles and a single-device volume
 bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H) {
