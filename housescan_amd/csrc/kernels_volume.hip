@@ -1239,11 +1239,11 @@ static __device__ __forceinline__ void pyramid_step(const float* m, int dx, int 
 }
 
 #ifdef HSK_RC_TIMING
-__device__ unsigned long long g_rc_times[8192 * 6];  // per tile: 4 stamps, march trips, trips in which a lane gathered
+__device__ unsigned long long g_rc_times[8192 * 8];  // per tile: 4 stamps, march trips, trips in which a lane gathered
 extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rc_times), (size_t)n * 8);
 }
-#define RC_STAMP(k) do { if (lane == 0 && tile_id < 8192) g_rc_times[tile_id * 6 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RC_STAMP(k) do { if (lane == 0 && tile_id < 8192) g_rc_times[tile_id * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RC_STAMP(k) do { } while (0)
 #endif
@@ -1485,6 +1485,7 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
     const float id0 = 1.0f / d0, id1 = 1.0f / d1, id2 = 1.0f / d2;
     const float inv_step = 1.0f / time_step;
     // (a wave-wide loop: lanes whose ray has ended idle inside it, so that the wave-wide minimum below can use shuffles)
+    RC_STAMP(6);
     while (__ballot(!ended && time_curr < max_time) != 0ull) {
       const bool act = !ended && time_curr < max_time;
 #ifdef HSK_RC_TIMING
@@ -1671,8 +1672,8 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
         ie = max(ie, (unsigned)__shfl_xor((int)ie, o, 64));
       }
       if (lane == (int)__builtin_ctzll(__ballot(true)) && tile_id < 8192) {
-        g_rc_times[tile_id * 6 + 4] = tmax;
-        g_rc_times[tile_id * 6 + 5] = (unsigned long long)(gmax & 0xffffu) | ((unsigned long long)(ia & 0xffffu) << 16) |
+        g_rc_times[tile_id * 8 + 4] = tmax;
+        g_rc_times[tile_id * 8 + 5] = (unsigned long long)(gmax & 0xffffu) | ((unsigned long long)(ia & 0xffffu) << 16) |
                                       ((unsigned long long)(is & 0xffffu) << 32) | ((unsigned long long)(ie & 0xffffu) << 48);
       }
     }

@@ -11,8 +11,8 @@ trk = hsk.KinfuTracker(n=int(sys.argv[1]) if len(sys.argv) > 1 else 512, use_gra
 for k in range(40):
     trk.process_frame(hsk.synth_depth(hsk.synth_pose(k)))
 lib = C.CDLL(_lib.LIB_PATH)
-tall = np.zeros((8192, 6), np.uint64)
-rc = lib.hsk_debug_rc_times(C.c_void_p(tall.ctypes.data), 8192 * 6)
+tall = np.zeros((8192, 8), np.uint64)
+rc = lib.hsk_debug_rc_times(C.c_void_p(tall.ctypes.data), 8192 * 8)
 t = tall[:4800].copy()
 helpers = tall[4800:4800 + 1024]
 hl = helpers[helpers[:, 3] > 0]
@@ -32,6 +32,8 @@ it_empty = ((t[:, 5] >> np.uint64(48)) & np.uint64(0xffff)).astype(np.int64)
 it_reg = it_all - it_skip
 print("loop iterations per wave: mean %.1f p90 %.0f max %d = crossings %.1f + regular trips %.1f (of which no lane gathered: %.1f)" % (
     it_all.mean(), np.percentile(it_all, 90), it_all.max(), it_skip.mean(), it_reg.mean(), it_empty.mean()))
+setup = (t[:, 6].astype(np.float64) - t[:, 1].astype(np.float64)) / 100.0   # ray set-up: after staging until the march loop starts
+print("ray set-up (before the loop): mean %.1f p90 %.1f max %.1f us" % (setup.mean(), np.percentile(setup, 90), setup.max()))
 t = t[:, :4].astype(np.float64) / 100.0   # s_memrealtime ticks at 100 MHz -> us
 t0 = t[:, 0].min()
 stage, march, refine, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
