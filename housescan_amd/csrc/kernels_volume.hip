@@ -1255,9 +1255,6 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #ifndef RC_WPE
 #define RC_WPE 5  // waves per SIMD the register allocator must leave room for (96 VGPRs): the 4800 tiles of a 640x480 frame are all resident at five (5120 slots), and six would cost spills
 #endif
-#ifndef RC_PRIO
-#define RC_PRIO 0
-#endif
 #ifndef RC_EXT
 #define RC_EXT 2       // further clear super-bricks a crossing may run on through
 #endif
@@ -1323,10 +1320,6 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
   const unsigned* __restrict__ flags = a.flags;
   const int flag_words = a.flag_words;
   const RingOut& ring = a.ring;
-#if RC_PRIO
-  asm volatile("s_cmp_lt_u32 %0, %1\n\ts_cbranch_scc0 1f\n\ts_setprio 3\n\ts_branch 2f\n1:\n\ts_cmp_lt_u32 %0, %2\n\ts_cbranch_scc0 2f\n\ts_setprio 1\n2:"
-               :: "s"(blockIdx.x), "s"(RC_PRIO * 80), "s"(2 * RC_PRIO * 80) : "scc");
-#endif
   // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
   // global memory only next to surfaces
   extern __shared__ unsigned lflags[];

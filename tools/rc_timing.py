@@ -14,8 +14,8 @@ lib = C.CDLL(_lib.LIB_PATH)
 tall = np.zeros((8192, 8), np.uint64)
 rc = lib.hsk_debug_rc_times(C.c_void_p(tall.ctypes.data), 8192 * 8)
 t = tall[:4800].copy()
-helpers = tall[4800:4800 + 1024]
-hl = helpers[helpers[:, 3] > 0]
+helpers = tall[4800:4800 + 320]
+hl = helpers[(helpers[:, 3] > 0) & (helpers[:, 0] + np.uint64(200) >= tall[:4800, 0].min())]   # (this launch's: the stamps are never cleared)
 if len(hl):   # helper waves of the splitting raycast (workgroups behind the tiles' own)
     h0 = tall[:4800, 0].min()
     hs = hl[:, :4].astype(np.float64) / 100.0
