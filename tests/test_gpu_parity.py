@@ -281,6 +281,76 @@ def test_raycast_bit_exact(hsk, oracle, synth_frames, n):
     trk.close()
 
 
+def _sparse_volume(rng, shape, size, tau, n_blobs):
+    """mostly free space (+1, weight 1) with a few solid balls: the TSDF of the union, truncated at tau"""
+    Z, Y, X = shape
+    cell = np.array(size, np.float64) / np.array([X, Y, Z])
+    zz, yy, xx = np.meshgrid((np.arange(Z) + 0.5) * cell[2], (np.arange(Y) + 0.5) * cell[1], (np.arange(X) + 0.5) * cell[0], indexing="ij")
+    sd = np.full(shape, 1e9)
+    for _ in range(n_blobs):
+        c = rng.uniform(0.15, 0.85, 3) * np.array(size)
+        r = rng.uniform(0.06, 0.22)
+        sd = np.minimum(sd, np.sqrt((xx - c[0]) ** 2 + (yy - c[1]) ** 2 + (zz - c[2]) ** 2) - r)
+    vol = np.zeros(shape + (2,), np.int16)
+    vol[..., 0] = np.rint(np.clip(sd / tau, -1.0, 1.0) * 32767.0).astype(np.int16)
+    vol[..., 1] = 1
+    return vol
+
+
+@pytest.mark.parametrize("case", ["cubic256", "flat", "tall"])
+def test_raycast_crossings_in_sparse_volumes(hsk, oracle, case):
+    """The wave-wide crossings of clear super-bricks run on through further clear ones along the ray (a DDA over the faces
+    that stops near edges and corners): volumes that are almost all air, seen along the axes, along the 45-degree
+    diagonals, from cameras that sit exactly on super-brick faces, edges and corners, and from random poses -- keys and
+    maps bit-exact against the oracle's step-by-step march."""
+    rng = np.random.default_rng({"cubic256": 7, "flat": 8, "tall": 9}[case])
+    if case == "cubic256":
+        n, shape, size, kw_o, kw_h = 256, (256, 256, 256), (3.0, 3.0, 3.0), {}, {}
+    elif case == "flat":
+        n, shape, size = 256, (64, 192, 256), (3.0, 2.25, 0.75)      # (z, y, x); size (x, y, z)
+        kw_o = dict(vol=(256, 192, 64), size=size)
+        kw_h = dict(vol_y=192, vol_z=64, vol_size_m=size, own_z1=64)
+    else:
+        n, shape, size = 80, (320, 112, 80), (1.0, 1.4, 4.0)
+        kw_o = dict(vol=(80, 112, 320), size=size)
+        kw_h = dict(vol_y=112, vol_z=320, vol_size_m=size, own_z1=320)
+    cfg_o = oracle.default_config(n, omp=True, **kw_o)
+    trk = hsk.KinfuTracker(hsk.default_config(n, **kw_h)) if kw_h else hsk.KinfuTracker(n=n)
+    vol = _sparse_volume(rng, shape, size, oracle.tau(cfg_o), 5)
+    trk.upload_tsdf(vol)
+    size = np.array(size)
+
+    def pose_of(R, t):
+        P = np.eye(4, dtype=np.float32)
+        P[:3, :3] = np.asarray(R, np.float32)
+        P[:3, 3] = np.asarray(t, np.float32)
+        return P
+
+    c45, I = np.float32(np.sqrt(0.5)), np.eye(3)
+    Ry45 = [[c45, 0, c45], [0, 1, 0], [-c45, 0, c45]]
+    Rx45 = [[1, 0, 0], [0, c45, -c45], [0, c45, c45]]
+    Rback = [[-1, 0, 0], [0, 1, 0], [0, 0, -1]]
+    edge = size / np.array(shape[::-1]) * (64 if case != "tall" else 32)   # a super-brick edge (4 bricks of 16 / 8 voxels)
+    poses = [pose_of(I, size * [0.5, 0.5, -0.1]),                 # along +z from outside
+             pose_of(I, [edge[0], edge[1], 0.0]),                   # on a corner line of the super-brick grid, on the volume's face
+             pose_of(Ry45, [edge[0], edge[1] * 1.5, edge[2] * 0.5]),  # diagonal in x / z, starting on a face
+             pose_of(Rx45, [edge[0] * 1.5, edge[1], edge[2]]),      # diagonal in y / z, starting on an edge
+             pose_of(Rback, size * [0.5, 0.5, 1.05]),               # along -z from behind
+             pose_of(np.asarray(Ry45) @ np.asarray(Rx45), edge * 1.0)]  # from a corner of the grid, oblique
+    for k in range(4):
+        poses.append((_lookat_pose if k % 2 else _random_pose)(rng, size / 2, size * (0.45 if k < 2 else 0.9)))
+    hits = 0
+    for i, pose in enumerate(poses):
+        vm, nm, keys = trk.raycast(pose, want_keys=True)
+        ovm, onm, okeys, _ = oracle.raycast(cfg_o, vol, pose, omp=True)
+        assert np.array_equal(keys, okeys), f"{case} pose {i}: keys differ at {int((keys != okeys).sum())} pixels"
+        assert_same_bits(vm, ovm, f"{case} pose {i}: vmap")
+        assert_same_bits(nm, onm, f"{case} pose {i}: nmap")
+        hits += int((~np.isnan(vm[0])).sum())
+    assert hits > 20000, hits
+    trk.close()
+
+
 def test_raycast_empty_volume(hsk, oracle, synth_frames):
     trk = hsk.KinfuTracker(n=64)
     vm, nm, keys = trk.raycast(synth_frames(0)[0], want_keys=True)
