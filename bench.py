@@ -213,6 +213,13 @@ def readout_block(trk, n, with_download=True):
            "note": "host clock; flush = the free-space weights held in the lane-block summaries written back into the volume (once: the "
                    "read-outs after it find them current); the timed frames never pay it"}
     del cloud
+    # the mesh the .ply export is written from (hsk_extract_mesh: count pass, row scan, write pass, D2H of 36 B per triangle)
+    t2 = time.perf_counter()
+    tris, n_tri = trk.extract_mesh()
+    t2b = time.perf_counter()
+    out["extract_mesh_ms"] = round((t2b - t2) * 1e3, 3)
+    out["mesh_triangles"] = int(n_tri)
+    del tris
     if with_download:
         t3 = time.perf_counter()
         vol = trk.download_tsdf()
