@@ -1281,9 +1281,9 @@ static __device__ __forceinline__ int wave_min_i32(int v) {
 // What the kernel needs only AFTER the march (the maps it writes, the pyramid levels): kept out of the march loop's
 // scalar registers.  The compiler loads every kernel argument it uses in the entry block and keeps it there; the march
 // loop already needs ~100 SGPRs (uniform volume constants plus a saved lane mask per level of divergent control flow),
-// so the 16 that these pointers took were spilled into VGPR lanes (v_writelane / v_readlane inside the loop, and VGPRs
-// the loop does not have: it sits at the 80-register edge of six waves per SIMD).  They are therefore the LAST member
-// of the argument block and read through the kernarg segment pointer after the loop.
+// so the 16 that these pointers took were spilled into VGPR lanes (v_writelane / v_readlane inside the loop, and any
+// further scalar state cost VGPRs the same way: what rounds 2 and 3 took for a wall at 80 VGPRs).  They are therefore
+// the LAST member of the argument block and read through the kernarg segment pointer after the loop.
 struct RcTail {
   float* vmap;
   float* nmap;
