@@ -18,12 +18,10 @@ static __device__ __forceinline__ double swap32_add_f64(double a, double b) {
 }
 
 // ---- 6x6 solve + pose update, shared by the device kernel and the host mirror (hsk_icp_solve) ----
-__host__ __device__ static inline void hsk_sincos(double x, double* s, double* c) {
-  if (!(fabs(x) < 1.0e5)) {
-    *s = 0.0;
-    *c = 1.0;
-    return;
-  }
+__host__ __device__ static inline void hsk_sincos(double x_in, double* s, double* c) {
+  // (no early return and no branch on the quadrant: selects -- see hsk_solve6)
+  const bool in_range = fabs(x_in) < 1.0e5;  // otherwise (also NaN): sine 0, cosine 1
+  const double x = in_range ? x_in : 0.0;
   const double two_over_pi = 0.63661977236758134308;
   const double pio2_hi = 1.57079632673412561417e+00;
   const double pio2_lo = 6.07710050650619224932e-11;
@@ -47,19 +45,11 @@ __host__ __device__ static inline void hsk_sincos(double x, double* s, double* c
   C = C * r2 + 1.0 / 24.0;
   const double cr = (1.0 - 0.5 * r2) + (r2 * r2) * C;
   const int q = ((int)kf) & 3;
-  if (q == 0) {
-    *s = sr;
-    *c = cr;
-  } else if (q == 1) {
-    *s = cr;
-    *c = -sr;
-  } else if (q == 2) {
-    *s = -sr;
-    *c = -cr;
-  } else {
-    *s = -cr;
-    *c = sr;
-  }
+  // q: 0 -> (sr, cr), 1 -> (cr, -sr), 2 -> (-sr, -cr), 3 -> (-cr, sr)
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  const double s1 = (q & 2) ? -s0 : s0, c1 = ((q + 1) & 2) ? -c0 : c0;
+  *s = in_range ? s1 : 0.0;
+  *c = in_range ? c1 : 1.0;
 }
 
 __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6) {
@@ -78,12 +68,16 @@ __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6)
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
   // LDL^T (unit lower L, diagonal D) with one reciprocal per pivot: no square roots on the dependent chain
+  // (the failure tests are gathered and taken at the end: on the device this runs on one lane of a wave that has its SIMD
+  // to itself, where every early return is a compare, a lane-mask update and a branch on the dependent chain; after a
+  // failed test the arithmetic goes on with whatever it has and its results are not used)
   double det = 1.0;
   double dinv[6];
+  bool good = true;
   for (int j = 0; j < 6; ++j) {
     double dj = A[j][j];
     for (int q = 0; q < j; ++q) dj = dj - (L[j][q] * L[j][q]) * D[q];
-    if (!(dj > 0.0)) return false;
+    good = good & (dj > 0.0);
     D[j] = dj;
     dinv[j] = 1.0 / dj;
     det = det * dj;
@@ -93,7 +87,7 @@ __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6)
       L[i][j] = r * dinv[j];
     }
   }
-  if (!(det >= 1e-15)) return false;
+  good = good & (det >= 1e-15);
   double yv[6], xv[6];
   for (int i = 0; i < 6; ++i) {  // L y = b
     double r = b[i];
@@ -105,11 +99,10 @@ __host__ __device__ static inline bool hsk_solve6(const double* in27, float* x6)
     for (int q = i + 1; q < 6; ++q) r = r - L[q][i] * xv[q];
     xv[i] = r;
   }
-  for (int q = 0; q < 6; ++q) {
-    if (!(xv[q] == xv[q]) || !(fabs(xv[q]) < 1e30)) return false;
-    x6[q] = (float)xv[q];
-  }
-  return true;
+  for (int q = 0; q < 6; ++q) good = good & (xv[q] == xv[q]) & (fabs(xv[q]) < 1e30);
+  if (good)  // (x6 is left alone on failure, as the callers expect)
+    for (int q = 0; q < 6; ++q) x6[q] = (float)xv[q];
+  return good;
 }
 
 __host__ __device__ static inline void hsk_mat3mul(const float* A, const float* B, float* O) {
@@ -186,7 +179,9 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
   const int lane = threadIdx.x & 63;
   float x6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   int go = 0;
-  if (lane == 0 && !p.lost) {
+  // EVERY lane solves (the same LDS words, the same arithmetic: a wave's instruction costs the same for one lane as for
+  // 64), so that nothing has to be masked, branched around or broadcast afterwards
+  if (!__builtin_amdgcn_readfirstlane(p.lost)) {  // (the same in every lane: a scalar branch)
     double s[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) s[k] = tot[k];
@@ -195,10 +190,6 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
     if (!go) p.lost = 1;
     ICP_STAMP(6);
   }
-  go = __builtin_amdgcn_readfirstlane(go);
-  p.lost = __builtin_amdgcn_readfirstlane(p.lost);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) x6[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x6[q])));
   double sd, cd;
   hsk_sincos((double)(lane == 0 ? x6[0] : (lane == 1 ? x6[1] : x6[2])), &sd, &cd);
   const float sf = (float)sd, cf = (float)cd;

@@ -475,7 +475,6 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
   float g[ICP_PX][3], np_[ICP_PX][3], vp_[ICP_PX][3];
 #pragma unroll
   for (int q = 0; q < ICP_PX; ++q) {
-    ok[q] = ok[q] && !hsk_isnan(nc[q][0]);
     g[q][0] = ((R[0] * vc[q][0] + R[1] * vc[q][1]) + R[2] * vc[q][2]) + t0;
     g[q][1] = ((R[3] * vc[q][0] + R[4] * vc[q][1]) + R[5] * vc[q][2]) + t1;
     g[q][2] = ((R[6] * vc[q][0] + R[7] * vc[q][1]) + R[8] * vc[q][2]) + t2;
@@ -483,12 +482,13 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
     const float cpx = (Rp[0] * dx + Rp[3] * dy) + Rp[6] * dz;  // Rprev^T * d
     const float cpy = (Rp[1] * dx + Rp[4] * dy) + Rp[7] * dz;
     const float cpz = (Rp[2] * dx + Rp[5] * dy) + Rp[8] * dz;
-    ok[q] = ok[q] && (cpz > 0.0f);
     const float fu = (cpx * in.fx) / cpz + in.cx;
     const float fv = (cpy * in.fy) / cpz + in.cy;
-    int u = 0, v = 0;
-    ok[q] = ok[q] && hsk_rint_guard(fu, u) && hsk_rint_guard(fv, v);
-    ok[q] = ok[q] && u >= 0 && v >= 0 && u < W && v < H;
+    // (every test is evaluated for every lane and joined with &: a chain of && becomes a lane-mask branch per link, and
+    // the wave that runs this is alone on its SIMD -- its scalar instructions are not hidden behind anybody's)
+    const bool inr = (fu > -1.0e6f) & (fu < 1.0e6f) & (fv > -1.0e6f) & (fv < 1.0e6f);  // hsk_rint_guard of both
+    const int u = __float2int_rn(inr ? fu : 0.0f), v = __float2int_rn(inr ? fv : 0.0f);
+    ok[q] = ok[q] & !hsk_isnan(nc[q][0]) & (cpz > 0.0f) & inr & (u >= 0) & (v >= 0) & (u < W) & (v < H);
     const size_t j = ok[q] ? (size_t)v * W + u : 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -499,18 +499,18 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
   // phase C: gates, the 7-vector row, 27 scaled products
 #pragma unroll
   for (int q = 0; q < ICP_PX; ++q) {
-    bool valid = ok[q] && !hsk_isnan(np_[q][0]);
+    bool valid = ok[q] & !hsk_isnan(np_[q][0]);
     const float ex = vp_[q][0] - g[q][0], ey = vp_[q][1] - g[q][1], ez = vp_[q][2] - g[q][2];
     // sqrtf(d2) <= dist_thresh of the spec, as d2 <= (largest float whose correctly rounded root is <= the threshold);
     // the launcher converts the thresholds (icp_gate_limits), sqrtf being monotone
-    valid = valid && (hsk_dot3(ex, ey, ez, ex, ey, ez) <= dist_thresh);
+    valid = valid & (hsk_dot3(ex, ey, ez, ex, ey, ez) <= dist_thresh);
     const float ngx = (R[0] * nc[q][0] + R[1] * nc[q][1]) + R[2] * nc[q][2];
     const float ngy = (R[3] * nc[q][0] + R[4] * nc[q][1]) + R[5] * nc[q][2];
     const float ngz = (R[6] * nc[q][0] + R[7] * nc[q][1]) + R[8] * nc[q][2];
     const float c0 = ngy * np_[q][2] - ngz * np_[q][1];
     const float c1 = ngz * np_[q][0] - ngx * np_[q][2];
     const float c2 = ngx * np_[q][1] - ngy * np_[q][0];
-    valid = valid && (hsk_dot3(c0, c1, c2, c0, c1, c2) < angle_thresh);  // sqrtf(.) < angle_thresh, same conversion
+    valid = valid & (hsk_dot3(c0, c1, c2, c0, c1, c2) < angle_thresh);  // sqrtf(.) < angle_thresh, same conversion
     {
       // Branch-free: a rejected pixel contributes a row of zeros (products exactly +-0, sums unchanged).  With the
       // accumulation inside `if (valid)` the compiler copied the 27 accumulator pairs at every join of the divergent
