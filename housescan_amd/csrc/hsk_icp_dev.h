@@ -222,6 +222,24 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
 // The same totals gathered by ONE wave (the one that solves): lane l adds 16 of the 32 shards of sum l & 31, one lane
 // swap joins the halves, lanes 0..26 leave the totals in tot[].  No block barrier, no second LDS stage -- the other
 // waves of the block have nothing to do before the pose is known anyway.  (Any order of addition gives the same bits.)
+// (in two parts, so that the caller can request the loads before anything else it has to fetch: loads return in the order
+// they were issued, and the sums are what the chain of an iteration waits for)
+static __device__ __forceinline__ void shard_load27_wave(const double* __restrict__ slot, double* a) {
+  const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = slot[(half * 16 + j) * 32 + k];
+}
+static __device__ __forceinline__ void shard_sum27_wave(double* a, double* tot) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int j = 0; j < w; ++j) a[j] = a[j] + a[j + w];
+  const double v = swap32_add_f64(a[0], a[0]);  // every lane: its half + the other half
+  if (lane < 27) tot[lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 static __device__ __forceinline__ void shard_reduce27_wave(const double* __restrict__ slot, double* tot) {
   const int lane = threadIdx.x & 63, k = lane & 31, half = lane >> 5;
   double a[16];

@@ -744,6 +744,13 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
   const int g_icp_iter = iter;
   (void)g_icp_iter;
   ICP_STAMP(0);
+  double* __restrict__ slot_add = slots + (size_t)(iter % 3) * ICP_SLOT_DOUBLES;
+  const double* __restrict__ slot_read = slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES;
+  double* __restrict__ slot_clear = slots + (size_t)((iter + 1) % 3) * ICP_SLOT_DOUBLES;
+  // the previous iteration's sums FIRST: they are what the iteration's chain waits for, and loads return in issue order --
+  // behind the pixel loads below they waited for 30 loads per lane that nobody needs before the solve is done
+  double sums_in[16];
+  if (threadIdx.x < 64 && iter > 0) shard_load27_wave(slot_read, sums_in);
   IcpLaneIn<ICP_PX> L;
   icp_load_current<ICP_PX>(vcur, ncur, W, H, 0, H, L);  // independent of the pose: in flight during the prologue
   // the previous pose estimate and the model pose come from other launches (L2 misses): fetch them now, not after
@@ -779,13 +786,10 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 3; ++i) tp[i] = st->tp[i];
   }
-  double* __restrict__ slot_add = slots + (size_t)(iter % 3) * ICP_SLOT_DOUBLES;
-  const double* __restrict__ slot_read = slots + (size_t)((iter + 2) % 3) * ICP_SLOT_DOUBLES;
-  double* __restrict__ slot_clear = slots + (size_t)((iter + 1) % 3) * ICP_SLOT_DOUBLES;
   for (int i = blockIdx.x * ICP_BLOCK + threadIdx.x; i < ICP_SLOT_DOUBLES; i += gridDim.x * ICP_BLOCK)
     __hip_atomic_store(slot_clear + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x < 64) {  // the first wave (icp_solve_step shares the work among its lanes)
-    if (iter > 0) shard_reduce27_wave(slot_read, tot);
+    if (iter > 0) shard_sum27_wave(sums_in, tot);
     ICP_STAMP(1);
     IcpPose p = p_in;
     if (iter > 0) icp_solve_step(tot, p, iter);
