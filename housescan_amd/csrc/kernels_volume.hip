@@ -137,9 +137,30 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
   // (Slot 0 of the accumulators, read here by all blocks, is emptied for the next frame by pass A's first block.)
   __shared__ double fin_tot[27];
   __shared__ IcpPose fin_pose;
+  // (the sums are requested first; the table work below, which needs no pose, runs while they travel)
+  double sums_in[16];
+  if (fin.slots && threadIdx.x < 64) shard_load27_wave(fin.slots + (size_t)((fin.iter + 2) % 3) * ICP_SLOT_DOUBLES, sums_in);
+  // The first blocks also dilate the tile table and clear the queue counters of pass A (no extra launch, memset node or
+  // extra blocks: at 512^3 the column work alone is exactly one block per CU).
+  {
+    if (blockIdx.x == 0)
+      for (int q = threadIdx.x; q < HSK_NQUEUES; q += blockDim.x) qcount[q * HSK_QCOUNT_STRIDE] = 0u;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tw * th && (int)blockIdx.x < dil_blocks) {
+      const int ty = i / tw, tx = i - ty * tw;
+      float mx = 0.0f, mn = 1e30f;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
+          mx = fmaxf(mx, tmax[yy * tw + xx]);
+          mn = fminf(mn, tmin[yy * tw + xx]);
+        }
+      dtab[i] = make_float2(mx, mn);
+    }
+  }
   if (fin.slots) {
     if (threadIdx.x < 64) {
-      shard_reduce27_wave(fin.slots + (size_t)((fin.iter + 2) % 3) * ICP_SLOT_DOUBLES, fin_tot);
+      shard_sum27_wave(sums_in, fin_tot);
       IcpPose p = *fin.pose_in;
       icp_solve_step(fin_tot, p);
       if (threadIdx.x == 0) {
@@ -158,24 +179,6 @@ __global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp,
       }
     }
     __syncthreads();
-  }
-  // The first blocks also dilate the tile table and clear the queue counters of pass A (no extra launch, memset node or
-  // extra blocks: at 512^3 the column work alone is exactly one block per CU).
-  {
-    if (blockIdx.x == 0)
-      for (int q = threadIdx.x; q < HSK_NQUEUES; q += blockDim.x) qcount[q * HSK_QCOUNT_STRIDE] = 0u;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < tw * th && (int)blockIdx.x < dil_blocks) {
-      const int ty = i / tw, tx = i - ty * tw;
-      float mx = 0.0f, mn = 1e30f;
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int yy = min(max(ty + dy, 0), th - 1), xx = min(max(tx + dx, 0), tw - 1);
-          mx = fmaxf(mx, tmax[yy * tw + xx]);
-          mn = fminf(mn, tmin[yy * tw + xx]);
-        }
-      dtab[i] = make_float2(mx, mn);
-    }
   }
   // One block = the x-y footprint of one pass-A workgroup (16 lane columns by 16 rows), so that the block can also leave
   // that workgroup's z range: pass A's workgroups of the chunks outside it (half of its waves lie outside the frustum)
@@ -655,40 +658,44 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restr
       free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
       dc_s[sidx] = 0.0f;
     }
-    // the summaries of the lane's (at most NS) lane-blocks: requested now, used in stage 3
+    // ---- stage 1: first level (16-px dilated tile table).  Both groups' look-ups are requested first, the lane's summaries
+    // behind them: loads return in the order they were issued, and requested ahead of the look-ups the summaries -- an
+    // 8 MiB table that misses where the 9.6 KB tile table hits -- made the first level wait for a byte that stage 3 uses.
     static_assert(NS == 2, "the summaries of a chunk's two groups are fetched as one 16-bit word");
-    unsigned sum16 = 0u;  // both summaries of the lane's chunk (group g of the chunk in byte g)
-    unsigned short* const sum_at = (unsigned short*)(uni + hsk_sum_index(vp, x0, y, zbeg));
-    if (!COUNT_ONLY && uni != nullptr && active && (actv[0] || actv[1])) sum16 = *sum_at;
-    unsigned sum8[NS];
-#pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) sum8[sidx] = actv[sidx] ? (sum16 >> (8 * ((zbs[sidx] - zbeg) >> 2))) & 0xffu : 0u;
-    unsigned new16 = sum16;
-    PA_STAMP(6);
-    // ---- stage 1: first level (16-px dilated tile table)
+    float2 Dt_s[NS];
+    bool ok_s[NS], in_any_s[NS];
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
-      if (!actv[sidx]) continue;
       const int zb = zbs[sidx];
-      const bool in_any = (zb + 3 >= zl) && (zb <= zh) && active;
-      const bool in_all = (zb >= zl) && (zb + 3 <= zh) && active;
+      in_any_s[sidx] = actv[sidx] && (zb + 3 >= zl) && (zb <= zh) && active;
+      in_all_s[sidx] = actv[sidx] && (zb >= zl) && (zb + 3 <= zh) && active;
       const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - tz;  // centre of planes zb .. zb+3
       const float czc = c.azc + i22 * gz;
       const float rc = __builtin_amdgcn_rcpf(czc);
       const float uc = (c.axfc + (i02 * gz) * in.fx) * rc + in.cx;
       const float vc = (c.ayfc + (i12 * gz) * in.fy) * rc + in.cy;
       const float r = k.rk4 * rc + 2.5f;
-      const bool ok = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
+      ok_s[sidx] = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
       const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
-      const float2 Dt = dtab[tv * tw + tu];
-      const float dc = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
-      const bool dead4 = ok && (dc * 0.99999f - Dt.x > k.cull_thr4);
-      const bool free44 = in_all && ok && (dc * 1.00001f + k.free_thr4 <= Dt.y);
-      in_all_s[sidx] = in_all;
-      dc_s[sidx] = dc;
-      free44_s[sidx] = free44;
-      other_s[sidx] = in_any && !dead4 && !free44;
+      Dt_s[sidx] = dtab[tv * tw + tu];
+      dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
     }
+    unsigned sum16 = 0u;  // both summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
+    unsigned short* const sum_at = (unsigned short*)(uni + hsk_sum_index(vp, x0, y, zbeg));
+    if (!COUNT_ONLY && uni != nullptr && active && (actv[0] || actv[1])) sum16 = *sum_at;
+    PA_STAMP(6);
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const float dc = dc_s[sidx];
+      const bool dead4 = ok_s[sidx] && (dc * 0.99999f - Dt_s[sidx].x > k.cull_thr4);
+      const bool free44 = in_all_s[sidx] && ok_s[sidx] && (dc * 1.00001f + k.free_thr4 <= Dt_s[sidx].y);
+      free44_s[sidx] = free44;
+      other_s[sidx] = in_any_s[sidx] && !dead4 && !free44;
+    }
+    unsigned sum8[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) sum8[sidx] = actv[sidx] ? (sum16 >> (8 * ((zbs[sidx] - zbeg) >> 2))) & 0xffu : 0u;
+    unsigned new16 = sum16;
     PA_STAMP(2);
     // ---- stage 2: second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
     //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
