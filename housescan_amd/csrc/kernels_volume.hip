@@ -1335,31 +1335,22 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
   const int lane = threadIdx.x & 63;
   RC_STAMP(0);
 #endif
-  {
-    // 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging loop cost 9 us per
-    // block: profiles/r01/raycast_analysis.md)
-    const int nq = (flag_words + HSK_SUPER_WORDS) >> 2;  // brick bits + super-brick bits, both multiples of 4 words
-    // (an indexed temporary array here was placed in scratch memory by the compiler: named registers instead)
-    const uint4* __restrict__ src = (const uint4*)flags;
-    uint4* dst = (uint4*)lflags;
-    const int q0 = threadIdx.x, q1 = q0 + RC_BLOCK, q2 = q1 + RC_BLOCK, q3 = q2 + RC_BLOCK;
-    static_assert(RC_STAGE_MAX == 4, "the staging below is written for four 16-B loads per thread");
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-    const uint4 a0 = q0 < nq ? src[q0] : zero;
-    const uint4 a1 = q1 < nq ? src[q1] : zero;
-    const uint4 a2 = q2 < nq ? src[q2] : zero;
-    const uint4 a3 = q3 < nq ? src[q3] : zero;
-    if (q0 < nq) dst[q0] = a0;
-    if (q1 < nq) dst[q1] = a1;
-    if (q2 < nq) dst[q2] = a2;
-    if (q3 < nq) dst[q3] = a3;
-    for (int q = threadIdx.x + RC_STAGE_MAX * RC_BLOCK; q < nq; q += RC_BLOCK) ((uint4*)lflags)[q] = ((const uint4*)flags)[q];
-  }
-  __syncthreads();
+  // The bitfield is REQUESTED here -- 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging
+  // loop cost 9 us per block: profiles/r01/raycast_analysis.md) -- and put into LDS further down, behind the ray set-up,
+  // which needs none of it: at the start of a launch every wave of the chip is at this point at once, and nothing else
+  // is there to run under the loads.
+  const int nq = (flag_words + HSK_SUPER_WORDS) >> 2;  // brick bits + super-brick bits, both multiples of 4 words
+  // (an indexed temporary array here was placed in scratch memory by the compiler: named registers instead)
+  const int q0 = threadIdx.x, q1 = q0 + RC_BLOCK, q2 = q1 + RC_BLOCK, q3 = q2 + RC_BLOCK;
+  static_assert(RC_STAGE_MAX == 4, "the staging is written for four 16-B loads per thread");
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  const uint4 a0 = q0 < nq ? ((const uint4*)flags)[q0] : zero4;
+  const uint4 a1 = q1 < nq ? ((const uint4*)flags)[q1] : zero4;
+  const uint4 a2 = q2 < nq ? ((const uint4*)flags)[q2] : zero4;
+  const uint4 a3 = q3 < nq ? ((const uint4*)flags)[q3] : zero4;
 #ifndef HSK_RC_TIMING
   const int lane = threadIdx.x & 63;
 #endif
-  RC_STAMP(1);
   const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
   // Tile rows are dispatched from the top and bottom edges of the image inwards (0, last, 1, last - 1, ...): the rays of
@@ -1435,6 +1426,16 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
       const unsigned w = lflags[bf >> 5];
       return stored ? ((w >> (bf & 31)) & 1u) : 0u;
     };
+    {
+      uint4* dst = (uint4*)lflags;
+      if (q0 < nq) dst[q0] = a0;
+      if (q1 < nq) dst[q1] = a1;
+      if (q2 < nq) dst[q2] = a2;
+      if (q3 < nq) dst[q3] = a3;
+      for (int q = threadIdx.x + RC_STAGE_MAX * RC_BLOCK; q < nq; q += RC_BLOCK) ((uint4*)lflags)[q] = ((const uint4*)flags)[q];
+    }
+    __syncthreads();
+    RC_STAMP(1);
     unsigned fl_prev = flag_at(px, py, pz);  // always the flag of the current near sample
     // Voxel of a sample: the spec's floor(p / cell).  q = p * (1 / cell) differs from the correctly rounded quotient
     // by < 3 * 2^-24 * |q|, so both have the same floor unless q lies within eps of an integer -- for every q inside
