@@ -733,11 +733,11 @@ static __device__ __forceinline__ void icp_block_sums_atomic(const double* acc, 
 
 
 template <int ICP_PX>
-__global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(const float* __restrict__ vcur, const float* __restrict__ ncur,
-                                                        const float* __restrict__ vprev, const float* __restrict__ nprev,
-                                                        int W, int H, Intr in, TrackState* st, float dist_thresh,
-                                                        float angle_thresh, const IcpPose* __restrict__ pose_in,
-                                                        IcpPose* __restrict__ pose_out, double* __restrict__ slots, int iter) {
+__global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(double* __restrict__ slots, int iter, const IcpPose* __restrict__ pose_in,
+                                                        TrackState* st, const float* __restrict__ vcur,
+                                                        const float* __restrict__ ncur, const float* __restrict__ vprev,
+                                                        const float* __restrict__ nprev, int W, int H, Intr in,
+                                                        float dist_thresh, float angle_thresh, IcpPose* __restrict__ pose_out) {
   __shared__ double sh[ICP_SH_ROWS][32];
   __shared__ double tot[27];
   __shared__ IcpPose sp;
@@ -857,14 +857,14 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
     if (level_events) (void)hipEventRecord(level_events[HSK_NLEVELS - 1 - l], s);  // profiling: the level's iterations start
     for (int it = 0; it < iters[l]; ++it, ++i) {
       if (icp_px(W) == ICP_PX_FINE)
-        hipLaunchKernelGGL(k_icp_iter<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
-                           H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
+        hipLaunchKernelGGL(k_icp_iter<ICP_PX_FINE>, dim3(nb), dim3(ICP_BLOCK), 0, s, slots, i, pb + (i & 1), st, vcur[l], ncur[l],
+                           vmod[l], nmod[l], W, H, lv[l].in, dist_thresh, angle_thresh, pb + ((i + 1) & 1));
       else if (icp_px(W) == ICP_PX_MID)
-        hipLaunchKernelGGL(k_icp_iter<ICP_PX_MID>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W,
-                           H, lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
+        hipLaunchKernelGGL(k_icp_iter<ICP_PX_MID>, dim3(nb), dim3(ICP_BLOCK), 0, s, slots, i, pb + (i & 1), st, vcur[l], ncur[l],
+                           vmod[l], nmod[l], W, H, lv[l].in, dist_thresh, angle_thresh, pb + ((i + 1) & 1));
       else
-        hipLaunchKernelGGL(k_icp_iter<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, vcur[l], ncur[l], vmod[l], nmod[l], W, H,
-                           lv[l].in, st, dist_thresh, angle_thresh, pb + (i & 1), pb + ((i + 1) & 1), slots, i);
+        hipLaunchKernelGGL(k_icp_iter<1>, dim3(nb), dim3(ICP_BLOCK), 0, s, slots, i, pb + (i & 1), st, vcur[l], ncur[l], vmod[l], nmod[l],
+                           W, H, lv[l].in, dist_thresh, angle_thresh, pb + ((i + 1) & 1));
     }
   }
   if (level_events) (void)hipEventRecord(level_events[HSK_NLEVELS], s);

@@ -126,11 +126,12 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 // project into the padded image [-1.5, W+0.5] x [-1.5, H+0.5] in front of the camera.  The view frustum is
 // convex, so each column meets it in one interval; clipping the line cam(gz) = a + gz * c against the five
 // half-spaces gives it.  Conservative by 2 planes (float error).  Empty columns get (INT_MAX, INT_MIN).
-__global__ void k_column_zrange(const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
-                                int2* __restrict__ zint, int dil_blocks, const float* __restrict__ tmax,
-                                const float* __restrict__ tmin, float2* __restrict__ dtab, int tw, int th,
-                                unsigned* __restrict__ qcount, IcpFinal fin, TrackState* __restrict__ st_out,
-                                int2* __restrict__ wgz) {
+// (argument order: what a kernel of the frame's chain needs first comes first -- the first 16 dwords of the arguments
+// arrive in SGPRs with the wave, -amdgpu-kernarg-preload-count in the Makefile)
+__global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, const float* __restrict__ tmin,
+                                float2* __restrict__ dtab, int tw, int th, int dil_blocks, unsigned* __restrict__ qcount,
+                                const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
+                                int2* __restrict__ zint, TrackState* __restrict__ st_out, int2* __restrict__ wgz) {
   // fin.slots != null: the frame's ICP has left its last solve to this launch (launch_icp_fused).  The first wave of
   // EVERY block reads the sharded sums of the last iteration and solves (deterministic: all blocks get the same pose),
   // the block then works with that pose; block 0 also publishes it -- what k_icp_final does in a launch of its own.
@@ -551,15 +552,16 @@ extern "C" int hsk_debug_pa_times(unsigned long long* out, int n) {
 #endif
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(uint4* __restrict__ vol, const float* __restrict__ scaled,
-                                                   const TrackState* __restrict__ st, VolParams vp, int W, int H,
-                                                   Intr in, int zchunk, unsigned long long* __restrict__ counter,
-                                                   unsigned* __restrict__ flags, const float2* __restrict__ dtab,
-                                                   int tw, int th, const int2* __restrict__ zint,
+__global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const int2* __restrict__ wgz,
+                                                   const int2* __restrict__ zint, int zchunk, int W, int H,
+                                                   unsigned char* __restrict__ uni, const float2* __restrict__ dtab, int tw, int th,
+                                                   uint4* __restrict__ vol, const float* __restrict__ scaled, VolParams vp,
+                                                   Intr in, unsigned long long* __restrict__ counter,
+                                                   unsigned* __restrict__ flags,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
                                                    const float2* __restrict__ qtab, double* __restrict__ icp_slot0,
-                                                   unsigned char* __restrict__ uni, IntegrateConst k, const int2* __restrict__ wgz) {
+                                                   IntegrateConst k) {
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
   // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
   if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -932,13 +934,13 @@ extern "C" int hsk_debug_pb_times(unsigned long long* out, int n) {
 #define PB_STAMP(k) do { } while (0)
 #endif
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(uint4* __restrict__ vol, const float* __restrict__ scaled,
-                                                                        const TrackState* __restrict__ st, VolParams vp, int W,
-                                                                        int H, Intr in, unsigned long long* __restrict__ counter,
-                                                                        unsigned* __restrict__ flags,
-                                                                        const int2* __restrict__ zint,
-                                                                        const unsigned* __restrict__ queue_all,
-                                                                        const unsigned* __restrict__ qcount, unsigned qcap) {
+__global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const TrackState* __restrict__ st,
+                                                                        const unsigned* __restrict__ qcount,
+                                                                        const unsigned* __restrict__ queue_all, unsigned qcap, int W,
+                                                                        int H, uint4* __restrict__ vol,
+                                                                        const float* __restrict__ scaled, Intr in, VolParams vp,
+                                                                        unsigned long long* __restrict__ counter,
+                                                                        unsigned* __restrict__ flags) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
 #ifdef HSK_PB_TIMING
@@ -1053,8 +1055,9 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const IcpFinal none = {nullptr, nullptr, 0};
   const IcpFinal fin = (icp_final && !count_only) ? *icp_final : none;
   int2* wgz = zint + ncols;  // behind the column table: one entry per pass-A workgroup footprint (integrate_zint_entries)
-  hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, st, vp, W, H, in, zint, dil_blocks,
-                     tmax, tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, qcount, fin, const_cast<TrackState*>(st), wgz);
+  hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, fin, tmax,
+                     tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, dil_blocks, qcount, st, vp, W, H, in, zint,
+                     const_cast<TrackState*>(st), wgz);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
@@ -1066,16 +1069,15 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const IntegrateConst kc = integrate_const(vp, W, H, in);
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
-    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr,
-                       (unsigned char*)nullptr, kc, wgz);
-    hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
-                       flags, zint, qdata, qcount, qcap);
+    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, st, wgz, zint, zchunk, W, H, (unsigned char*)nullptr, dil, tw, th,
+                       (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr, kc);
+    hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
+                       counter, flags);
   } else {
-    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, (uint4*)vol, scaled, st, vp, W, H, in,
-                       zchunk, counter, flags, dil, tw, th, zint, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, uni, kc, wgz);
-    hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, (uint4*)vol, scaled, st, vp, W, H, in, counter,
-                       flags, zint, qdata, qcount, qcap);
+    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, st, wgz, zint, zchunk, W, H, uni, dil, tw, th, (uint4*)vol, scaled, vp,
+                       in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, kc);
+    hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
+                       counter, flags);
   }
 }
 
@@ -1298,15 +1300,15 @@ struct RcTail {
   MapPyramid pyr;
   int W, H;
 };
-struct RcArgs {
-  const short2* vol;
-  const TrackState* st;
-  VolParams vp;
-  int W, H;
-  Intr in;
+struct RcArgs {   // (what the kernel needs first comes first: the first 16 dwords arrive in SGPRs with the wave)
   const unsigned* flags;
   int flag_words;
+  int W, H;
+  const TrackState* st;
+  const short2* vol;
   RingOut ring;
+  Intr in;
+  VolParams vp;
   RcTail tail;   // never touched by name inside the kernel
 };
 // a member of the argument block fetched where it is used (see RcTail)
