@@ -806,7 +806,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(double* __restrict__ slo
   if (!sp.lost)
     icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, sp.R, sp.t, Rp, tp, dist_thresh, angle_thresh, acc);
   ICP_STAMP(3);
-  __syncthreads();  // sh is reused by the block reduction below
+  // (no barrier here: `sh` has no other user in this kernel since the sums of the previous iteration are gathered by one wave)
   icp_block_sums_atomic(acc, (double (*)[32])sh, slot_add);
   ICP_STAMP(4);
 }
