@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Long-horizon parity: FRAMES frames of the scripted synthetic stream through the pipelined tracker at N^3 against the CPU
+oracle's tracker -- every pose and the final TSDF bit for bit.  (The pytest suite holds shorter runs at these sizes: the
+oracle takes ~1 s per frame at 512^3 on 16 cores.)   usage: tools/long_parity.py N FRAMES"""
+import os
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))  # (a 256-CPU box behind a 16-core quota)
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+import housescan_amd as hsk
+from oracle import oracle
+n, frames = int(sys.argv[1]), int(sys.argv[2])
+cfg_o = oracle.default_config(n, omp=True)
+ot = oracle.Tracker(cfg_o, omp=True)
+trk = hsk.KinfuTracker(n=n)
+fr = [hsk.synth_depth(hsk.synth_pose(k)) for k in range(frames)]
+t0 = time.time()
+want = [ot.process(d) for d in fr]
+t1 = time.time()
+got = []
+trk.submit_frame(fr[0])
+for d in fr[1:]:
+    trk.submit_frame(d)
+    got.append(trk.wait_frame())
+got.append(trk.wait_frame())
+bad = 0
+for k, ((p, ok), (po, oko)) in enumerate(zip(got, want)):
+    if ok != oko or np.ascontiguousarray(p, np.float32).tobytes() != np.ascontiguousarray(po, np.float32).tobytes():
+        bad += 1
+        if bad < 4: print("frame", k, "differs", ok, oko)
+vol = trk.download_tsdf()
+dv = int((vol != ot.volume()).any(axis=-1).sum())
+print(f"n={n} frames={frames}: pose mismatches {bad}, differing voxels {dv}, oracle {t1 - t0:.1f} s")
+sys.exit(1 if (bad or dv) else 0)
