@@ -1269,11 +1269,14 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #define RC_EXT 2       // further clear super-bricks a crossing may run on through
 #endif
 #define RC_SKIP_MAX (64.0f * (RC_EXT + 1))  // most steps crossed at once
+#ifndef RC_MARGIN
+#define RC_MARGIN 0.125f  // steps a crossing stops short of the last face (3 mm: the exit times and the accumulated ray parameter are
+#endif                    // good to micrometres; two whole steps, the first choice, cost every crossing two steps: 57.3 -> 56.5 us)
 #ifndef RC_TIE
 #define RC_TIE 0.0625f  // steps by which the runner-up face must lie behind the first for a crossing to run on through it
 #endif
 #ifndef RC_SKIP
-#define RC_SKIP 3      // fewest steps worth crossing at once inside a clear super-brick
+#define RC_SKIP 2      // fewest steps worth crossing at once inside a clear super-brick
 #endif
 #ifndef RC_GROUP
 #define RC_GROUP 4     // march steps located and gathered together (k_raycast)
@@ -1482,7 +1485,7 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
     bool ended = !(in_img && t_start < t_exit);
     // Crossing clear super-bricks: when the near sample of EVERY marching lane of the wave sits in a super-brick (4^3
     // bricks) none of whose bricks has held a negative TSDF, and every lane's ray stays inside its super-brick for the
-    // next RC_SKIP steps with two steps to spare, none of those steps can gather or end -- their only effect is to
+    // next RC_SKIP steps and RC_MARGIN of a step more, none of those steps can gather or end -- their only effect is to
     // advance time_curr and step.  So the wave advances them by the same float additions and looks up the new near
     // sample once.  The decision is wave-wide (the 64 rays of an 8x8 tile are a few centimetres apart, so they cross the
     // same super-bricks together; per-lane skipping made every trip pay for both paths: raycast_analysis.md).
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
           // ends with -- must not pay for exit distances and a wave-wide minimum at every trip)
           if (__ballot(act && !clear) != 0ull) return 0;
           const float g0 = half ? 0.5f * s_edge0 : s_edge0, g1 = half ? 0.5f * s_edge1 : s_edge1, g2 = half ? 0.5f * s_edge2 : s_edge2;
-          // ray parameter at which the ray leaves the block (approximate; two spare steps absorb the error)
+          // ray parameter at which the ray leaves the block (approximate; RC_MARGIN of a step absorbs the error)
           float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * g0 - t0) * id0;
           float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * g1 - t1) * id1;
           float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * g2 - t2) * id2;
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
             }
           }
 #endif
-          const float room = (te - time_curr) * inv_step - 2.0f;
+          const float room = (te - time_curr) * inv_step - RC_MARGIN;
           return wave_min_i32(!act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, RC_SKIP_MAX) : 0));
         };
         int n = crossing_steps(ss, sxn, syn, szn, flag_words, false);
