@@ -15,9 +15,14 @@ JSON line (the task contract) with, beside the contract's keys (SURVEY.md 8(d), 
   cpu_baseline    the CPU oracle (kind "port") on this box's host cores: all cores and one thread, built -O3 -march=native
 
   python bench.py                                   # 1 GPU, 512^3
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
-      z-slab sharded over N GPUs through the C ABI (hsk_group_*: RCCL inside the library); torch.distributed (gloo) only
-      hands the communicator id round and takes the max over the ranks' clocks
+  python bench.py --gpus N                          # bare, or under python -m torch.distributed.run --nproc-per-node N
+      ONE volume sharded as z-slabs over N GPUs through the C ABI (hsk_group_*), every form on the same frames, each on
+      fresh worker processes: "rccl" (two ncclAllReduce composites per frame), "rccl_icp_allreduce" (the north_star's
+      literal form: + the 27 ICP sums all-reduced at each of the 19 iterations), "direct" (one-hop peer writes); value =
+      the fastest form whose poses and TSDF planes equal a single context's ("matches_single_gpu"), with "ranks_seen"
+      from the communicator, the weak-scaling partitions (rooms_weak, pairs_weak), the 1024^3 slabs (slabs_1024) and
+      DESIGN.md section 6's predicted microseconds beside the measured stage_us.  A form that fails or hangs is killed
+      by the launcher and recorded under launcher.failed_forms; the others still run.
 """
 import argparse
 import csv
@@ -496,137 +501,511 @@ def run_single(args, hsk, torch, local_rank):
     return out
 
 
-def run_multi(args, hsk, torch, world, rank, local_rank):
-    """N > 1: z-slabs (one per rank) through the C ABI's hsk_group_* (RCCL inside the library), or one room per GPU"""
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # host-side only: the id, the barrier, the max of the clocks
-    K, Wm, n = args.steps, args.warmup, args.volume
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1.  `python bench.py --gpus N` is a LAUNCHER that never touches the GPU itself: for every form of the sharded path it
+# starts FRESH worker processes (one per GPU: `--child FORM`), watches them (heartbeat files; a form whose workers exit
+# non-zero or stall is killed and recorded as failed, the next form starts on new processes), and assembles ONE line from
+# what the workers of rank 0 wrote.  Bare invocation: this process starts all N workers.  Under torch.distributed.run
+# (the contract's launch line) every rank process is such a launcher for its own worker only; rank 0's is the director
+# (it decides the next form and publishes it as a file the others follow).  The workers of one form meet through a
+# torch.distributed FileStore in the launcher's scratch directory (gloo, host side only: the id, the barrier, the max of
+# the clocks); the data path's collectives are RCCL calls inside the library, or its one-hop peer exchange.
+# ---------------------------------------------------------------------------------------------------------------------
+SLAB_FORMS = ("rccl", "rccl_icp_allreduce", "direct")
+FORM_TEXT = {
+    "rccl": "RCCL: ncclAllReduce(MIN) of the raycast step keys + ncclAllReduce(SUM) of the winners' vertex / normal bits per frame; every slab "
+            "runs the whole ICP on the composited maps",
+    "rccl_icp_allreduce": "the north_star's literal form: the two RCCL composites per frame AND the ICP row-sharded over the slabs with its 27 sums "
+                          "ncclAllReduce'd at each of the 19 iterations (HSK_GROUP_ICP_ALLREDUCE)",
+    "direct": "one-hop peer writes over xGMI-mapped memory + stream wait / write-value flags (HSK_GROUP_DIRECT, no RCCL call on the frame path); "
+              "every slab runs the whole ICP",
+}
+
+
+def slab_range(i, n, Z):
+    base, rem = Z // n, Z % n
+    z0 = i * base + min(i, rem)
+    return z0, z0 + base + (1 if i < rem else 0)
+
+
+def slab_halo_planes(n, size_m=3.0, trunc=0.03):
+    """planes a slab stores beyond its own on each side (hskinfu_group.hip: slab_halo)"""
+    cell = size_m / n
+    tau = max(trunc, 2.1 * cell)
+    return int(np.ceil(1.5 * 0.8 * tau / cell)) + 3
+
+
+def predicted_us(n, G):
+    """the frame time of G z-slabs priced from round 3's single-GPU stage times and xGMI link rates
+    (arithmetic, never measured) -- carried in the line so that the first multi-GPU run adjudicates it"""
+    base = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}.get(n)
+    if base is None or G < 2:
+        return None
+    icp, integ, ray = base
+    integ_g = integ * (1.0 / G + 2.0 * slab_halo_planes(n) / n)
+    ray_g = ray / G + 2.0
+    exch = {2: 30.0, 4: 38.0, 8: 45.0}.get(G, 30.0 + 2.5 * (G - 2))
+    adopt = 15.0
+    frame = icp + integ_g + ray_g + exch + adopt
+    return {"icp": icp, "integrate": round(integ_g, 1), "raycast": round(ray_g, 1), "slab_work_us": round(icp + integ_g + ray_g, 1),
+            "exchange_us": exch, "adopt_us": adopt, "frame_us": round(frame, 1), "frames_per_s": round(1e6 / frame, 1),
+            "single_gpu_frame_us": icp + integ + ray,
+            "source": "DESIGN.md section 6 (direct exchange; replicated ICP; from round 3's single-GPU stage times and ~100 GB/s per xGMI link)"}
+
+
+def plane_crcs(vol):
+    """crc32 of every z plane of a [nz, Y, X, 2] int16 volume"""
+    import zlib
+    return [zlib.crc32(memoryview(np.ascontiguousarray(vol[z]))) for z in range(vol.shape[0])]
+
+
+def poses_digest(poses):
+    import hashlib
+    return hashlib.sha1(np.ascontiguousarray(np.stack(poses), np.float32).tobytes()).hexdigest()
+
+
+class Heartbeat:
+    """the worker's sign of life: a file whose content is the phase and whose mtime the launcher watches"""
+
+    def __init__(self, path):
+        self.path, self.phase = path, "start"
+
+    def __call__(self, phase=None):
+        if phase is not None:
+            self.phase = phase
+        if self.path:
+            try:
+                with open(self.path, "w") as f:
+                    f.write(self.phase)
+            except OSError:
+                pass
+
+
+def pipelined_run(first, submit, wait, total, Wm, barrier, hb):
+    """frame 0 and the warm-up through `first` (submit + wait), then the timed frames with one frame in flight ahead;
+    returns (seconds of the timed region, lost frames, pose of every frame)"""
+    poses, lost = [], 0
+    for i in range(1 + Wm):
+        p, _ = first(i)
+        poses.append(p.copy())
+    hb("warm")
+    barrier()
+    t0 = time.perf_counter()
+    submit(1 + Wm)
+    for i in range(2 + Wm, total):
+        submit(i)
+        p, ok = wait()
+        lost += (not ok)
+        poses.append(p.copy())
+        if (i & 63) == 0:
+            hb()
+    p, ok = wait()
+    lost += (not ok)
+    poses.append(p.copy())
+    barrier()
+    return time.perf_counter() - t0, lost, poses
+
+
+def child_main(args):
+    """one worker: rank RANK of WORLD_SIZE of form args.child, a fresh process on its own GPU"""
+    form, n = args.child, args.volume
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
+    tag = os.path.join(args.child_dir, args.child_tag)
+    hb = Heartbeat("%s.hb.%d" % (tag, rank))
+    hb("start")
+    import torch
+
+    import housescan_amd as hsk
+    have = check_build(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    hb("imported")
+    K, Wm = args.steps, args.warmup
     total = 1 + Wm + K
-    if args.mode == "pairs" and world % 2:
-        raise SystemExit("--mode pairs needs an even number of GPUs")
+    single = form in ("single",)
+    dist = None
+    if not single:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="file://" + tag + ".rdzv", rank=rank, world_size=world)
+    hb("rendezvous")
 
     def barrier():
-        dist.barrier()
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
+        if dist is None:
+            return x
         t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(mode):
-        """W untimed + K timed frames in `mode`; returns (elapsed max over ranks, lost, last pose, its ground truth, rooms)"""
-        room = rank // 2 if mode == "pairs" else (rank if mode == "rooms" else 0)
-        poses_gt, frames = make_frames(hsk, 25 * room if mode != "slab" else 0, total)  # every room its own stretch of the trajectory
-        dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
-        dev_frames = [dev_all[i] for i in range(total)]
-        torch.cuda.synchronize()
-        lost = 0
-        if mode == "rooms":
-            trk = hsk.KinfuTracker(n=n, device_id=local_rank)
-            submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
-            first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
-        else:
-            flags = hsk.GROUP_ICP_ALLREDUCE if args.icp == "allreduce" else 0
-            if args.exchange == "direct" and args.icp != "allreduce":   # (the all-reduced ICP exists in the RCCL form only)
-                flags |= hsk.GROUP_DIRECT | hsk.GROUP_PROFILE
-            if mode == "pairs":
-                # BASELINE configs[4]: one room per PAIR of GPUs -- a two-slab group with its own two-rank communicator
-                pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
-                g_rank, g_world, g_src, g_pg = rank % 2, 2, 2 * room, pgs[room]
-            else:
-                g_rank, g_world, g_src, g_pg = rank, world, 0, None
-
-            def make_group(fl):
-                """the group of this rank under flags fl; every rank of the group learns whether ALL of them got theirs"""
-                ids = [(os.urandom(128) if (fl & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == g_src else None]
-                dist.broadcast_object_list(ids, src=g_src, group=g_pg)
-                try:
-                    t, why = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=g_rank, world=g_world, comm_id=ids[0], flags=fl), None
-                except hsk.KinfuError as e:
-                    t, why = None, str(e)
-                ok = torch.tensor([0 if t is None else 1])
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=g_pg)
-                return t, why, bool(ok.item())
-
-            trk, why, ok_all = make_group(flags)
-            timed.exchange_used = "direct" if (flags & hsk.GROUP_DIRECT) else "rccl"
-            if not ok_all and (flags & hsk.GROUP_DIRECT):
-                # the one-hop form could not be set up on this node (no peer access / IPC / stream memory operations):
-                # fall back to the RCCL collectives, all ranks together
-                if trk is not None:
-                    trk.close()
-                flags &= ~(hsk.GROUP_DIRECT | hsk.GROUP_PROFILE)
-                timed.exchange_used = "rccl (direct exchange unavailable: %s)" % (why or "a peer rank failed")
-                trk, why, ok_all = make_group(flags)
-            if not ok_all:
-                raise SystemExit("bench.py: the slab group could not be created: %s" % (why or "a peer rank failed"))
-            submit = lambda i: trk.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
-
-            def first(i):
-                submit(i)
-                return trk.wait_frame()
+    base, _, sub = form.partition(":")   # "pairs:direct" / "pairs:rccl"
+    room = rank // 2 if base == "pairs" else (rank if base == "rooms" else 0)
+    poses_gt, frames = make_frames(hsk, 25 * room, total)   # every room its own stretch of the trajectory; slabs: the stream's head
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+    dev_frames = [dev_all[i] for i in range(total)]
+    torch.cuda.synchronize()
+    out = {"form": form, "volume": n, "world": world, "steps": K, "warmup": Wm, "build_id": have}
+    grp = trk = None
+    if base in ("single", "rooms"):
+        trk = hsk.KinfuTracker(n=n, device_id=local_rank)
+        submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
+        first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
         wait = trk.wait_frame
-        for i in range(1 + Wm):
-            first(i)
-        barrier()
-        t0 = time.perf_counter()
-        submit(1 + Wm)
-        for i in range(2 + Wm, total):
-            submit(i)
-            pose, ok = wait()
-            lost += (not ok)
-        pose, ok = wait()
-        lost += (not ok)
-        barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        prof = None
-        if mode != "rooms" and (flags & hsk.GROUP_PROFILE):
-            ms, front, cnt = trk.exchange_ms()
-            if cnt:
-                prof = {"exchange_us": round(1e3 * ms / cnt, 1), "slab_work_us": round(1e3 * front / cnt, 1), "frames": int(cnt),
-                        "note": "rank 0's device, HIP events: slab work = ICP + integrate + slab-local raycast of a frame; exchange = key push, "
-                                "MIN, winners' push and the waits for the peers (one-hop peer writes + stream wait / write-value flags)"}
-        timed.profile = prof
-        trk.close()
-        del dev_frames, dev_all
-        return elapsed, lost, pose, poses_gt[total - 1], (world if mode == "rooms" else (world // 2 if mode == "pairs" else 1))
+    else:
+        slab_form = sub if base == "pairs" else base
+        flags = hsk.GROUP_PROFILE | {"rccl": 0, "rccl_icp_allreduce": hsk.GROUP_ICP_ALLREDUCE, "direct": hsk.GROUP_DIRECT}[slab_form]
+        if base == "pairs":
+            pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
+            g_rank, g_world, g_src, g_pg = rank % 2, 2, 2 * room, pgs[room]
+        else:
+            g_rank, g_world, g_src, g_pg = rank, world, 0, None
+        if g_world == 1 and not (flags & hsk.GROUP_DIRECT):
+            flags |= hsk.GROUP_FORCE_RCCL   # a world of one rank still goes through ncclCommInitRank and the two all-reduces
+        ids = [(os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == g_src else None]
+        dist.broadcast_object_list(ids, src=g_src, group=g_pg)
+        try:
+            grp, why = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=g_rank, world=g_world, comm_id=ids[0], flags=flags), None
+        except hsk.KinfuError as e:
+            why = str(e)
+        ok = torch.tensor([0 if grp is None else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not bool(ok.item()):   # every rank learns it: nobody is left waiting in a collective
+            if rank == 0 or why:
+                sys.stderr.write("bench.py worker %d: the group of form %s could not be created: %s\n" % (rank, form, why or "a peer rank failed"))
+            raise SystemExit(3)
+        out["ranks_seen"] = grp.ranks_seen()
+        submit = lambda i: grp.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
+        wait = grp.wait_frame
 
-    elapsed, lost, pose, gt, rooms = timed(args.mode)
-    stage_prof = getattr(timed, "profile", None)
-    out = {
-        "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
-        "value": round(rooms * K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True,
-        "scaling": "strong" if args.mode == "slab" else "weak", "vs_baseline": None,
-        "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
-        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n if args.mode == "slab" else
-                               ("configs[4]: %d concurrent %d^3 rooms, a GPU pair (two z-slabs, own communicator) each" % (rooms, n)
-                                if args.mode == "pairs" else "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n),
-                   "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
-                   "parallelism": ("slab%d-icp-%s" % (world, args.icp)) if args.mode == "slab" else
-                                  ("rooms%d" % world if args.mode == "rooms" else "pairs%d-icp-%s" % (rooms, args.icp)),
-                   "exchange": None if args.mode == "rooms" else
-                               ("direct: one-hop peer writes + stream wait / write-value flags (HSK_GROUP_DIRECT, no RCCL)"
-                                if getattr(timed, "exchange_used", "") == "direct" else
-                                "RCCL: all-reduce(MIN) of the keys, all-reduce(SUM) of the winners' bits [%s]" % getattr(timed, "exchange_used", "rccl")),
-                   "api": "hsk_submit_frame_dev / hsk_wait_frame" if args.mode == "rooms" else
-                          "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI), 1 frame in flight ahead"},
-        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
-                     "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
-    }
-    if stage_prof:
-        out["stage_us"] = stage_prof
-    if args.mode == "slab" and not args.no_rooms:
-        # the same GPUs on the path's other partition (BASELINE configs[4]-shaped): an independent room per GPU, no
-        # data-path collective -- weak scaling, next to the strong-scaling slab figure above
-        el_r, lost_r, _, _, rooms_r = timed("rooms")
-        out["rooms_weak"] = {"value": round(rooms_r * K / el_r, 2), "unit": "frames/s", "scaling": "weak", "rooms": rooms_r,
-                             "ms_per_step": round(1000.0 * el_r / K, 4), "lost_frames": int(lost_r),
-                             "workload": "one %d^3 room per GPU, hsk_submit_frame_dev / hsk_wait_frame, %d frames each" % (n, K)}
-    dist.barrier()
-    dist.destroy_process_group()
-    return out if rank == 0 else None
+        def first(i):
+            submit(i)
+            return wait()
+    hb("created")
+    elapsed, lost, poses = pipelined_run(first, submit, wait, total, Wm, barrier, hb)
+    elapsed = max_over_ranks(elapsed)
+    hb("timed")
+    rooms = world if base == "rooms" else (world // 2 if base == "pairs" else 1)
+    gt = poses_gt[total - 1]
+    out.update({"value": round(rooms * K / elapsed, 2), "unit": "frames/s", "ms_per_step": round(1000.0 * elapsed / K, 4), "rooms": rooms,
+                "lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(poses[-1][:3, 3] - gt[:3, 3]) * 1000.0), 3),
+                "final_pose_f32_hex": np.ascontiguousarray(poses[-1][:3, :4], np.float32).tobytes().hex(), "poses_sha1": poses_digest(poses)})
+    if grp is not None:
+        ms, front, cnt = grp.exchange_ms()
+        if cnt:
+            out["stage_us"] = {"slab_work_us": round(1e3 * front / cnt, 1), "exchange_us": round(1e3 * ms / cnt, 1), "frames": int(cnt),
+                               "note": "rank 0's device, HIP events: slab work = ICP (with its all-reduces in the icp_allreduce form) + integrate + "
+                                       "slab-local raycast of a frame; exchange = the two composites, waits for the peers included"}
+    # ---- the check against ONE context on the same frames: every pose of the run, and every stored plane of every slab ----
+    ref_path = os.path.join(args.child_dir, "single_%d.json" % n)
+    if base == "single":
+        vol = trk.download_tsdf()
+        out["plane_crc"] = plane_crcs(vol)
+        del vol
+    elif base in SLAB_FORMS:
+        sl = grp.slab(0)
+        vol = sl.download_tsdf()
+        mine = {"rank": rank, "z0": int(sl.stored_z0), "crc": plane_crcs(vol)}
+        del vol
+        hb("crc")
+        got = [None] * world if rank == 0 else None
+        dist.gather_object(mine, got, dst=0)
+        if rank == 0 and os.path.exists(ref_path):
+            ref = json.load(open(ref_path))
+            planes_ok = all(g["crc"] == ref["plane_crc"][g["z0"]:g["z0"] + len(g["crc"])] for g in got)
+            covered = sum(slab_range(r, world, n)[1] - slab_range(r, world, n)[0] for r in range(world)) == n
+            out["matches_single_gpu"] = bool(planes_ok and covered and out["poses_sha1"] == ref["poses_sha1"] and
+                                             out["final_pose_f32_hex"] == ref["final_pose_f32_hex"])
+            out["matches_detail"] = {"every_pose_of_the_run": out["poses_sha1"] == ref["poses_sha1"],
+                                     "every_stored_plane_of_every_slab_crc32": bool(planes_ok), "planes_compared": int(sum(len(g["crc"]) for g in got))}
+    elif rank == 0 and os.path.exists(ref_path):   # rooms / pairs: rank 0's room runs the same frames as the single context
+        ref = json.load(open(ref_path))
+        out["matches_single_gpu"] = bool(out["poses_sha1"] == ref["poses_sha1"])
+        out["matches_detail"] = {"every_pose_of_room_0": out["matches_single_gpu"]}
+    hb("checked")
+    if grp is not None:
+        grp.close()
+    if trk is not None:
+        trk.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        for path in [tag + ".json"] + ([ref_path] if base == "single" else []):   # (the single context's result is also the later forms' reference)
+            with open(path + ".tmp", "w") as f:
+                json.dump(out, f)
+            os.replace(path + ".tmp", path)
+    hb("done")
+
+
+class Launcher:
+    """see the comment block above"""
+    # seconds without a sign of life before the workers of a form are killed: while torch / the library are being paged
+    # in (a fresh box: minutes), afterwards (HSK_BENCH_STALL_S overrides it), and a follower's wait for the director
+    IMPORT_STALL_S, STALL_S, STEP_FILE_S = 420.0, float(os.environ.get("HSK_BENCH_STALL_S", "150")), 1800.0
+
+    def __init__(self, args, argv):
+        self.args, self.world = args, args.gpus
+        self.torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+        if self.torchrun:
+            self.my_ranks = [int(os.environ["RANK"])]
+            self.dir = os.path.join(tempfile.gettempdir(), "hskbench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+            os.makedirs(self.dir, exist_ok=True)
+        else:
+            self.my_ranks = list(range(self.world))
+            self.dir = tempfile.mkdtemp(prefix="hskbench_")
+        self.director = 0 in self.my_ranks
+        self.step_no = 0
+        self.failed = {}
+        self.log_tail = {}
+
+    # ---- one step: the workers of one form at one volume ----
+    def spawn(self, step):
+        a = self.args
+        procs = []
+        for r in step["ranks"]:
+            if r not in self.my_ranks:
+                continue
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(len(step["ranks"])), GLOO_SOCKET_IFNAME=os.environ.get("GLOO_SOCKET_IFNAME", "lo"),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                       HSK_FRAME_TIMEOUT_S=os.environ.get("HSK_FRAME_TIMEOUT_S", "30"))
+            if not self.torchrun or "LOCAL_RANK" not in os.environ:
+                env["LOCAL_RANK"] = str(r)
+            for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "OMP_NUM_THREADS"):
+                env.pop(v, None)
+            # (HSK_BENCH_WORKER: the CPU tests of the launcher put a scripted stand-in for the GPU worker here)
+            cmd = [sys.executable, os.environ.get("HSK_BENCH_WORKER") or os.path.join(ROOT, "bench.py"), "--child", step["form"], "--child-dir", self.dir, "--child-tag", step["tag"],
+                   "--gpus", str(self.world), "--steps", str(step["steps"]), "--warmup", str(step["warmup"]), "--volume", str(step["volume"])]
+            if a.share_gpu:
+                cmd.append("--share-gpu")
+            if a.allow_exp:
+                cmd.append("--allow-exp")
+            log = open(os.path.join(self.dir, "%s.log.%d" % (step["tag"], r)), "w")
+            procs.append((r, subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True), log))
+        return procs
+
+    def kill(self, procs):
+        import signal
+        for _, p, _ in procs:   # exactly the process groups this launcher started
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for _, p, _ in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def watch(self, step, procs):
+        """wait for the workers; (ok, why)"""
+        t_start = time.time()
+        first_bad = None
+        while True:
+            codes = [p.poll() for _, p, _ in procs]
+            if all(c is not None for c in codes):
+                break
+            now = time.time()
+            if any(c not in (None, 0) for c in codes):
+                first_bad = first_bad or now
+                if now - first_bad > 20.0:   # a worker failed: its peers get a moment to notice, then go too
+                    self.kill(procs)
+                    break
+            newest, phases = t_start, []
+            for r, _, _ in procs:
+                hbp = os.path.join(self.dir, "%s.hb.%d" % (step["tag"], r))
+                try:
+                    newest = max(newest, os.path.getmtime(hbp))
+                    phases.append(open(hbp).read() or "start")
+                except OSError:
+                    phases.append("not started")
+            limit = self.IMPORT_STALL_S if any(ph in ("not started", "start") for ph in phases) else self.STALL_S
+            if now - newest > limit:
+                self.kill(procs)
+                return False, "stalled for %.0f s in phase %s: workers killed" % (limit, "/".join(sorted(set(phases))))
+            time.sleep(0.05)
+        for _, _, log in procs:
+            log.close()
+        codes = [p.returncode for _, p, _ in procs]
+        if any(c != 0 for c in codes):
+            tails = []
+            for r, p, _ in procs:
+                if p.returncode != 0:
+                    try:
+                        lines = open(os.path.join(self.dir, "%s.log.%d" % (step["tag"], r))).read().strip().splitlines()
+                    except OSError:
+                        lines = []
+                    tails.append("rank %d rc %s: %s" % (r, p.returncode, " | ".join(lines[-3:])[-400:]))
+            return False, "; ".join(tails)
+        return True, None
+
+    def run_step(self, form, volume, ranks=None, steps=None, warmup=None):
+        """director: publish the step, run my share of it; returns rank 0's result dict or None"""
+        a = self.args
+        step = {"form": form, "volume": volume, "ranks": list(range(self.world)) if ranks is None else ranks,
+                "steps": a.steps if steps is None else steps, "warmup": a.warmup if warmup is None else warmup,
+                "tag": "s%02d_%s_%d" % (self.step_no, form.replace(":", "_"), volume)}
+        self.publish(step)
+        return self.execute(step)
+
+    def publish(self, step):
+        path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
+        with open(path + ".tmp", "w") as f:
+            json.dump(step, f)
+        os.replace(path + ".tmp", path)
+        self.step_no += 1
+
+    def execute(self, step):
+        procs = self.spawn(step)
+        if not procs:
+            return None
+        ok, why = self.watch(step, procs)
+        res_path = os.path.join(self.dir, step["tag"] + ".json")
+        if ok and (0 not in [r for r, _, _ in procs] or os.path.exists(res_path)):
+            return json.load(open(res_path)) if os.path.exists(res_path) else {}
+        self.failed["%s@%d" % (step["form"], step["volume"])] = why or "no result written"
+        return None
+
+    def follow(self):
+        """a launcher that is not the director (torch.distributed.run, rank != 0): run my worker of every published step"""
+        while True:
+            path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > self.STEP_FILE_S:
+                    return 0   # the director is gone; nothing of this rank's is left running
+                time.sleep(0.05)
+            step = json.load(open(path))
+            self.step_no += 1
+            if step["form"] == "done":
+                return 0
+            self.execute(step)
+
+    # ---- the director's plan and the line ----
+    def direct(self):
+        a, n, G = self.args, self.args.volume, self.world
+        t_begin = time.time()
+        single = self.run_step("single", n, ranks=[0])
+        rooms = self.run_step("rooms", n) if (a.mode in ("slab", "rooms") and not a.no_rooms) or a.mode == "rooms" else None
+        forms = {}
+        if a.mode == "slab":
+            for f in a.forms:
+                forms[f] = self.run_step(f, n)
+        good = {f: r for f, r in forms.items() if r and r.get("matches_single_gpu", single is None) and not r["lost_frames"]}
+        best = max(good, key=lambda f: good[f]["value"]) if good else None
+        pairs = None
+        if a.mode == "pairs" or (a.mode == "slab" and G >= 4 and G % 2 == 0 and not a.no_rooms):
+            sub = "direct" if (a.mode == "pairs" and "direct" in a.forms) or (forms.get("direct") and "direct" in good) else "rccl"
+            pairs = self.run_step("pairs:" + sub, n)
+            if pairs is None and sub == "direct":
+                pairs = self.run_step("pairs:rccl", n)
+        big = None
+        if a.mode == "slab" and n == 512 and not a.no_1024 and best is not None:
+            K2, W2 = min(a.steps, 40), min(a.warmup, 5)
+            s2 = self.run_step("single", 1024, ranks=[0], steps=K2, warmup=W2)
+            order = [best] + [f for f in sorted(good, key=lambda f: -good[f]["value"]) if f != best]
+            r2 = f2 = None
+            for f in order:
+                r2, f2 = self.run_step(f, 1024, steps=K2, warmup=W2), f
+                if r2 and r2.get("matches_single_gpu", s2 is None):
+                    break
+            big = {"workload": "configs[3]: ONE 1024^3 TSDF as %d z-slabs, the same synthetic stream, %d timed frames" % (G, K2),
+                   "single_gpu_same_frames": None if s2 is None else {k: s2[k] for k in ("value", "unit", "ms_per_step", "lost_frames")},
+                   "form": f2, "slabs": None if r2 is None else {k: r2[k] for k in r2 if k not in ("build_id", "form", "world", "volume")},
+                   "speedup_vs_single_gpu": None if not (r2 and s2) else round(r2["value"] / s2["value"], 3),
+                   "predicted_us": predicted_us(1024, G)}
+        self.publish({"form": "done"})
+        # ---- the line ----
+        K, Wm = a.steps, a.warmup
+        strip = lambda r: None if r is None else {k: r[k] for k in r if k not in ("build_id", "form", "world", "volume", "steps", "warmup", "plane_crc")}  # noqa: E731
+        head = good[best] if best else None
+        if head is None and a.mode == "pairs" and pairs:
+            head = pairs
+        if head is None and rooms:
+            head = rooms   # no slab form ran to a checked result: the weak-scaling partition is what this node measured
+        if head is None:
+            sys.stderr.write("bench.py: no form of the %d-GPU path completed: %s\n" % (G, json.dumps(self.failed)))
+            self.dump_logs()
+            return None
+        slab_head = best is not None
+        out = {
+            "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
+            "value": head["value"], "unit": "frames/s", "n_gpus": G, "steps": K, "warmup": Wm, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if slab_head else "weak", "vs_baseline": None,
+            "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+            "config": {"workload": ("configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n) if slab_head else
+                                   ("configs[4]: %d concurrent %d^3 rooms, a GPU pair (two z-slabs) each" % (head["rooms"], n) if head is pairs else
+                                    "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n),
+                       "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
+                       "parallelism": ("slab%d-%s" % (G, best)) if slab_head else ("pairs%d" % head["rooms"] if head is pairs else "rooms%d" % G),
+                       "exchange": FORM_TEXT.get(best) if slab_head else None,
+                       "api": "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI), 1 frame in flight ahead" if (slab_head or head is pairs)
+                              else "hsk_submit_frame_dev / hsk_wait_frame"},
+            "headline_form": best if slab_head else ("pairs" if head is pairs else "rooms"),
+            "headline_note": ("value = the fastest z-slab form whose every pose and every stored TSDF plane equal a single context's on the same "
+                              "frames (strong scaling of ONE volume); rooms_weak = the same GPUs with one independent room each") if slab_head else
+                             "no z-slab form completed with a checked result on this node (see forms / failed_forms): value is the weak-scaling partition",
+            "matches_single_gpu": head.get("matches_single_gpu"),
+            "ranks_seen": head.get("ranks_seen", G if not slab_head else None),
+            "tracking": {"lost_frames": head["lost_frames"], "final_translation_error_mm": head["final_translation_error_mm"],
+                         "final_pose_f32_hex": head["final_pose_f32_hex"]},
+            "rooms_weak": None if rooms is None else dict(strip(rooms), scaling="weak",
+                                                            workload="one %d^3 room per GPU, hsk_submit_frame_dev / hsk_wait_frame, %d frames each, no data-path collective" % (n, K)),
+            "forms": {f: (dict(strip(r), what=FORM_TEXT[f]) if r else {"failed": self.failed.get("%s@%d" % (f, n), "failed")}) for f, r in forms.items()},
+            "single_gpu_same_frames": None if single is None else {k: single[k] for k in ("value", "unit", "ms_per_step", "lost_frames", "final_pose_f32_hex")},
+            "speedup_vs_single_gpu": None if not (single and slab_head) else round(head["value"] / single["value"], 3),
+            "predicted_us": predicted_us(n, G),
+        }
+        if head.get("stage_us"):
+            out["stage_us"] = head["stage_us"]
+        if pairs is not None:
+            out["pairs_weak"] = dict(strip(pairs), scaling="weak", workload="BASELINE configs[4]: one %d^3 room per GPU pair (two z-slabs, own exchange)" % n)
+        if big is not None:
+            out["slabs_1024"] = big
+        out["launcher"] = {"mode": "torch.distributed.run: every rank process launches its own fresh worker per form" if self.torchrun else
+                                   "bare: this process launched all %d workers of every form" % G,
+                           "failed_forms": self.failed, "wall_s": round(time.time() - t_begin, 1),
+                           "share_gpu_check_only": bool(a.share_gpu)}
+        out["build_id"] = head.get("build_id")
+        # (build_id.py is loaded by path: importing the package would load libhskinfu.so -- and the HIP runtime -- into the launcher)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("hsk_build_id", os.path.join(ROOT, "housescan_amd", "csrc", "build_id.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if out["build_id"] != mod.build_id():
+            out["experimental_build"] = True
+        return out
+
+    def dump_logs(self):
+        for f in sorted(glob.glob(os.path.join(self.dir, "*.log.*"))):
+            try:
+                txt = open(f).read().strip().splitlines()[-6:]
+            except OSError:
+                continue
+            if txt:
+                sys.stderr.write("--- %s\n%s\n" % (os.path.basename(f), "\n".join(txt)))
+
+    def cleanup(self):
+        if self.director:
+            time.sleep(0.2)
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def check_build(args):
+    """The measured library must be the default build of THIS tree: "+exp" marks other compiler flags (timing experiments,
+    some of which give wrong results by construction), a different hash a stale .so.  tests/conftest.py refuses both too."""
+    from housescan_amd import _lib
+    from housescan_amd.csrc import build_id as tree_id
+    have, want = _lib.load().hsk_build_id().decode(), tree_id.build_id()
+    if have != want and not args.allow_exp:
+        raise SystemExit("bench.py: housescan_amd/libhskinfu.so is build %s, the tree is %s -- rebuild with "
+                         "`python -c 'import __graft_entry__ as g; g.build()'` (or pass --allow-exp for a timing experiment)" % (have, want))
+    return have
 
 
 def run_multi_torch(args, hsk, torch, world, rank, local_rank):
@@ -692,6 +1071,18 @@ def run_multi_torch(args, hsk, torch, world, rank, local_rank):
     return out if rank == 0 else None
 
 
+def emit(out, have=None, want=None):
+    """the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then"""
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -700,54 +1091,83 @@ def main():
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the oracle-counted raycast bytes)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
-    ap.add_argument("--no-1024", action="store_true", help="skip the 1024^3 roofline block")
+    ap.add_argument("--no-1024", action="store_true", help="skip the 1024^3 block (N = 1: roofline_1024; N > 1: slabs_1024)")
     ap.add_argument("--no-host-frames", action="store_true", help="skip the PCIe-inclusive (host frame) figure")
     ap.add_argument("--no-readout", action="store_true", help="skip the read-out timings (flush of the deferred weights, cloud, volume download)")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 300-frame recorded-stream replay at 256^3 (trajectory report)")
     ap.add_argument("--stream", default=None, metavar="FILE.hskd",
                     help="time the replay of a recorded depth stream through hsk_track_stream instead of the synthetic in-HBM frames "
                          "(a missing FILE is first recorded from the 300-frame synthetic stream)")
-    ap.add_argument("--no-rooms", action="store_true", help="N > 1, --mode slab: skip the secondary one-room-per-GPU (weak scaling) block")
+    ap.add_argument("--no-rooms", action="store_true", help="N > 1, --mode slab: skip the one-room-per-GPU and room-per-GPU-pair (weak scaling) blocks")
     ap.add_argument("--quick", action="store_true", help="all of the above")
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
     ap.add_argument("--sync-api", action="store_true", help="time hsk_process_frame_dev (one host sync per frame) instead of submit/wait")
     ap.add_argument("--mode", choices=["slab", "rooms", "pairs"], default="slab",
-                    help="N > 1: z-slabs of ONE volume (strong scaling), one room per GPU, or one room per GPU pair (configs[4])")
-    ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated")
-    ap.add_argument("--exchange", choices=["direct", "rccl"], default="direct",
-                    help="N > 1 slabs, group engine: the per-frame composites as one-hop peer writes (default) or as two RCCL all-reduces")
+                    help="N > 1: z-slabs of ONE volume (strong scaling; the line also carries the rooms / pairs blocks), only one room per GPU, "
+                         "or only one room per GPU pair (configs[4])")
+    ap.add_argument("--forms", default=None,
+                    help="N > 1 slabs: comma-separated forms to time, of " + ", ".join(SLAB_FORMS) + " (default: all; the headline is the fastest "
+                         "one that matches a single context)")
+    ap.add_argument("--icp", choices=["replicated", "allreduce"], default=None, help="N > 1 (older spelling): with --exchange, names ONE form")
+    ap.add_argument("--exchange", choices=["direct", "rccl"], default=None, help="N > 1 (older spelling): time only this exchange")
     ap.add_argument("--engine", choices=["group", "torch"], default="group",
-                    help="N > 1 slabs: hsk_group_* (C ABI, RCCL inside the library) or the Python harness over torch.distributed")
+                    help="N > 1 slabs: hsk_group_* (C ABI; the launcher described above) or, under torch.distributed.run only, the Python "
+                         "harness over torch.distributed")
     ap.add_argument("--backend", default="nccl", help="--engine torch: torch.distributed backend (nccl = RCCL; gloo for the check below)")
     ap.add_argument("--share-gpu", action="store_true",
-                    help="all ranks on device 0 (logic check on a one-GPU box): --engine torch over gloo, or the group engine with --exchange direct")
+                    help="all ranks on device 0 (logic check on a one-GPU box; RCCL refuses two ranks on one device, so only the direct form "
+                         "and the rooms run there)")
     ap.add_argument("--allow-exp", action="store_true",
                     help="measure a library built with other than the default flags or from other sources (the A/B scripts under tools/); "
                          "the line then carries \"experimental_build\": true and is not a result")
+    ap.add_argument("--child", default=None, help=argparse.SUPPRESS)       # a worker of the N > 1 launcher
+    ap.add_argument("--child-dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-tag", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.quick:
         args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = args.no_rooms = True
         args.no_readout = args.no_trajectory = True
+    if args.forms:
+        args.forms = [f.strip() for f in args.forms.split(",") if f.strip()]
+        bad = [f for f in args.forms if f not in SLAB_FORMS]
+        if bad:
+            raise SystemExit("--forms: unknown form(s) %s (known: %s)" % (bad, ", ".join(SLAB_FORMS)))
+    elif args.exchange or args.icp:
+        args.forms = ["rccl_icp_allreduce"] if args.icp == "allreduce" else [args.exchange or "direct"]
+    else:
+        args.forms = list(SLAB_FORMS)
+
+    if args.child:
+        return child_main(args)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    multi = args.gpus > 1 or world > 1 or bool(os.environ.get("HSK_BENCH_FORCE_MULTI"))  # (the variable: the N > 1 flow on one rank, for the tests)
+    if multi and not args.stream and not (args.engine == "torch" and args.mode == "slab"):
+        # the launcher: no GPU call, no torch import in THIS process (its workers are fresh processes, never an exec)
+        if world > 1 and world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d under a launch of %d ranks" % (args.gpus, world))
+        if args.mode == "pairs" and args.gpus % 2:
+            raise SystemExit("--mode pairs needs an even number of GPUs")
+        L = Launcher(args, sys.argv)
+        if not L.director:
+            return L.follow()
+        try:
+            out = L.direct()
+        finally:
+            L.cleanup()
+        if out is None:
+            raise SystemExit(1)
+        emit(out)
+        return 0
 
     import torch
 
     import housescan_amd as hsk
-    from housescan_amd import _lib
     from housescan_amd.csrc import build_id as tree_id
-
-    # The measured library must be the default build of THIS tree: "+exp" marks other compiler flags (timing experiments,
-    # some of which give wrong results by construction), a different hash a stale .so.  tests/conftest.py refuses both too.
-    have, want = _lib.load().hsk_build_id().decode(), tree_id.build_id()
-    if have != want and not args.allow_exp:
-        raise SystemExit("bench.py: housescan_amd/libhskinfu.so is build %s, the tree is %s -- rebuild with "
-                         "`python -c 'import __graft_entry__ as g; g.build()'` (or pass --allow-exp for a timing experiment)" % (have, want))
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    have, want = check_build(args), tree_id.build_id()
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -763,26 +1183,19 @@ def main():
                                       "timed region -- not the HBM-resident headline figure)" % args.volume, "volume": args.volume, "image": [W, H],
                           "icp_iters": [10, 5, 4], "parallelism": "1 gpu", "api": rep["api"]},
                "stream": rep}
-    elif world == 1 and not os.environ.get("HSK_BENCH_FORCE_MULTI"):  # (the variable: the N > 1 flow on a world of one rank, for the tests)
-        out = run_single(args, hsk, torch, local_rank)
-    elif args.engine == "torch" and args.mode == "slab":  # (the harness has no rooms / pairs form)
+    elif multi:   # --engine torch --mode slab, launched by torch.distributed.run
+        if world != args.gpus:
+            raise SystemExit("--engine torch must be launched with torch.distributed.run --nproc-per-node N")
         out = run_multi_torch(args, hsk, torch, world, rank, local_rank)
     else:
-        out = run_multi(args, hsk, torch, world, rank, local_rank)
+        out = run_single(args, hsk, torch, local_rank)
     if rank == 0 and out is not None:
         out["build_id"] = have   # which sources the measured library was built from (housescan_amd/csrc/build_id.py)
         if have != want:
             out["experimental_build"] = True
-        # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then
-        sys.stdout.flush()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -106,6 +106,7 @@ SYMBOLS = {
     "hsk_group_wait_frame": (C.c_int, [_P, _F, _I]),
     "hsk_group_exchange_ms": (C.c_int, [_P, _D, _D, C.POINTER(C.c_ulonglong)]),
     "hsk_group_n_slabs": (C.c_int, [_P]),
+    "hsk_group_ranks_seen": (C.c_int, [_P, _I]),
     "hsk_group_slab": (_P, [_P, C.c_int]),
     "hsk_group_download_tsdf": (C.c_int, [_P, _P]),
     "hsk_synth_pose": (C.c_int, [C.c_int, _F]),

@@ -12,6 +12,8 @@ size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (kernels_vol
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni);  // before anything reads weights
 size_t integrate_queue_words(const VolParams& vp);
+size_t integrate_queue_counter_words();  // the head of the queue buffer that holds the counters ...
+unsigned long long integrate_queue_entries(const unsigned* counter_words);  // ... and their sum, from a host copy of it
 size_t integrate_zint_entries(const VolParams& vp);  // column z ranges + workgroup z ranges (launch_integrate's zint)
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);

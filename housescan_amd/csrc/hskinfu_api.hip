@@ -709,6 +709,16 @@ extern "C" int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, i
 // Completion of the frame parked in a ring slot.  Pipelined single-device frames (kind 0 with a mark) are announced by
 // the device itself: the raycast stores the frame's sequence number into the pinned slot after the state words, and
 // the host polls it -- event records on the main stream cost ~16 us of idle GPU per frame (2334 -> 2426 frames/s).
+// how long a pipelined frame may take to report before the wait gives up (HSK_FRAME_TIMEOUT_S, seconds; default 20): a
+// frame takes milliseconds, so this only ever ends a wait behind a peer rank of a group that has died or hung
+static double frame_timeout_s() {
+  static const double t = []() {
+    const char* e = getenv("HSK_FRAME_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 20.0;
+  }();
+  return t;
+}
 static int wait_slot(hsk_ctx* k, int slot) {
   if (k->ring_expect[slot] == 0u) {
     HIPCHK(k, hipEventSynchronize(k->ring_ev[slot]));
@@ -722,7 +732,8 @@ static int wait_slot(hsk_ctx* k, int slot) {
     __builtin_ia32_pause();
     if ((spin & 4095u) == 4095u) {
       const auto dt = std::chrono::steady_clock::now() - t0;
-      if (dt > std::chrono::seconds(20)) return fail(k, HSK_ERR_HIP, "a pipelined frame did not report within 20 s");
+      if (std::chrono::duration<double>(dt).count() > frame_timeout_s())
+        return fail(k, HSK_ERR_TIMEOUT, "a pipelined frame did not report within HSK_FRAME_TIMEOUT_S (default 20 s)");
       if (dt > std::chrono::milliseconds(2)) sched_yield();
     }
   }
@@ -887,30 +898,58 @@ extern "C" int hsk_track_stream(hsk_ctx* k, hsk_depth_stream* s, int first, int 
   int w = 0, h = 0, n = 0;
   if (hsk_stream_info(s, &w, &h, &n, nullptr) != HSK_OK) return fail(k, HSK_ERR_ARG, "not a stream opened for reading");
   if (w != k->cfg.width || h != k->cfg.height) return fail(k, HSK_ERR_ARG, "the stream's frame size does not match the context");
-  if (first < 0 || count < 0 || first + count > n) return fail(k, HSK_ERR_ARG, "frame range outside the stream");
+  if (first < 0 || count < 0 || first > n || count > n - first) return fail(k, HSK_ERR_ARG, "frame range outside the stream");
   if (k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   uint16_t* buf = (uint16_t*)malloc((size_t)w * h * 2);
   if (!buf) return fail(k, HSK_ERR_STATE, "out of host memory");
-  int collected = 0, r = HSK_OK;
-  auto collect = [&]() -> int {
+  // `next`: the frame to submit next; `collected`: results handed out so far (frames first .. first + collected - 1).
+  // A frame that reports tracking LOST (a pipelined frame, kind 0, with tracked = 0) leaves its successor -- already in
+  // flight -- dropped on the device: that result is collected and thrown away, and the successor goes in again as the
+  // first frame of the restarted scan, which is what hsk_process_frame makes of it.
+  int next = 0, collected = 0, r = HSK_OK;
+  auto collect = [&](bool* lost_verdict) -> int {
     float pose[16];
     int tr = 0;
+    const bool pipelined = k->ring_kind[k->ring_head] == 0;
     const int rc = hsk_wait_frame(k, pose, &tr);
     if (rc != HSK_OK) return rc;
     if (poses_out) memcpy(poses_out + (size_t)16 * collected, pose, sizeof(pose));
     if (tracked_out) tracked_out[collected] = tr;
     collected += 1;
+    *lost_verdict = pipelined && !tr;
     return HSK_OK;
   };
-  for (int i = 0; i < count && r == HSK_OK; ++i) {
-    if (hsk_stream_read(s, first + i, buf) != HSK_OK) {
-      r = fail(k, HSK_ERR_STATE, "reading a frame from the stream failed");
-      break;
+  auto after_collect = [&](bool lost) -> int {
+    if (!lost) return HSK_OK;
+    if (k->ring_count > 0) {  // the frames behind the lost one: dropped on the device; the reset, then their results discarded
+      const int rr = reset_behind_lost_frame(k);
+      if (rr != HSK_OK) return rr;
     }
-    r = hsk_submit_frame(k, buf, w, h);  // copies the frame before it returns
-    if (r == HSK_OK && k->ring_count > 1) r = collect();
+    while (k->ring_count > 0) {
+      const int rc = hsk_wait_frame(k, nullptr, nullptr);
+      if (rc != HSK_OK) return rc;
+    }
+    next = collected;  // ... and fed again, the first of them restarting the scan
+    return HSK_OK;
+  };
+  while (r == HSK_OK && collected < count) {
+    bool lost = false;
+    if (next < count) {
+      if (hsk_stream_read(s, first + next, buf) != HSK_OK) {
+        r = fail(k, HSK_ERR_STATE, "reading a frame from the stream failed");
+        break;
+      }
+      r = hsk_submit_frame(k, buf, w, h);  // copies the frame before it returns
+      next += 1;
+      if (r == HSK_OK && k->ring_count > 1) {
+        r = collect(&lost);
+        if (r == HSK_OK) r = after_collect(lost);
+      }
+    } else {
+      r = collect(&lost);
+      if (r == HSK_OK) r = after_collect(lost);
+    }
   }
-  while (r == HSK_OK && k->ring_count > 0) r = collect();
   free(buf);
   return r;
 }
@@ -1199,13 +1238,12 @@ extern "C" int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_
 extern "C" int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries) {
   if (!k || !n_entries) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  const size_t words = 256 * 64;  // HSK_NQUEUES counters, one per 256-B line (kernels_volume.hip)
+  const size_t words = integrate_queue_counter_words();
   unsigned* h = (unsigned*)malloc(words * 4);
   if (!h) return fail(k, HSK_ERR_STATE, "out of host memory");
   hipError_t e = hipMemcpyAsync(h, k->d_queue, words * 4, hipMemcpyDeviceToHost, k->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
-  uint64_t n = 0;
-  for (size_t q = 0; q < 256; ++q) n += h[q * 64];
+  const uint64_t n = e == hipSuccess ? integrate_queue_entries(h) : 0;
   free(h);
   HIPCHK(k, e);
   *n_entries = n;

@@ -38,6 +38,8 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -66,7 +68,7 @@ Rccl* rccl(std::string* err) {
 #define SYM(f)                                                              \
   R.f = (decltype(R.f))dlsym(R.so, "nccl" #f);                              \
   if (!R.f && why.empty()) why = "RCCL lacks the symbol nccl" #f;
-      SYM(GetUniqueId) SYM(CommInitRank) SYM(CommInitAll) SYM(CommDestroy) SYM(AllReduce) SYM(GroupStart) SYM(GroupEnd)
+      SYM(GetUniqueId) SYM(CommInitRank) SYM(CommInitAll) SYM(CommDestroy) SYM(CommAbort) SYM(CommCount) SYM(AllReduce) SYM(GroupStart) SYM(GroupEnd)
       SYM(GetErrorString)
 #undef SYM
     }
@@ -146,7 +148,10 @@ struct Dev {
   int* cm = nullptr;          // composite: vertex / normal bit patterns of the winners, int32[6 P]
   int* kg_of[HSK_GROUP_MAX_DEV] = {};  // every device's gather buffer / composite as THIS device addresses it
   int* cm_of[HSK_GROUP_MAX_DEV] = {};
-  hipEvent_t ev_s0 = nullptr, ev_x0 = nullptr, ev_x1 = nullptr;  // HSK_GROUP_PROFILE: frame start, exchange start / end
+  // HSK_GROUP_PROFILE: frame start, exchange start / end -- two sets, used by alternate frames, so that a set is read
+  // (at the submission two frames later) long after its frame has been collected: reading the previous frame's would
+  // make every submission wait for the frame in flight
+  hipEvent_t ev_s0[2] = {}, ev_x0[2] = {}, ev_x1[2] = {};
 };
 
 }  // namespace
@@ -187,7 +192,8 @@ struct hsk_group {
   std::vector<void*> ipc_opened;   // peer buffers opened through hipIpcOpenMemHandle (rank form)
   double exch_ms = 0.0, front_ms = 0.0;  // HSK_GROUP_PROFILE
   unsigned long long exch_frames = 0;
-  bool exch_pending = false;
+  bool exch_pending[2] = {false, false};
+  int ev_set = 0;
 };
 
 static thread_local std::string g_group_err;
@@ -271,9 +277,11 @@ static void group_free(hsk_group* g) {
     (void)hipSetDevice(d.id);
     if (d.kg) (void)hipFree(d.kg);
     if (d.cm) (void)hipFree(d.cm);
-    if (d.ev_s0) (void)hipEventDestroy(d.ev_s0);
-    if (d.ev_x0) (void)hipEventDestroy(d.ev_x0);
-    if (d.ev_x1) (void)hipEventDestroy(d.ev_x1);
+    for (int i = 0; i < 2; ++i) {
+      if (d.ev_s0[i]) (void)hipEventDestroy(d.ev_s0[i]);
+      if (d.ev_x0[i]) (void)hipEventDestroy(d.ev_x0[i]);
+      if (d.ev_x1[i]) (void)hipEventDestroy(d.ev_x1[i]);
+    }
     if (d.comm && R) (void)R->CommDestroy(d.comm);
     if (d.kmin) (void)hipFree(d.kmin);
     if (d.bsum) (void)hipFree(d.bsum);
@@ -317,11 +325,7 @@ static int direct_setup(hsk_group* g, const void* comm_id) {
     GHIP(g, hipMalloc((void**)&d.cm, 6 * P * 4));
     GHIP(g, hipMemset(d.kg, 0, (size_t)g->n_slabs_total * P * 4));
     GHIP(g, hipMemset(d.cm, 0, 6 * P * 4));
-    if (g->flags & HSK_GROUP_PROFILE) {
-      GHIP(g, hipEventCreate(&d.ev_s0));
-      GHIP(g, hipEventCreate(&d.ev_x0));
-      GHIP(g, hipEventCreate(&d.ev_x1));
-    }
+    GHIP(g, hipDeviceSynchronize());  // (null-stream memsets, non-blocking streams: the buffers are handed out complete)
   }
   if (ranks) {
     char name[64];
@@ -330,6 +334,15 @@ static int direct_setup(hsk_group* g, const void* comm_id) {
     for (int i = 0; i < 16; ++i) o += snprintf(name + o, sizeof(name) - (size_t)o, "%02x", (unsigned)(b[i] ^ b[16 + i] ^ b[32 + i] ^ b[48 + i]));
     const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
     if (fd < 0) GFAIL(g, HSK_ERR_STATE, "direct exchange: shm_open failed");
+    // from here to the point where every rank holds its mapping, a rank that gives up takes the NAME with it (the peers
+    // then time out on a page nobody else will ever open, instead of /dev/shm keeping it)
+    struct Unlinker {
+      const char* n;
+      bool armed = true;
+      ~Unlinker() {
+        if (armed) (void)shm_unlink(n);
+      }
+    } unlinker{name};
     if (ftruncate(fd, (off_t)sizeof(DirectPage)) != 0) {
       close(fd);
       GFAIL(g, HSK_ERR_STATE, "direct exchange: ftruncate failed");
@@ -375,7 +388,7 @@ static int direct_setup(hsk_group* g, const void* comm_id) {
         if (now_s() - t0 > 120.0) GFAIL(g, HSK_ERR_STATE, "direct exchange: a rank did not attach within 120 s");
         usleep(200);
       }
-    if (own.gidx == 0) (void)shm_unlink(name);  // everybody holds a mapping: the name can go
+    unlinker.armed = own.gidx == 0;  // everybody holds a mapping: the name can go (rank 0 takes it away)
     return HSK_OK;
   }
   void* m = nullptr;
@@ -453,6 +466,11 @@ static int group_build(const hsk_config* c, int n_total, int first, int n_local,
       g->err = "hsk_group_create: device setup failed (device id out of range, or out of memory)";
       return bail(HSK_ERR_HIP);
     }
+    for (int i = 0; i < 2 && (flags & HSK_GROUP_PROFILE); ++i)
+      if (hipEventCreate(&d.ev_s0[i]) != hipSuccess || hipEventCreate(&d.ev_x0[i]) != hipSuccess || hipEventCreate(&d.ev_x1[i]) != hipSuccess) {
+        g->err = "hsk_group_create: profiling events";
+        return bail(HSK_ERR_HIP);
+      }
   }
   for (auto& s : g->slabs) {
     hsk_config sc = *c;
@@ -571,6 +589,24 @@ extern "C" int hsk_group_create_rank(const hsk_config* c, int rank, int world, c
 extern "C" void hsk_group_destroy(hsk_group* g) { group_free(g); }
 extern "C" const char* hsk_group_last_error(const hsk_group* g) { return g ? g->err.c_str() : g_group_err.c_str(); }
 extern "C" int hsk_group_n_slabs(const hsk_group* g) { return g ? (int)g->slabs.size() : -1; }
+// how many ranks / devices the exchange of this group really spans: the RCCL communicator's own count, the ranks
+// attached to the direct form's shared page, or the distinct devices of a single-process group
+extern "C" int hsk_group_ranks_seen(hsk_group* g, int* n) {
+  if (!g || !n) return HSK_ERR_ARG;
+  *n = (int)g->devs.size();
+  if (g->use_rccl && !g->devs.empty() && g->devs[0].comm) {
+    Rccl* R = rccl(nullptr);
+    int c = 0;
+    if (!R) GFAIL(g, HSK_ERR_STATE, "RCCL is not loaded");
+    GNCCL(g, R, R->CommCount(g->devs[0].comm, &c));
+    *n = c;
+  } else if (g->direct && g->page_is_shm && g->page) {
+    int c = 0;
+    for (int r = 0; r < HSK_GROUP_MAX_DEV; ++r) c += g->page->attached[r] ? 1 : 0;
+    *n = c;
+  }
+  return HSK_OK;
+}
 extern "C" hsk_ctx* hsk_group_slab(hsk_group* g, int i) { return (g && i >= 0 && i < (int)g->slabs.size()) ? g->slabs[i].k : nullptr; }
 
 // all-reduce `buf` (per device) in place over the communicator; one call per device inside an RCCL group
@@ -619,6 +655,20 @@ static int group_icp_allreduce(hsk_group* g) {
     }
   }
   return HSK_OK;
+}
+
+// HSK_GROUP_PROFILE: the times held by event set `set` of the first local device into the sums
+static void group_read_profile(hsk_group* g, int set) {
+  if (!g->exch_pending[set] || g->devs.empty()) return;
+  Dev& d = g->devs[0];
+  float a = 0.0f, b = 0.0f;
+  if (hipEventSynchronize(d.ev_x1[set]) == hipSuccess && hipEventElapsedTime(&a, d.ev_s0[set], d.ev_x0[set]) == hipSuccess &&
+      hipEventElapsedTime(&b, d.ev_x0[set], d.ev_x1[set]) == hipSuccess) {
+    g->front_ms += a;
+    g->exch_ms += b;
+    g->exch_frames += 1;
+  }
+  g->exch_pending[set] = false;
 }
 
 // the oldest frame the slabs still hold -> e (every slab must report the same pose and verdict)
@@ -672,18 +722,10 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
   for (size_t di = 0; di < g->devs.size(); ++di) {
     Dev& d = g->devs[di];
     GHIP(g, hipSetDevice(d.id));
-    if (d.ev_s0 && di == 0 && !restart) {
-      if (g->exch_pending) {  // the previous frame's times: read before the events are reused
-        float a = 0.0f, b = 0.0f;
-        if (hipEventSynchronize(d.ev_x1) == hipSuccess && hipEventElapsedTime(&a, d.ev_s0, d.ev_x0) == hipSuccess &&
-            hipEventElapsedTime(&b, d.ev_x0, d.ev_x1) == hipSuccess) {
-          g->front_ms += a;
-          g->exch_ms += b;
-          g->exch_frames += 1;
-        }
-        g->exch_pending = false;
-      }
-      GHIP(g, hipEventRecord(d.ev_s0, d.stream));
+    if (d.ev_s0[0] && di == 0 && !restart) {
+      g->ev_set ^= 1;
+      group_read_profile(g, g->ev_set);  // the times of the frame before last: read before its events are reused
+      GHIP(g, hipEventRecord(d.ev_s0[g->ev_set], d.stream));
     }
     // the frame as every slab of this device reads it: the caller's device buffer, or the pinned staging slot itself
     // (device-visible).  With a frame still in flight the copy + preprocessing go to each slab's second stream
@@ -730,7 +772,7 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
     for (size_t di = 0; di < g->devs.size(); ++di) {
       Dev& d = g->devs[di];
       GHIP(g, hipSetDevice(d.id));
-      if (d.ev_x0 && di == 0) GHIP(g, hipEventRecord(d.ev_x0, d.stream));
+      if (d.ev_x0[0] && di == 0) GHIP(g, hipEventRecord(d.ev_x0[g->ev_set], d.stream));
       for (int si : d.slabs) {
         Slab& s = g->slabs[si];
         KeyDests kd;
@@ -759,9 +801,9 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
       GHIP(g, hipSetDevice(d.id));
       for (int r = 0; r < nd; ++r)
         if (r != d.gidx) GHIP(g, hipStreamWaitValue32(d.stream, &g->page_dev[di]->f2[d.gidx][r], seq, hipStreamWaitValueGte, 0xffffffffu));
-      if (d.ev_x1 && di == 0) {
-        GHIP(g, hipEventRecord(d.ev_x1, d.stream));
-        g->exch_pending = true;
+      if (d.ev_x1[0] && di == 0) {
+        GHIP(g, hipEventRecord(d.ev_x1[g->ev_set], d.stream));
+        g->exch_pending[g->ev_set] = true;
       }
       for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_frame_end_async(g->slabs[si].k, d.kmin, d.cm));
     }
@@ -769,6 +811,10 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
     return HSK_OK;
   }
   // composite 1: the first event along every ray
+  if (g->devs[0].ev_x0[0]) {
+    GHIP(g, hipSetDevice(g->devs[0].id));
+    GHIP(g, hipEventRecord(g->devs[0].ev_x0[g->ev_set], g->devs[0].stream));
+  }
   for (auto& d : g->devs) {
     GHIP(g, hipSetDevice(d.id));
     bool first = true;
@@ -796,6 +842,11 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
   }
   r = group_allreduce(g, false, ncclInt32, ncclSum, 6 * P, 1);
   if (r != HSK_OK) return r;
+  if (g->devs[0].ev_x1[0]) {
+    GHIP(g, hipSetDevice(g->devs[0].id));
+    GHIP(g, hipEventRecord(g->devs[0].ev_x1[g->ev_set], g->devs[0].stream));
+    g->exch_pending[g->ev_set] = true;
+  }
   for (auto& d : g->devs) {
     GHIP(g, hipSetDevice(d.id));
     for (int si : d.slabs) GSLAB(g, g->slabs[si], hsk_mgpu_frame_end_async(g->slabs[si].k, d.kmin, d.bsum));
@@ -804,9 +855,32 @@ static int group_enqueue_body(hsk_group* g, const uint16_t* depth_host, const vo
   return HSK_OK;
 }
 
+// Poisoning also lets this process's own queues DRAIN, so that hsk_group_reset / hsk_group_destroy (stream
+// synchronisation, hipFree) return instead of hanging behind work that waits for a peer which will never answer:
+//  * direct exchange: every flag this process's streams wait for (its own rows of F1 / F2) is raised to the last
+//    enqueued exchange by a host store into the shared page -- the frames in flight finish on stale data, their results
+//    are never handed out (every call fails from here on);
+//  * RCCL between ranks: the communicator is aborted (ncclCommAbort: the collective kernels poll its abort flag).
 static void group_poison(hsk_group* g) {
   g->poisoned = true;
   g->poison_why = g->err;
+  if (g->direct && g->page) {
+    for (auto& d : g->devs)
+      for (int r = 0; r < g->n_dev_total; ++r) {
+        __atomic_store_n(&g->page->f1[d.gidx][r], g->seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&g->page->f2[d.gidx][r], g->seq, __ATOMIC_RELEASE);
+      }
+    __sync_synchronize();
+  }
+  if (g->use_rccl && g->world > 1) {
+    Rccl* R = rccl(nullptr);
+    for (auto& d : g->devs)
+      if (d.comm && R) {
+        (void)hipSetDevice(d.id);
+        (void)R->CommAbort(d.comm);
+        d.comm = nullptr;
+      }
+  }
 }
 
 static int group_enqueue(hsk_group* g, const uint16_t* depth_host, const void* const* depth_dev, int w, int h) {
@@ -862,11 +936,12 @@ extern "C" int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int 
 }
 
 // Drops the frames in flight and starts the scan afresh.  Also the way out of a poisoned single-process group (every
-// slab context is reset, whatever frame it was on); a poisoned multi-rank group stays poisoned -- its peers may sit in a
-// collective -- and can only be destroyed.
+// slab context is reset, whatever frame it was on); a poisoned multi-rank group (RCCL or direct form) stays poisoned --
+// its peers may sit in a collective or wait for a flag, and their sequence numbers no longer agree with this rank's --
+// and can only be destroyed.
 extern "C" int hsk_group_reset(hsk_group* g) {
   if (!g) return HSK_ERR_ARG;
-  if (g->poisoned && g->use_rccl && g->world > 1) GPOISONED(g);
+  if (g->poisoned && g->world > 1 && (g->use_rccl || g->direct)) GPOISONED(g);
   for (auto& s : g->slabs) {
     GHIP(g, hipSetDevice(g->devs[s.dev_slot].id));
     GSLAB(g, s, hsk_reset(s.k));  // (collects and drops the slab's frames in flight itself)
@@ -882,6 +957,10 @@ extern "C" int hsk_group_reset(hsk_group* g) {
 // frames whose times have been read so far (the last submitted frame's are read at the next submission)
 extern "C" int hsk_group_exchange_ms(hsk_group* g, double* sum_ms, double* front_sum_ms, unsigned long long* n_frames) {
   if (!g) return HSK_ERR_ARG;
+  if (g->fifo.empty() && !g->poisoned && !g->devs.empty() && hipSetDevice(g->devs[0].id) == hipSuccess) {
+    group_read_profile(g, 0);  // every frame has been collected: both sets are complete
+    group_read_profile(g, 1);
+  }
   if (sum_ms) *sum_ms = g->exch_ms;
   if (front_sum_ms) *front_sum_ms = g->front_ms;
   if (n_frames) *n_frames = g->exch_frames;

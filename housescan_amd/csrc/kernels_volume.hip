@@ -1031,6 +1031,12 @@ size_t integrate_zint_entries(const VolParams& vp) {
   const size_t fp = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16);
   return (size_t)(vp.X / 4) * vp.Y + ((fp + 1) & ~(size_t)1) + 8 * fp;  // (the wave table is int4: kept 16-B aligned)
 }
+size_t integrate_queue_counter_words() { return (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE; }
+unsigned long long integrate_queue_entries(const unsigned* counter_words) {
+  unsigned long long n = 0;
+  for (size_t q = 0; q < HSK_NQUEUES; ++q) n += counter_words[q * HSK_QCOUNT_STRIDE];
+  return n;
+}
 // words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
 size_t integrate_queue_words(const VolParams& vp) {
   const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;

@@ -328,6 +328,12 @@ class KinfuGroup:
     def n_slabs(self):
         return self.lib.hsk_group_n_slabs(self.h)
 
+    def ranks_seen(self):
+        """ranks / devices the group's exchange spans, as the communicator (or the shared flag page) itself counts them"""
+        n = C.c_int()
+        self._ck(self.lib.hsk_group_ranks_seen(self.h, C.byref(n)))
+        return n.value
+
     def exchange_ms(self):
         """GROUP_PROFILE: (summed ms of the per-frame exchange, summed ms of the slab work before it, frames counted) on
         the first local device"""

@@ -35,6 +35,7 @@ extern "C" {
 #define HSK_ERR_HIP (-2)
 #define HSK_ERR_STATE (-3)
 #define HSK_ERR_NOGPU (-4)
+#define HSK_ERR_TIMEOUT (-5) /* a pipelined frame did not report within HSK_FRAME_TIMEOUT_S seconds (environment, default 20) */
 
 #define HSK_LEVELS 3
 #define HSK_KEY_NONE 0x7fffffff
@@ -191,11 +192,16 @@ int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int w, int h, f
  * After a tracking loss the frames already in flight behind the lost one are dropped (tracked = 0); the submission
  * that follows restarts the scan, its result is handed out behind theirs.
  * A failure in the MIDDLE of a frame (some slabs or devices have taken it, others not) poisons the group: every later
- * call returns HSK_ERR_STATE until hsk_group_reset succeeds (single process) or the group is destroyed (several ranks:
- * the peers may be left in a collective).
- * STATUS: groups of several slabs on ONE device, with and without RCCL, are tested bit-exact against a single context;
- * groups over more than one device (ncclCommInitAll / ncclCommInitRank with world > 1) have never run on hardware --
- * no multi-GPU box was available (tests/test_gpu_multi_device.py runs when one is). */
+ * call returns HSK_ERR_STATE until hsk_group_reset succeeds (single process) or the group is destroyed (several ranks,
+ * RCCL or direct form: the peers may be left in a collective or waiting for a flag).  A peer rank that dies or hangs
+ * shows as HSK_ERR_TIMEOUT from hsk_group_wait_frame on every other rank after HSK_FRAME_TIMEOUT_S seconds (environment
+ * variable, default 20) -- which poisons the group.  Poisoning lets this rank's own queues drain (direct form: the
+ * flags its streams wait for are raised from the host; RCCL form: ncclCommAbort), so hsk_group_destroy returns.
+ * STATUS: groups of several slabs on ONE device -- RCCL form, direct form, and the direct form between 2 and 3 OS
+ * processes sharing the device -- are tested bit-exact against a single context; groups over more than one DEVICE
+ * (ncclCommInitAll / ncclCommInitRank with world > 1, the direct form over xGMI peer mappings) have never run on
+ * hardware -- no multi-GPU box was available (tests/test_gpu_multi_device.py runs all three forms when one is, and
+ * `bench.py --gpus N` checks every form it times against a single context: "matches_single_gpu"). */
 int hsk_group_submit_frame(hsk_group* g, const uint16_t* depth, int w, int h);
 /* depth_dev[d]: the frame in the memory of the d-th distinct device of this process (creation order), complete and
  * valid until the frame has been waited for */
@@ -205,6 +211,9 @@ int hsk_group_wait_frame(hsk_group* g, float pose_out[16], int* tracked);
  * included) and the slab's own work before it (ICP + integrate + slab-local raycast) */
 int hsk_group_exchange_ms(hsk_group* g, double* sum_ms, double* front_sum_ms, unsigned long long* n_frames);
 int hsk_group_n_slabs(const hsk_group* g);            /* slabs held by this process */
+/* how many ranks / devices the group's exchange really spans: ncclCommCount of its communicator (RCCL forms), the ranks
+ * attached to the shared flag page (direct form between processes), the distinct devices of a single-process group */
+int hsk_group_ranks_seen(hsk_group* g, int* n_ranks);
 hsk_ctx* hsk_group_slab(hsk_group* g, int i);         /* for hsk_download_map, hsk_extract_cloud, ... on one slab */
 /* the planes this process owns, at their place in a full 2 * X * Y * Z array (other planes are left untouched) */
 int hsk_group_download_tsdf(hsk_group* g, int16_t* full_tsdf_weight_pairs);
@@ -276,7 +285,9 @@ int hsk_stream_info(const hsk_depth_stream* s, int* w, int* h, int* n_frames, fl
  * Main.hs:1285-1290 around takeDepthSnapshot, HoniHelper.hs:20-36): frames [first, first + count) of `s` through the
  * tracker, pipelined -- frame i + 1 is read from the file and uploaded while frame i is on the GPU.  poses_out: 16 floats
  * per frame (row-major cam->world), tracked_out: one int per frame (either may be NULL).  The context must have no frame
- * in flight; results are exactly those of hsk_process_frame called with the same frames. */
+ * in flight; results are exactly those of hsk_process_frame called with the same frames -- also behind a lost frame:
+ * frame i + 1, in flight when frame i reports tracking lost, is dropped on the device, then read again and resubmitted
+ * as the first frame of the restarted scan (as the reference-shaped host loop would feed it). */
 int hsk_track_stream(hsk_ctx* k, hsk_depth_stream* s, int first, int count, float* poses_out, int* tracked_out);
 
 #ifdef __cplusplus

@@ -293,3 +293,78 @@ def test_direct_exchange_between_processes_sharing_the_gpu(hsk, synth_frames, tm
         got = got | np.load(idfile + ".vol%d.npy" % r)   # each rank fills only the planes it owns
     assert_same_bits(got, ref.download_tsdf(), "the ranks' owned planes together")
     ref.close()
+
+
+DEAD_PEER_SCRIPT = """
+import os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r})
+import housescan_amd as hsk
+rank, world, idfile, n = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+uid = open(idfile, "rb").read()
+grp = hsk.KinfuGroup(hsk.default_config(n, device_id=0), rank=rank, world=world, comm_id=uid, flags=hsk.GROUP_DIRECT)
+assert grp.ranks_seen() == world
+frames = [hsk.synth_depth(hsk.synth_pose(k)) for k in range(40)]
+grp.submit_frame(frames[0])
+t_fail = None
+try:
+    for k, d in enumerate(frames[1:], 1):
+        grp.submit_frame(d)
+        grp.wait_frame()
+        if k == 6 and rank == world - 1:
+            os._exit(9)          # this rank dies in the middle of the stream, a frame in flight, no teardown
+        t_fail = time.time()
+    print("no error")
+except hsk.KinfuError as e:
+    print("error after %.1f s: %s" % (time.time() - t_fail, e))
+    try:
+        grp.wait_frame()
+    except hsk.KinfuError as e2:
+        print("then: %s" % e2)
+    try:
+        grp.reset()
+    except hsk.KinfuError as e3:
+        print("reset refused: %s" % e3)
+    t0 = time.time()
+    grp.close()                  # must return: the streams' waits were released when the group was poisoned
+    print("closed in %.1f s" % (time.time() - t0))
+    sys.exit(3)
+"""
+
+
+def test_direct_exchange_survives_a_dead_peer(hsk, tmp_path):
+    """VERDICT r03 item 7 / ADVICE r03: one of three ranks of a direct-exchange group dies mid-stream.  The flags it would
+    have raised never come; every other rank must get a negative code (HSK_ERR_TIMEOUT) from hsk_group_wait_frame within
+    HSK_FRAME_TIMEOUT_S, find the group poisoned (reset refused: several ranks), and hsk_group_destroy must return -- the
+    waits queued on its streams were released from the host -- so the process exits by itself, non-zero; the shared-memory
+    page's name is gone from /dev/shm."""
+    import glob
+    import sys
+    import time
+    world, n = 3, 64
+    before = set(glob.glob("/dev/shm/hskx_*"))
+    idfile = str(tmp_path / "comm_id")
+    open(idfile, "wb").write(os.urandom(128))
+    script = DEAD_PEER_SCRIPT.format(root=ROOT)
+    env = dict(os.environ, HSK_FRAME_TIMEOUT_S="4")
+    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), str(world), idfile, str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(world)]
+    t0 = time.time()
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=180))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a surviving rank hung behind the dead peer")
+    assert procs[world - 1].returncode == 9
+    for r in range(world - 1):
+        so, se = outs[r]
+        assert procs[r].returncode == 3, (r, procs[r].returncode, so, se[-2000:])
+        assert "error after" in so and "-5" in so and "did not report" in so, so
+        assert "then:" in so and "poisoned" in so and "reset refused" in so and "closed in" in so, so
+        waited = float(so.split("error after ")[1].split(" s")[0])
+        assert 3.0 < waited < 30.0, so
+    assert time.time() - t0 < 150
+    assert set(glob.glob("/dev/shm/hskx_*")) <= before, "the direct exchange left its shared-memory page behind"

@@ -37,7 +37,7 @@ def _pipelined(t, frames):
 
 
 @needs_two
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 4])   # RCCL composites, + all-reduced ICP, the direct exchange over peer access
 def test_group_over_two_devices_single_process(hsk, synth_frames, flags):
     n = 128
     frames = [synth_frames(k)[1] for k in range(8)]
@@ -67,7 +67,8 @@ RANK_SCRIPT = textwrap.dedent("""
         while not os.path.exists(idfile):
             time.sleep(0.05)
         uid = open(idfile, "rb").read()
-    grp = hsk.KinfuGroup(hsk.default_config(n, device_id=rank), rank=rank, world=2, comm_id=uid)
+    grp = hsk.KinfuGroup(hsk.default_config(n, device_id=rank), rank=rank, world=2, comm_id=uid, flags=int(sys.argv[4]))
+    assert grp.ranks_seen() == 2
     frames = [hsk.synth_depth(hsk.synth_pose(k)) for k in range(8)]
     grp.submit_frame(frames[0])
     out = []
@@ -85,13 +86,22 @@ RANK_SCRIPT = textwrap.dedent("""
 
 
 @needs_two
-def test_rank_form_two_processes_two_devices(hsk, synth_frames, tmp_path):
+@pytest.mark.parametrize("flags", [0, 2, 4])   # 4: hipIpc-mapped peer buffers across two DEVICES, flags raised over xGMI
+def test_rank_form_two_processes_two_devices(hsk, synth_frames, tmp_path, flags):
     n = 128
     idfile = str(tmp_path / "comm_id")
     script = RANK_SCRIPT.format(root=ROOT)
-    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), idfile, str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
-    outs = [p.communicate(timeout=600) for p in procs]
+    env = dict(os.environ, HSK_FRAME_TIMEOUT_S="30")
+    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), idfile, str(n), str(flags)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and so.strip().endswith("done"), (r, se[-2000:])
     ref = hsk.KinfuTracker(n=n)
@@ -106,3 +116,18 @@ def test_rank_form_two_processes_two_devices(hsk, synth_frames, tmp_path):
     got = np.load(idfile + ".vol0.npy") | np.load(idfile + ".vol1.npy")   # each rank fills only the planes it owns
     assert_same_bits(got, full, "the two ranks' owned planes together")
     ref.close()
+
+
+@needs_two
+def test_bench_bare_on_two_devices():
+    """`python bench.py --gpus 2` as the driver would type it, on two real devices: every form must run, match the single
+    context and see two ranks"""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "3", "--volume", "256"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["launcher"]["failed_forms"] == {}, out["launcher"]
+    for f in ("rccl", "rccl_icp_allreduce", "direct"):
+        assert out["forms"][f]["matches_single_gpu"] is True and out["forms"][f]["ranks_seen"] == 2, (f, out["forms"][f])
+    assert out["rooms_weak"]["rooms"] == 2 and out["matches_single_gpu"] is True

@@ -1022,16 +1022,31 @@ def test_bench_two_ranks_match_one(tmp_path):
                          "--icp", icp] + common)
         assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["tracking"]["lost_frames"] == 0
         assert two["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"], icp
-    # ... and the default engine (hsk_group_* in the rank form) with its direct exchange: two OS processes, a slab each,
-    # peer buffers through hipIpc handles, flags on a shared page -- what `bench.py --gpus N` runs on an N-GPU node
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    two = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                     "--master-port", str(port), "bench.py", "--gpus", "2", "--share-gpu", "--exchange", "direct"] + common)
-    assert two["n_gpus"] == 2 and two["config"]["exchange"].startswith("direct") and two["tracking"]["lost_frames"] == 0
-    assert two["stage_us"]["exchange_us"] > 0 and two["stage_us"]["slab_work_us"] > 0
-    assert two["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"]
+    # ... and the default engine (hsk_group_* in the rank form): `python bench.py --gpus 2` BARE -- the launcher starts two
+    # fresh worker processes per form, a slab each, all on device 0 here.  RCCL refuses two ranks on one device
+    # ("Duplicate GPU"), so its two forms must be recorded as failed and the run must still end with the direct form's
+    # checked result: peer buffers through hipIpc handles, flags on a shared page -- what runs on an N-GPU node
+    for launch in ("bare", "torchrun"):
+        if launch == "bare":
+            cmd = [sys.executable, "bench.py"]
+        else:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), "bench.py"]
+        two = last_json(cmd + ["--gpus", "2", "--share-gpu", "--steps", "6", "--warmup", "2", "--volume", "256", "--no-1024"])
+        assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["headline_form"] == "direct", (launch, two)
+        assert two["config"]["exchange"].startswith("one-hop") and two["tracking"]["lost_frames"] == 0
+        assert two["matches_single_gpu"] is True and two["ranks_seen"] == 2
+        assert two["forms"]["direct"]["matches_detail"]["planes_compared"] >= 256
+        assert two["stage_us"]["exchange_us"] > 0 and two["stage_us"]["slab_work_us"] > 0
+        assert "failed" in two["forms"]["rccl"] and "rccl@256" in two["launcher"]["failed_forms"], two["forms"]["rccl"]
+        assert two["rooms_weak"]["rooms"] == 2 and two["rooms_weak"]["lost_frames"] == 0 and two["rooms_weak"]["matches_single_gpu"] is True
+        assert two["single_gpu_same_frames"]["lost_frames"] == 0
+        assert two["predicted_us"] is None   # (DESIGN section 6 prices 512^3 and 1024^3 only)
+    one6 = last_json([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--volume", "256", "--quick"])
+    assert two["tracking"]["final_pose_f32_hex"] == one6["tracking"]["final_pose_f32_hex"] == two["single_gpu_same_frames"]["final_pose_f32_hex"]
 
 
 def test_bench_group_engine_world_of_one(tmp_path):
@@ -1059,3 +1074,10 @@ def test_bench_group_engine_world_of_one(tmp_path):
     assert grp["config"]["parallelism"].startswith("slab1") and grp["tracking"]["lost_frames"] == 0
     assert grp["scaling"] == "strong" and grp["rooms_weak"]["scaling"] == "weak" and grp["rooms_weak"]["lost_frames"] == 0
     assert grp["tracking"]["final_pose_f32_hex"] == one["tracking"]["final_pose_f32_hex"]
+    # every form ran (a world of one rank: ncclCommInitRank with world 1, the all-reduced ICP, the direct form) and every
+    # one of them equals the single context pose for pose and plane for plane
+    assert grp["launcher"]["failed_forms"] == {} and grp["ranks_seen"] == 1
+    for f in ("rccl", "rccl_icp_allreduce", "direct"):
+        assert grp["forms"][f]["matches_single_gpu"] is True and grp["forms"][f]["lost_frames"] == 0, f
+    # ... and the launcher's single-context worker is the same measurement as run_single's (within the noise of 12 frames)
+    assert 0.5 < grp["single_gpu_same_frames"]["value"] / one["value"] < 2.0

@@ -123,3 +123,38 @@ def test_readout_in_the_middle_of_a_pipelined_stream(hsk, oracle, synth_frames, 
     assert_same_bits(trk.download_tsdf(), ot.volume(), f"{n}^3: final volume")
     ot.close()
     trk.close()
+
+
+def test_track_stream_restarts_on_the_frame_after_a_lost_one(hsk, synth_frames, tmp_path):
+    """hsk_track_stream keeps a frame in flight; when frame i loses tracking, frame i + 1 has already been
+    dropped on the device -- the feed must read it again and resubmit it as the first frame of the restarted scan, so that
+    poses, verdicts and the volume stay exactly those of hsk_process_frame on the same frames (lost frames back to back, a
+    lost frame second to last and last included)."""
+    zero = np.zeros((480, 640), np.uint16)
+    seq = [synth_frames(k)[1] for k in range(6)] + [zero] + [synth_frames(k)[1] for k in range(6, 10)] + [zero, zero] + \
+          [synth_frames(k)[1] for k in range(10, 14)] + [zero] + [synth_frames(14)[1]] + [zero]
+    path = str(tmp_path / "with_holes.hskd")
+    w = hsk.DepthStreamWriter(path)
+    for d in seq:
+        w.write(d)
+    w.close()
+    rd = hsk.DepthStreamReader(path)
+    for n in (64, 128):
+        ref = hsk.KinfuTracker(n=n)
+        want = [ref.process_frame(d) for d in seq]
+        trk = hsk.KinfuTracker(n=n)
+        pa, oka = trk.track_stream(rd, 0, 7)       # ends ON the lost frame: the next call starts on the restart frame
+        pb, okb = trk.track_stream(rd, 7, len(seq) - 7)
+        poses, ok = np.concatenate([pa, pb]), np.concatenate([oka, okb])
+        assert [bool(o) for o in ok] == [o for _, o in want], n
+        assert sum(1 for _, o in want if not o) >= 9   # frame 0, four lost frames and the frame after each
+        assert_same_bits(poses, np.stack([p for p, _ in want]), f"{n}^3: poses of a stream with lost frames, feed vs hsk_process_frame")
+        assert_same_bits(trk.download_tsdf(), ref.download_tsdf(), f"{n}^3: TSDF after a stream with lost frames")
+        one = hsk.KinfuTracker(n=n)                # ... and in ONE call
+        pc, okc = one.track_stream(rd, 0, len(seq))
+        assert_same_bits(pc, poses, "one call vs two")
+        assert list(okc) == list(ok)
+        assert_same_bits(one.download_tsdf(), ref.download_tsdf(), "one call: TSDF")
+        for t in (ref, trk, one):
+            t.close()
+    rd.close()
