@@ -326,6 +326,16 @@ static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams&
   return (((((size_t)(zb >> 3) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 + (size_t)((x0 >> 2) & 15)) * 2 +
          (size_t)((zb >> 2) & 1);
 }
+// Where the 16-B vector of voxels x0 .. x0 + 3 (x0 a multiple of 4) of row y, stored plane zb + u (zb a multiple of 4,
+// u in 0 .. 3) sits in the volume, in vectors.  VIDX needs `vp`, `x0`, `y` and (linear form) `idx0`, `plane_vec` in scope.
+#ifdef HSK_BLOCKED_VOL
+static __device__ __forceinline__ size_t hsk_bbase(const VolParams& vp, int x0, int y, int zb) {
+  return ((((size_t)(zb >> 2) * vp.Y + (size_t)y) * (size_t)(vp.X >> 2)) + (size_t)(x0 >> 2)) << 2;
+}
+#define VIDX(zbv, u) (hsk_bbase(vp, x0, y, (zbv)) + (size_t)(u))
+#else
+#define VIDX(zbv, u) (idx0 + (size_t)((zbv) + (u)) * plane_vec)
+#endif
 static __device__ __forceinline__ unsigned hsk_uniform_code(unsigned word) {
   const unsigned w = word >> 16;
   if (word == 0u) return 1u;
@@ -435,6 +445,14 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
     pn[j] = gx * gx + gy * gy;
   }
   const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
+  // The brick flag of the lane-block (its 4 planes lie in one brick: zb is a multiple of 4, a brick's edge of 8 or more) is
+  // requested HERE, with the trip's first loads, and acted on once after the last plane.  Looked up where a plane turns
+  // out to hold a new negative value, it was a load whose result the very next branch needs: a full drain of the
+  // wave's memory queue (the stores of the planes before it included) up to four times a trip.
+  unsigned flag_word = 0u;
+  bool neg_any = false;
+  const int fbit = ((zb >> vp.bshift) * (vp.Y >> vp.bshift) + (y >> vp.bshift)) * (vp.X >> vp.bshift) + (x0 >> vp.bshift);
+  if (!COUNT_ONLY && planes != 0u) flag_word = flags[fbit >> 5];
 #pragma unroll
   for (int h0 = 0; h0 < 4; h0 += U) {
     bool inr[U];
@@ -451,34 +469,40 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         q[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (inr[u]) q[u] = vol[idx0 + (size_t)(zb + h0 + u) * plane_vec];
+        if (inr[u]) q[u] = vol[VIDX(zb, h0 + u)];
       }
     }
     // 2. projection of the 4U voxel centres (A.4, exact), then their depth gathers
     float D[U][4];  // scaled depth at the voxel's pixel, 0 when it has none; afterwards the observation F
     float gz2[U];
     int pix[U][4];
+    // the gathers of the trip's first planes are requested before the later planes are projected: their round trip
+    // runs under that arithmetic instead of ahead of a wait
+    static_assert(U == 4, "the trip is taken as two halves of two planes");
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float gz = ((float)(vp.zs0 + zb + h0 + u) + 0.5f) * vp.cell[2] - P.tz;
-      const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
-      gz2[u] = gz * gz;
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float camz = az[j] + bz;
-        const float inv_z = hsk_rcp_exact(camz);
-        const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
-        const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
-        // (|f| >= 1e6 of the specification's guard: the conversion saturates far beyond W and H, the bound test rejects it)
-        const int uu = (int)rintf(fu), vv = (int)rintf(fv);
-        const bool ok = inr[u] && camz >= 1.17549435e-38f && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
-        pix[u][j] = ok ? vv * W + uu : -1;
+      for (int u = 2 * half; u < 2 * half + 2; ++u) {
+        const float gz = ((float)(vp.zs0 + zb + h0 + u) + 0.5f) * vp.cell[2] - P.tz;
+        const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
+        gz2[u] = gz * gz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float camz = az[j] + bz;
+          const float inv_z = hsk_rcp_exact(camz);
+          const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
+          const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
+          const int uu = (int)rintf(fu), vv = (int)rintf(fv);
+          const bool ok = inr[u] && camz >= 1.17549435e-38f && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
+          pix[u][j] = ok ? vv * W + uu : -1;
+        }
       }
+#pragma unroll
+      for (int u = 2 * half; u < 2 * half + 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) D[u][j] = scaled[max(pix[u][j], 0)];
+      if (half == 0) asm volatile("" ::: "memory");  // (keeps the first half's gathers ahead of the second half's arithmetic)
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) D[u][j] = scaled[max(pix[u][j], 0)];
     // 3. the observation: F in [-1, 1] for a voxel the rule rewrites, -4 for one it leaves alone
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -530,11 +554,11 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
       }
       // (saturated free space -- +1 at the weight cap -- comes back unchanged: no store)
       if (nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3])
-        vol[idx0 + (size_t)(zb + h0 + u) * plane_vec] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-      if (neg) mark_brick_negative(flags, vp, x0, y, zb + h0 + u);
-
+        vol[VIDX(zb, h0 + u)] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+      neg_any = neg_any || neg;
     }
   }
+  if (!COUNT_ONLY && neg_any && ((flag_word >> (fbit & 31)) & 1u) == 0u) mark_brick_negative(flags, vp, x0, y, zb);
   return cnt;
 }
 
@@ -551,29 +575,46 @@ extern "C" int hsk_debug_pa_times(unsigned long long* out, int n) {
 #else
 #define PA_STAMP(k) do { } while (0)
 #endif
+// (below, lane predicates are joined by & and |, without short-circuit evaluation: `a && b` on lane-varying conditions is
+// compiled into a lane-mask branch round b -- s_and_saveexec / s_cbranch_execz, scalar instructions, which pass A is short of)
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const int2* __restrict__ wgz,
-                                                   const int2* __restrict__ zint, int zchunk, int W, int H,
-                                                   unsigned char* __restrict__ uni, const float2* __restrict__ dtab, int tw, int th,
+                                                   const int2* __restrict__ zint, int zchunk, unsigned gxa, unsigned gmagic,
+                                                   double* __restrict__ icp_slot0, unsigned char* __restrict__ uni,
+                                                   const float2* __restrict__ dtab, int W, int H, int tw, int th, unsigned gya,
                                                    uint4* __restrict__ vol, const float* __restrict__ scaled, VolParams vp,
                                                    Intr in, unsigned long long* __restrict__ counter,
                                                    unsigned* __restrict__ flags,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
-                                                   const float2* __restrict__ qtab, double* __restrict__ icp_slot0,
-                                                   IntegrateConst k) {
+                                                   const float2* __restrict__ qtab, IntegrateConst k) {
+  // Half of the launch's workgroups lie outside the view frustum, and what they execute before they find that out is a
+  // tenth of the kernel's scalar instructions: the test comes FIRST and runs on what arrives with the wave -- the
+  // arguments preloaded into SGPRs (the x-block count and its reciprocal for the rotation: `% gridDim.x` was a hidden-
+  // argument load and twenty instructions of division) and ONE scalar load, the footprint's z range.
+  const unsigned gdx = gxa, gdy = gya;  // the launch's grid (x blocks per row, rows of blocks)
+  const unsigned bsum = blockIdx.x + blockIdx.y + blockIdx.z;
+  const unsigned bxr = bsum - __umulhi(bsum, gmagic) * gdx;  // bsum % gdx: exact for bsum < 2^16 (gmagic = 2^32 / gdx + 1)
+  const unsigned byr = blockIdx.y;  // (rotating the rows with the chunk as well changes nothing: 42.2-42.9 us against 41.7)
+  const int zbeg = blockIdx.z * zchunk;
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
-  // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the test below)
-  if (!COUNT_ONLY && icp_slot0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-    for (int i = threadIdx.y * 64 + threadIdx.x; i < ICP_SLOT_DOUBLES; i += 256)
-      __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // dtab: per 16x16-pixel tile (max, min-if-all-valid) of the scaled depth, 3x3-dilated.  It is 9.6 KB and stays
-  // hot in every CU's vector L1; staging it in LDS per workgroup cost ~2.5 us of each short-lived block's life.
+  // one launch later, for the next frame's first iteration -- also on a lost frame, hence before the tests below)
+  if (!COUNT_ONLY && bsum == 0u) {
+    if (icp_slot0)
+      for (int i = threadIdx.y * 64 + threadIdx.x; i < ICP_SLOT_DOUBLES; i += 256)
+        __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    // (zend = min(zbeg + zchunk, nzs) is not needed here: the footprint's range ends below nzs)
+    const unsigned long long w2 = *(const unsigned long long*)(wgz + (byr * gdx + bxr));  // (x = low word, y = high word)
+    const int wz_x = (int)(unsigned)w2, wz_y = (int)(unsigned)(w2 >> 32);
+    if ((zbeg > wz_y) | (zbeg + zchunk - 1 < wz_x)) return;
+  }
   const int lane = threadIdx.x;
   if (!COUNT_ONLY && st->lost) return;
 #ifdef HSK_PA_TIMING
-  const unsigned pa_wave = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4u + threadIdx.y);
+  const unsigned pa_wave = (((blockIdx.z * gdy + blockIdx.y) * gdx + blockIdx.x) * 4u + threadIdx.y);
   if (!COUNT_ONLY && lane == 0 && pa_wave < 65536u) {
     for (int q = 0; q < 8; ++q) g_pa_times[pa_wave * 8 + q] = 0ull;
     g_pa_times[pa_wave * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
@@ -582,28 +623,19 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
   PA_STAMP(0);
   // wave footprint: 64 voxels in x (16 lanes x 16 B = 256 contiguous bytes) by 4 rows in y -- compact, so
   // that the wave-uniform z range and the group classification reject whole planes, not just lanes
-  // Which x block a workgroup takes rotates with its row and its chunk.  Workgroups go round the eight XCDs in turn, and a
-  // volume of 512 voxels has exactly eight blocks per row: unrotated, every workgroup of x block b ran on XCD b, and the
-  // frustum covers the middle blocks of a row far more than the outer ones -- the XCDs' loads differed by as much
+  // Which x block a workgroup takes rotates with its row and its chunk (bxr above).  Workgroups go round the eight XCDs in
+  // turn, and a volume of 512 voxels has exactly eight blocks per row: unrotated, every workgroup of x block b ran on XCD b,
+  // and the frustum covers the middle blocks of a row far more than the outer ones -- the XCDs' loads differed by as much
   // (profiles/r02/raycast_split_experiment.md met the same aliasing).
-  const unsigned bxr = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
-  const unsigned byr = blockIdx.y;  // (rotating the rows with the chunk as well changes nothing: 42.2-42.9 us against 41.7)
   const int x0 = (int)(bxr * 16u + (unsigned)(lane & 15)) * 4;
   const int y = (int)(byr * 4u + threadIdx.y) * 4 + (lane >> 4);
-  const bool active = (x0 < vp.X) && (y < vp.Y);
+  const bool active = (x0 < vp.X) & (y < vp.Y);
   unsigned long long cnt = 0;
-  const int zbeg = blockIdx.z * zchunk;
   const int zend = min(zbeg + zchunk, vp.nzs);
-  {
-    // the z range of this workgroup's whole x-y footprint (k_column_zrange): a chunk outside it holds nothing to do for any
-    // lane -- half of pass A's workgroups, which thus leave on one scalar load
-    const int2 wz = wgz[byr * gridDim.x + bxr];
-    if (zbeg > wz.y || zend - 1 < wz.x) return;
-  }
   // ... and of this wave's own footprint (16 lane columns x 4 rows): the wave-uniform loop bounds, without a wave-wide
   // reduction of the lanes' ranges (min over lanes of max(zl, zbeg) = max(min zl, zbeg)); a wave with nothing to do
   // leaves here, its lanes' ranges never loaded
-  const int4 wv = ((const int4*)(wgz + (((size_t)gridDim.x * gridDim.y + 1) & ~(size_t)1)))[(size_t)(byr * gridDim.x + bxr) * 4 +
+  const int4 wv = ((const int4*)(wgz + (((size_t)gdx * gdy + 1) & ~(size_t)1)))[(size_t)(byr * gdx + bxr) * 4 +
                                                                                           (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y)];
   const int wl = max(wv.x, zbeg), wh = min(wv.y, zend - 1);
   int zl = 0x7fffffff, zh = -0x7fffffff;  // this lane's stored-plane range inside the padded frustum
@@ -670,15 +702,15 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       const int zb = zbs[sidx];
-      in_any_s[sidx] = actv[sidx] && (zb + 3 >= zl) && (zb <= zh) && active;
-      in_all_s[sidx] = actv[sidx] && (zb >= zl) && (zb + 3 <= zh) && active;
+      in_any_s[sidx] = actv[sidx] & (zb + 3 >= zl) & (zb <= zh) & active;
+      in_all_s[sidx] = actv[sidx] & (zb >= zl) & (zb + 3 <= zh) & active;
       const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - tz;  // centre of planes zb .. zb+3
       const float czc = c.azc + i22 * gz;
       const float rc = __builtin_amdgcn_rcpf(czc);
       const float uc = (c.axfc + (i02 * gz) * in.fx) * rc + in.cx;
       const float vc = (c.ayfc + (i12 * gz) * in.fy) * rc + in.cy;
       const float r = k.rk4 * rc + 2.5f;
-      ok_s[sidx] = czc > k.zmin4 && fabsf(uc - k.hw) + r <= k.hw && fabsf(vc - k.hh) + r <= k.hh;
+      ok_s[sidx] = (czc > k.zmin4) & (fabsf(uc - k.hw) + r <= k.hw) & (fabsf(vc - k.hh) + r <= k.hh);
       const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
       Dt_s[sidx] = dtab[tv * tw + tu];
       dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
@@ -690,10 +722,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       const float dc = dc_s[sidx];
-      const bool dead4 = ok_s[sidx] && (dc * 0.99999f - Dt_s[sidx].x > k.cull_thr4);
-      const bool free44 = in_all_s[sidx] && ok_s[sidx] && (dc * 1.00001f + k.free_thr4 <= Dt_s[sidx].y);
+      const bool dead4 = ok_s[sidx] & (dc * 0.99999f - Dt_s[sidx].x > k.cull_thr4);
+      const bool free44 = in_all_s[sidx] & ok_s[sidx] & (dc * 1.00001f + k.free_thr4 <= Dt_s[sidx].y);
       free44_s[sidx] = free44;
-      other_s[sidx] = in_any_s[sidx] && !dead4 && !free44;
+      other_s[sidx] = in_any_s[sidx] & !dead4 & !free44;
     }
     unsigned sum8[NS];
 #pragma unroll
@@ -738,13 +770,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
       }
       umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
       // the 4-px table when the box spans at most 3 x 3 of its tiles, else the 8-px one (at most 3 x 3 again, else undecided)
-      const bool in_img = zmn > 0.05f && umin >= 0.0f && vmin >= 0.0f && umax <= (float)(W - 1) && vmax <= (float)(H - 1);
+      const bool in_img = (zmn > 0.05f) & (umin >= 0.0f) & (vmin >= 0.0f) & (umax <= (float)(W - 1)) & (vmax <= (float)(H - 1));
       const int iu0 = (int)umin, iv0 = (int)vmin, iu1 = (int)umax, iv1 = (int)vmax;
-      const bool fine = (iu1 >> 2) <= (iu0 >> 2) + 2 && (iv1 >> 2) <= (iv0 >> 2) + 2;
+      const bool fine = ((iu1 >> 2) <= (iu0 >> 2) + 2) & ((iv1 >> 2) <= (iv0 >> 2) + 2);
       const int sh = fine ? 2 : 3;
       const int tu0 = iu0 >> sh, tv0 = iv0 >> sh;
       const int nx = (iu1 >> sh) - tu0, ny = (iv1 >> sh) - tv0;  // tiles spanned, less one
-      const bool ok2 = in_img && nx <= 2 && ny <= 2;
+      const bool ok2 = in_img & (nx <= 2) & (ny <= 2);
       const float2* __restrict__ tab = fine ? qtab : ftab;
       const int tbw = fine ? 2 * fw : fw, tbh = fine ? 2 * fh : fh;
       // (one look-up: table (nx, ny) holds the (max, min) of the nx x ny tiles from each tile on, k_tile_window)
@@ -756,10 +788,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
       const float gz2_hi = fmaxf(gza * gza, gzb * gzb);
       const float gz2_lo = (gza <= 0.0f && gzb >= 0.0f) ? 0.0f : fminf(gza * gza, gzb * gzb);
       const float d_hi = __builtin_amdgcn_sqrtf(pn_hi + gz2_hi), d_lo = __builtin_amdgcn_sqrtf(pn_lo + gz2_lo);
-      const bool dead2 = ok2 && (d_lo * 0.99999f - Dx > k.cull_thr2);
-      const bool free2 = in_all_s[sidx] && ok2 && (d_hi * 1.00001f + k.free_thr2 <= Dn);
-      if (other_s[sidx] && free2) free44_s[sidx] = true;
-      other_s[sidx] = other_s[sidx] && !dead2 && !free2;
+      const bool dead2 = ok2 & (d_lo * 0.99999f - Dx > k.cull_thr2);
+      const bool free2 = in_all_s[sidx] & ok2 & (d_hi * 1.00001f + k.free_thr2 <= Dn);
+      free44_s[sidx] = free44_s[sidx] | (other_s[sidx] & free2);
+      other_s[sidx] = other_s[sidx] & !dead2 & !free2;
     }
     PA_STAMP(3);
 #ifdef HSK_PA_TIMING
@@ -776,7 +808,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
     // per row and wave index (the capacity bound).  Both groups' tickets are requested before either is used.
     // (the tickets are REQUESTED here, before the free-space loads, and used after the stores: the counters' round trip
     // runs under the volume's -- one dependent round trip less in a wave's life)
-    const unsigned lin = (blockIdx.z * gridDim.y + byr) * gridDim.x + bxr;
+    const unsigned lin = (blockIdx.z * gdy + byr) * gdx + bxr;
     const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
     // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_window)
     unsigned long long bo[NS];
@@ -810,7 +842,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
       bool rd[NS];
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) {
-        const bool fr = actv[sidx] && free44_s[sidx], ot = actv[sidx] && other_s[sidx];
+        const bool fr = actv[sidx] & free44_s[sidx], ot = actv[sidx] & other_s[sidx];
         const unsigned sm = sum8[sidx];
         const int sbit = 8 * ((zbs[sidx] - zbeg) >> 2);  // where the group's summary sits in new16
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
@@ -820,7 +852,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
           const unsigned word = (wstore << 16) | (unsigned)HSK_DIVISOR;
           const uint4 q = make_uint4(word, word, word, word);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q);
+          for (int u = 0; u < 4; ++u) store_vec(VIDX(zbs[sidx], u), q);
         }
         // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays;
         // 0 for a block on its way to pass B (the word is stored once, after the read path below)
@@ -842,10 +874,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (vp.stream_nt) {
-              const v4u t = __builtin_nontemporal_load((const v4u*)&vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec]);
+              const v4u t = __builtin_nontemporal_load((const v4u*)&vol[VIDX(zbs[sidx], u)]);
               q4[u] = make_uint4(t.x, t.y, t.z, t.w);
             } else {
-              q4[u] = vol[idx0 + (size_t)(zbs[sidx] + u) * plane_vec];
+              q4[u] = vol[VIDX(zbs[sidx], u)];
             }
           }
           const bool fr = actv[sidx] && free44_s[sidx];
@@ -853,13 +885,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
           if (sm == 0u) {  // (free) the update rule on whatever the block holds
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (update_vector_free4(q4[u])) store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[u]);
+              if (update_vector_free4(q4[u])) store_vec(VIDX(zbs[sidx], u), q4[u]);
           } else {  // the pending observations (and this frame's, for a free block) onto weights under +1
             const unsigned p = sm - HSK_SUM_RAGGED + (fr ? 1u : 0u);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               hsk_vector_add_weight(q4[u], p);
-              store_vec(idx0 + (size_t)(zbs[sidx] + u) * plane_vec, q4[u]);
+              store_vec(VIDX(zbs[sidx], u), q4[u]);
             }
           }
           if (fr) {
@@ -1074,15 +1106,16 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned nblk = grid.x * grid.y * (unsigned)zchunks;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
   const IntegrateConst kc = integrate_const(vp, W, H, in);
+  const unsigned gmagic = (unsigned)(0x100000000ull / grid.x) + 1u;  // n % grid.x = n - mulhi(n, gmagic) * grid.x for n < 2^16
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
-    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, st, wgz, zint, zchunk, W, H, (unsigned char*)nullptr, dil, tw, th,
-                       (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, (double*)nullptr, kc);
+    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
+                       W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   } else {
-    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, st, wgz, zint, zchunk, W, H, uni, dil, tw, th, (uint4*)vol, scaled, vp,
-                       in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, fin.slots, kc);
+    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
+                       (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   }
@@ -1115,11 +1148,13 @@ __global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char
   const int xl = (int)(i % qx), y = (int)((i / qx) % vp.Y), zb = (int)(i / ((size_t)qx * vp.Y)) * 4;
   const size_t ui = hsk_sum_index(vp, xl * 4, y, zb);
   const size_t plane_vec = (size_t)vp.X * vp.Y / 4, idx0 = (size_t)y * qx + xl;
+  const int x0 = xl * 4;
+  (void)x0; (void)plane_vec; (void)idx0;
   if (!MATERIALIZE) {
     unsigned code = 0u;
     if (zb + 3 < vp.nzs) {
       uint4 q[4];
-      for (int u = 0; u < 4; ++u) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+      for (int u = 0; u < 4; ++u) q[u] = vol[VIDX(zb, u)];
       code = hsk_sum_classify(q);
     }
     uni[ui] = (unsigned char)code;
@@ -1128,13 +1163,13 @@ __global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char
   const unsigned sm = uni[ui];
   if (sm >= 2u && sm < HSK_SUM_RAGGED) {
     const unsigned word = ((sm - 1u) << 16) | (unsigned)HSK_DIVISOR;
-    for (int u = 0; u < 4; ++u) vol[idx0 + (size_t)(zb + u) * plane_vec] = make_uint4(word, word, word, word);
+    for (int u = 0; u < 4; ++u) vol[VIDX(zb, u)] = make_uint4(word, word, word, word);
   } else if (sm > HSK_SUM_RAGGED) {
     uint4 q[4];
-    for (int u = 0; u < 4; ++u) q[u] = vol[idx0 + (size_t)(zb + u) * plane_vec];
+    for (int u = 0; u < 4; ++u) q[u] = vol[VIDX(zb, u)];
     for (int u = 0; u < 4; ++u) {
       hsk_vector_add_weight(q[u], sm - HSK_SUM_RAGGED);
-      vol[idx0 + (size_t)(zb + u) * plane_vec] = q[u];
+      vol[VIDX(zb, u)] = q[u];
     }
     uni[ui] = (unsigned char)hsk_sum_classify(q);
   }

@@ -3,7 +3,7 @@ source "$(dirname "$0")/restore_default.sh"
 cd ${GRAFT_REPO_ROOT:-.}
 for v in "$@"; do
   touch housescan_amd/csrc/*.hip
-  make -s -C housescan_amd/csrc FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-function $v" 2>&1 | grep -E "error"
+  make -s -C housescan_amd/csrc FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-function -Wno-bitwise-instead-of-logical $v" 2>&1 | grep -E "error"
   for n in 512 1024; do
     python bench.py --allow-exp --steps 100 --warmup 10 --no-cpu-baseline --volume $n 2>&1 | grep -o '{"metric.*' | python -c "
 import json,sys

@@ -6,7 +6,7 @@ source "$(dirname "$0")/restore_default.sh"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 tag=$1; shift
-BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function"
+BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical"
 BARGS="--steps 40 --warmup 5"
 i=0
 for defs in "$@"; do
