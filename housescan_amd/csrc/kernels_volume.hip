@@ -595,7 +595,8 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
   // argument load and twenty instructions of division) and ONE scalar load, the footprint's z range.
   const unsigned gdx = gxa, gdy = gya;  // the launch's grid (x blocks per row, rows of blocks)
   const unsigned bsum = blockIdx.x + blockIdx.y + blockIdx.z;
-  const unsigned bxr = bsum - __umulhi(bsum, gmagic) * gdx;  // bsum % gdx: exact for bsum < 2^16 (gmagic = 2^32 / gdx + 1)
+  // bsum % gdx: exact for bsum < 2^16 with gmagic = 2^32 / gdx + 1; a single x block (gmagic = 0: the reciprocal does not fit) is 0
+  const unsigned bxr = gmagic != 0u ? bsum - __umulhi(bsum, gmagic) * gdx : 0u;
   const unsigned byr = blockIdx.y;  // (rotating the rows with the chunk as well changes nothing: 42.2-42.9 us against 41.7)
   const int zbeg = blockIdx.z * zchunk;
   // (when k_column_zrange has done the frame's last ICP solve: the accumulator slot all its blocks read is emptied here,
@@ -1106,7 +1107,8 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned nblk = grid.x * grid.y * (unsigned)zchunks;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
   const IntegrateConst kc = integrate_const(vp, W, H, in);
-  const unsigned gmagic = (unsigned)(0x100000000ull / grid.x) + 1u;  // n % grid.x = n - mulhi(n, gmagic) * grid.x for n < 2^16
+  // n % grid.x = n - mulhi(n, gmagic) * grid.x for n < 2^16; 0 for a single x block (the kernel takes 0 for the remainder)
+  const unsigned gmagic = grid.x > 1u ? (unsigned)(0x100000000ull / grid.x) + 1u : 0u;
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import housescan_amd as hsk
 from oracle import oracle
 bad = 0
-for n in [int(a) for a in sys.argv[1:]] or [128, 256]:
+for n in [int(a) for a in sys.argv[1:]] or [64, 128, 256]:  # (64: one x block per row, the smallest grid)
     cfg = oracle.default_config(n, omp=True)
     trk = hsk.KinfuTracker(n=n)
     vol = np.zeros((n, n, n, 2), np.int16)
