@@ -532,7 +532,7 @@ def slab_halo_planes(n, size_m=3.0, trunc=0.03):
     """planes a slab stores beyond its own on each side (hskinfu_group.hip: slab_halo)"""
     cell = size_m / n
     tau = max(trunc, 2.1 * cell)
-    return int(np.ceil(1.5 * 0.8 * tau / cell)) + 3
+    return int(np.ceil(2.0 * 0.8 * tau / cell)) + 3
 
 
 def predicted_us(n, G):

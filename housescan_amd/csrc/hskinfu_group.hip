@@ -242,15 +242,16 @@ static void slab_range(int i, int n, int Z, int* z0, int* z1) {
   *z0 = i * base + (i < rem ? i : rem);
   *z1 = *z0 + base + (i < rem ? 1 : 0);
 }
-// planes a slab stores beyond what it owns: an owned raycast step reads its near sample (one step back) and the refined
-// vertex within [t - step/2, t + 3 step/2] (deviation D3), +-1 cell for the normal taps, +-1 voxel for the trilinear taps
+// planes a slab stores beyond what it owns: an owned raycast step (its FAR sample lies in an owned plane) reads its near
+// sample (one step back) and the refined vertex within [t - step, t + 2 step] (deviation D3): two steps either side of
+// the far sample's plane at most, +-1 cell for the normal taps, +-1 voxel for the trilinear taps
 static int slab_halo(const hsk_config* c) {
   float m = c->vol_size_m[0] / (float)c->vol_x;
   const float cy = c->vol_size_m[1] / (float)c->vol_y, cz = c->vol_size_m[2] / (float)c->vol_z;
   m = m > cy ? m : cy;
   m = m > cz ? m : cz;
   const float tau = c->trunc_dist_m > 2.1f * m ? c->trunc_dist_m : 2.1f * m;
-  const float steps = 1.5f * (0.8f * tau) / cz;
+  const float steps = 2.0f * (0.8f * tau) / cz;
   int h = (int)steps;
   if ((float)h < steps) ++h;
   return h + 3;

@@ -38,13 +38,15 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
   for (int i = tid; i < BIL_S * BIL_S; i += 256) {
     const int ly = i / BIL_S, lx = i % BIL_S;
     const int gx = bx + lx - BIL_R, gy = by + ly - BIL_R;
-    tile[ly][lx] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? (int)src[gy * W + gx] : -1;
+    // (the windows' upper clip is exclusive of the image's last column and row -- upstream's loop bounds,
+    // cx < min(x - 6 + 13, W - 1): those pixels are in no window, not even their own)
+    tile[ly][lx] = (gx >= 0 && gy >= 0 && gx < W - 1 && gy < H - 1) ? (int)src[gy * W + gx] : -1;
   }
   for (int i = tid; i < 512; i += 256) wc[i] = wc_tab[i];
   __syncthreads();
   const int x = bx + threadIdx.x, y = by + threadIdx.y;
   const bool inside = x < W && y < H;
-  const int value = inside ? tile[threadIdx.y + BIL_R][threadIdx.x + BIL_R] : 0;
+  const int value = inside ? (int)src[y * W + x] : 0;
   // scaleDepth (A.4), and this 16x16 tile's (max, min) of it for the integrate kernel's group classification:
   // a pixel outside the image or without depth makes the tile minimum 0 ("not all valid")
   float sc = 0.0f;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
       }
     }
   }
-  int res = __float2int_rn(sum1 / sum2);
+  int res = sum2 > 0.0f ? __float2int_rn(sum1 / sum2) : 0;  // (0 / 0: a last-column / last-row pixel whose window holds no weight)
   res = res < 0 ? 0 : (res > 32767 ? 32767 : res);
   dst[y * W + x] = (unsigned short)res;
 }
@@ -131,8 +133,8 @@ __global__ void k_pyrdown(const unsigned short* __restrict__ src, int W, int H, 
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w2 || y >= h2) return;
   const int center = src[(2 * y) * W + 2 * x];
-  const int y0 = max(2 * y - 2, 0), y1 = min(2 * y + 2, H - 1);
-  const int x0 = max(2 * x - 2, 0), x1 = min(2 * x + 2, W - 1);
+  const int y0 = max(2 * y - 2, 0), y1 = min(2 * y + 2, H - 2);  // (upper clip exclusive of the last row / column, as the bilateral's)
+  const int x0 = max(2 * x - 2, 0), x1 = min(2 * x + 2, W - 2);
   int sum = 0, count = 0;
   for (int cy = y0; cy <= y1; ++cy)
     for (int cx = x0; cx <= x1; ++cx) {

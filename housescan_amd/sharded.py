@@ -37,10 +37,10 @@ def slab_range(rank, world, Z):
 
 def slab_halo(tau, cell_z):
     """Planes a slab must store beyond what it owns: an owned raycast step reads its near sample (one step
-    back), the refined vertex within [t - step/2, t + 3 step/2] (oracle D3), +-1 cell for the normal taps and
-    +-1 voxel for the trilinear taps."""
+    back), the refined vertex within [t - step, t + 2 step] (oracle D3: two steps either side of the far sample's
+    plane), +-1 cell for the normal taps and +-1 voxel for the trilinear taps."""
     step = 0.8 * tau
-    return int(math.ceil(1.5 * step / cell_z)) + 3
+    return int(math.ceil(2.0 * step / cell_z)) + 3
 
 
 def row_range(rank, world, H):

@@ -29,7 +29,7 @@
 /* ORA_LITERAL = every deviation taken back out; the single switches exist so that tools/spec_vs_literal.py can attribute
  * the difference to its causes (one variant library per switch, oracle/Makefile: variant) */
 #ifdef ORA_LITERAL
-#define ORA_LIT_D1 1 /* bilateral: one expf per tap, exclusive window clip, zero centre filtered */
+#define ORA_LIT_D1 1 /* bilateral: one expf per tap, zero centre filtered (the exclusive window clip is the specification's too) */
 #define ORA_LIT_D3 1 /* raycast: extrapolated hit times accepted */
 #define ORA_LIT_D4 1 /* ICP: plain binary64 sums, LLT Cholesky, libm sinf / cosf */
 #define ORA_LIT_D6 1 /* integrate: "1 / z < 0" as the in-front test */
@@ -325,8 +325,10 @@ void ora_bilateral(const uint16_t* src, int W, int H, uint16_t* dst) {
         dst[y * W + x] = 0;
         continue;
       }
-      const int y0 = y - BIL_R < 0 ? 0 : y - BIL_R, y1 = y + BIL_R > H - 1 ? H - 1 : y + BIL_R;
-      const int x0 = x - BIL_R < 0 ? 0 : x - BIL_R, x1 = x + BIL_R > W - 1 ? W - 1 : x + BIL_R;
+      /* the window's upper clip is EXCLUSIVE of the image's last column / row, as upstream's loop bounds are
+       * (cx < min(x - 6 + 13, W - 1)): column W - 1 and row H - 1 are in no window, not even their own pixels' */
+      const int y0 = y - BIL_R < 0 ? 0 : y - BIL_R, y1 = y + BIL_R > H - 2 ? H - 2 : y + BIL_R;
+      const int x0 = x - BIL_R < 0 ? 0 : x - BIL_R, x1 = x + BIL_R > W - 2 ? W - 2 : x + BIL_R;
       float sum1 = 0.0f, sum2 = 0.0f;
       for (int cy = y0; cy <= y1; ++cy)
         for (int cx = x0; cx <= x1; ++cx) {
@@ -338,7 +340,7 @@ void ora_bilateral(const uint16_t* src, int W, int H, uint16_t* dst) {
           sum1 = sum1 + (float)tmp * w;
           sum2 = sum2 + w;
         }
-      int res = (int)lrintf(sum1 / sum2);
+      int res = sum2 > 0.0f ? (int)lrintf(sum1 / sum2) : 0; /* (0 / 0: a last-column / last-row pixel whose window holds no weight) */
       if (res < 0) res = 0;
       if (res > 32767) res = 32767;
       dst[y * W + x] = (uint16_t)res;
@@ -352,8 +354,10 @@ void ora_pyrdown(const uint16_t* src, int W, int H, uint16_t* dst) {
   for (int y = 0; y < h2; ++y)
     for (int x = 0; x < w2; ++x) {
       const int center = src[(2 * y) * W + 2 * x];
-      const int y0 = 2 * y - 2 < 0 ? 0 : 2 * y - 2, y1 = 2 * y + 2 > H - 1 ? H - 1 : 2 * y + 2;
-      const int x0 = 2 * x - 2 < 0 ? 0 : 2 * x - 2, x1 = 2 * x + 2 > W - 1 ? W - 1 : 2 * x + 2;
+      /* upper clip exclusive of the last column / row, as in the bilateral (upstream: cx < min(2x - 2 + 5, W - 1)); the
+       * centre (2y, 2x) <= (H - 2, W - 2) is always inside.  Integer arithmetic: this IS the Appendix-A-literal form too. */
+      const int y0 = 2 * y - 2 < 0 ? 0 : 2 * y - 2, y1 = 2 * y + 2 > H - 2 ? H - 2 : 2 * y + 2;
+      const int x0 = 2 * x - 2 < 0 ? 0 : 2 * x - 2, x1 = 2 * x + 2 > W - 2 ? W - 2 : 2 * x + 2;
       int sum = 0, count = 0;
       for (int cy = y0; cy <= y1; ++cy)
         for (int cx = x0; cx <= x1; ++cx) {
@@ -710,6 +714,37 @@ void ora_pose_update(float R[9], float t[3], const float x6[6]) {
   memcpy(R, turned, sizeof(turned));
 }
 
+#ifdef ORA_D3_STATS
+/* study build (tools/d3_study.py): where the interpolated hit time of a zero crossing falls relative to the march step
+ * [t, t + step] that found it, in steps: bins (-inf,-4) [-4,-2) [-2,-1) [-1,-0.5) [-0.5,0) [0,1] (1,1.5] (1.5,2] (2,3] (3,5] (5,inf) NaN */
+static long long g_d3_bins[12];
+static void ora_d3_note(float r) {
+  int b;
+  if (isnan(r)) b = 11;
+  else if (r < -4.0f) b = 0;
+  else if (r < -2.0f) b = 1;
+  else if (r < -1.0f) b = 2;
+  else if (r < -0.5f) b = 3;
+  else if (r < 0.0f) b = 4;
+  else if (r <= 1.0f) b = 5;
+  else if (r <= 1.5f) b = 6;
+  else if (r <= 2.0f) b = 7;
+  else if (r <= 3.0f) b = 8;
+  else if (r <= 5.0f) b = 9;
+  else b = 10;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+  g_d3_bins[b] += 1;
+}
+void ora_d3_stats(long long out[12], int reset) {
+  for (int i = 0; i < 12; ++i) {
+    out[i] = g_d3_bins[i];
+    if (reset) g_d3_bins[i] = 0;
+  }
+}
+#endif
+
 /* ------------------------------------------------------------------------------------------------ */
 /* A.6 raycast                                                                                        */
 /* ------------------------------------------------------------------------------------------------ */
@@ -829,12 +864,16 @@ void ora_raycast(const int16_t* vol, const int dims[3], const float size[3], flo
             const float Ft = rc_trilinear(&V, pc);
             if (!isnan(Ft)) {
               const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
-              /* deviation from A.6: reject an interpolated time outside
-               * [t - step/2, t + 3 step/2]; bounds the taps to the slab halo. */
+#ifdef ORA_D3_STATS
+              ora_d3_note((Ts - time_curr) / time_step);
+#endif
+              /* deviation from A.6: reject an interpolated time outside [t - step, t + 2 step] -- two
+               * steps round the far sample, which bounds the taps to the slab halo; 99.8 % of the crossings of the
+               * scripted stream fall inside (tools/d3_study.py), A.6 as written keeps the extrapolated rest too. */
 #ifdef ORA_LIT_D3
               if (!isnan(Ts)) { /* A.6 as written: whatever the interpolation gives (also an extrapolated time) */
 #else
-              if (Ts >= time_curr - 0.5f * time_step && Ts <= time_curr + 1.5f * time_step) {
+              if (Ts >= time_curr - time_step && Ts <= time_curr + 2.0f * time_step) {
 #endif
                 const float vtx[3] = {t[0] + dir[0] * Ts, t[1] + dir[1] * Ts, t[2] + dir[2] * Ts};
                 vmap[i] = vtx[0];

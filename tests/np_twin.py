@@ -105,7 +105,7 @@ def pyrdown(src):
     for y in range(h2):
         for x in range(w2):
             c = s[2 * y, 2 * x]
-            win = s[max(2 * y - 2, 0):min(2 * y + 2, H - 1) + 1, max(2 * x - 2, 0):min(2 * x + 2, W - 1) + 1]
+            win = s[max(2 * y - 2, 0):min(2 * y + 2, H - 2) + 1, max(2 * x - 2, 0):min(2 * x + 2, W - 2) + 1]   # (exclusive upper clip)
             m = np.abs(win - c) < 90
             out[y, x] = win[m].sum() // m.sum()
     return out
@@ -174,7 +174,7 @@ def bilateral_tables():
 
 
 def bilateral(src):
-    """A.3 + D1: 13x13 window clipped to the image, weight = ws(dx, dy) * wc(|dd|) (wc = 0 from 512 mm on), a zero
+    """A.3 + D1: 13x13 window clipped to the image EXCLUSIVE of its last row and column (upstream's loop bounds), weight = ws(dx, dy) * wc(|dd|) (wc = 0 from 512 mm on), a zero
     centre gives 0, the sums run row by row through the window, result = rint(sum1 / sum2) clamped to [0, 32767]"""
     H, W = src.shape
     ws, wc = bilateral_tables()
@@ -185,7 +185,7 @@ def bilateral(src):
     for dy in range(-6, 7):
         for dx in range(-6, 7):
             ny, nx = yy + dy, xx + dx
-            inside = (ny >= 0) & (ny < H) & (nx >= 0) & (nx < W)
+            inside = (ny >= 0) & (ny < H - 1) & (nx >= 0) & (nx < W - 1)   # (upper clip exclusive of the last row / column)
             tmp = s[np.clip(ny, 0, H - 1), np.clip(nx, 0, W - 1)]
             dd = np.abs(s - tmp)
             wcv = np.where(dd < 512, wc[np.minimum(dd, 511)], f32(0)).astype(f32)
@@ -193,7 +193,7 @@ def bilateral(src):
             sum1 = np.where(inside, sum1 + tmp.astype(f32) * w, sum1).astype(f32)
             sum2 = np.where(inside, sum2 + w, sum2).astype(f32)
     with np.errstate(all="ignore"):
-        res = np.rint(sum1 / sum2)
+        res = np.where(sum2 > 0, np.rint(sum1 / sum2), 0)
     res = np.clip(np.where(s == 0, 0, res), 0, 32767)
     return np.where(s == 0, 0, res).astype(np.uint16)
 
@@ -469,7 +469,7 @@ def raycast(vol, size, trunc, W, H, fx, fy, cx, cy, pose, Z=None, zs0=0, zo0=0, 
                 Ft = G.trilinear(pcc)
                 with np.errstate(all="ignore"):
                     Ts = (tcc - (step_len * Ft) / (Ftdt - Ft)).astype(f32)
-                    good = ~np.isnan(Ftdt) & ~np.isnan(Ft) & (Ts >= tcc - f32(0.5) * step_len) & (Ts <= tcc + f32(1.5) * step_len)
+                    good = ~np.isnan(Ftdt) & ~np.isnan(Ft) & (Ts >= tcc - step_len) & (Ts <= tcc + f32(2.0) * step_len)
                 if good.any():
                     gi = np.nonzero(good)[0]
                     gsel = (csel[0][gi], csel[1][gi])

@@ -86,4 +86,4 @@ def test_slab_partition_helpers():
         assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
     assert [row_range(r, 4, 480) for r in range(4)] == [(0, 120), (120, 240), (240, 360), (360, 480)]
     # 512^3 / 3 m: step 24 mm = 4.1 cells -> 7 + 3
-    assert slab_halo(0.03, 3.0 / 512) == 10
+    assert slab_halo(0.03, 3.0 / 512) == 12   # ceil(2 * 0.024 / 0.00586) + 3
