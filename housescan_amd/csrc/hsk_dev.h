@@ -44,6 +44,27 @@ struct VolParams {
   int pad_;
 };
 
+// ---- where a voxel lives (round 4) ------------------------------------------------------------------------------------
+// The volume is stored in 64-B BLOCKS of one lane-block each -- 4 x-adjacent voxels by 4 consecutive stored planes, the
+// unit the integrate's two passes classify and rewrite: word index of voxel (x, y, stored plane zz)
+//     ((((zz >> 2) * Y + y) * (X / 4) + (x >> 2)) * 16) + (zz & 3) * 4 + (x & 3)
+// so a queued lane-block is ONE sector where the row-major layout had four, 1 MiB apart; x-adjacent lane-blocks stay
+// contiguous (a pass-A wave row: 16 lanes x 64 B = 1 KiB).  The index is a sum of one term per axis, so the raycast's
+// 2 x 2 x 2 taps cost two terms per axis and eight additions.  Stored planes are padded to a multiple of 4 (the padding is
+// never observed: weight 0).  Host arrays (hsk_download_tsdf / hsk_upload_tsdf) stay row-major, x fastest: the
+// conversion kernels are k_vol_to_linear / k_vol_from_linear.
+__host__ __device__ static inline size_t hsk_vox_xterm(int x) { return ((size_t)(x >> 2) << 4) + (size_t)(x & 3); }
+__host__ __device__ static inline size_t hsk_vox_yterm(const VolParams& vp, int y) { return (size_t)y * ((size_t)(vp.X >> 2) << 4); }
+__host__ __device__ static inline size_t hsk_vox_zterm(const VolParams& vp, int zz) {
+  return (size_t)(zz >> 2) * (size_t)vp.Y * ((size_t)(vp.X >> 2) << 4) + ((size_t)(zz & 3) << 2);
+}
+__host__ __device__ static inline size_t hsk_vox_index(const VolParams& vp, int x, int y, int zz) {
+  return hsk_vox_zterm(vp, zz) + hsk_vox_yterm(vp, y) + hsk_vox_xterm(x);
+}
+__host__ __device__ static inline size_t hsk_vol_words(const VolParams& vp) {  // allocation, in voxels (4 B each)
+  return (size_t)vp.X * vp.Y * (size_t)((vp.nzs + 3) & ~3);
+}
+
 #ifndef HSK_FLAG_WORDS_MAX
 #define HSK_FLAG_WORDS_MAX 1024  // 4 KiB
 #endif

@@ -18,6 +18,9 @@ size_t integrate_zint_entries(const VolParams& vp);  // column z ranges + workgr
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);
+// stored planes [zz0, zz0 + nz) of the volume (64-B blocks, hsk_dev.h: hsk_vox_index) to / from a row-major device array
+void launch_vol_to_linear(hipStream_t s, const void* vol, const VolParams& vp, int zz0, int nz, void* lin);
+void launch_vol_from_linear(hipStream_t s, void* vol, const VolParams& vp, int zz0, int nz, const void* lin);
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
                     float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid = nullptr,
                     const RingOut* ring = nullptr);

@@ -355,7 +355,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   }
   pose16_to_rt(c->init_pose, k->init_R, k->init_t);
   // memory
-  k->vol_bytes = (size_t)vp.X * vp.Y * vp.nzs * 4;
+  k->vol_bytes = hsk_vol_words(vp) * 4;  // (stored planes padded to whole 64-B blocks of 4 planes: hsk_dev.h, hsk_vox_index)
   vp.stream_nt = k->vol_bytes > ((size_t)1 << 30) ? 1 : 0;  // > 1 GiB: four times the Infinity Cache and more
   CK(hipMalloc(&k->d_vol, k->vol_bytes));
   const size_t P0 = (size_t)c->width * c->height;
@@ -1084,6 +1084,7 @@ extern "C" int hsk_icp_solve(const double in27[27], float x6[6], int* ok) {
   return HSK_OK;
 }
 
+#define HSK_COPY_PLANES 32  // planes converted per batch by hsk_download_tsdf / hsk_upload_tsdf (128 MiB of staging at 1024^3)
 extern "C" int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz) {
   if (!k) return HSK_ERR_ARG;
   if (z0) *z0 = k->vp.zs0;
@@ -1095,8 +1096,21 @@ extern "C" int hsk_download_tsdf(hsk_ctx* k, int16_t* out) {
   if (!k || !out) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   flush_weights(k);  // the weights of deep free space live in the summaries until read
-  HIPCHK(k, hipMemcpyAsync(out, k->d_vol, k->vol_bytes, hipMemcpyDeviceToHost, k->stream));
-  HIPCHK(k, hipStreamSynchronize(k->stream));
+  // the caller's array is row-major (x fastest, then y, then plane); the volume is stored in 64-B blocks: converted on the
+  // device, a batch of planes at a time, through a staging buffer that lives for this call
+  const size_t plane_bytes = (size_t)k->vp.X * k->vp.Y * 4;
+  const int batch = k->vp.nzs < HSK_COPY_PLANES ? k->vp.nzs : HSK_COPY_PLANES;
+  void* stage = nullptr;
+  HIPCHK(k, hipMalloc(&stage, plane_bytes * (size_t)batch));
+  hipError_t e = hipSuccess;
+  for (int zz0 = 0; zz0 < k->vp.nzs && e == hipSuccess; zz0 += batch) {
+    const int nz = k->vp.nzs - zz0 < batch ? k->vp.nzs - zz0 : batch;
+    launch_vol_to_linear(k->stream, k->d_vol, k->vp, zz0, nz, stage);
+    e = hipMemcpyAsync((char*)out + (size_t)zz0 * plane_bytes, stage, plane_bytes * (size_t)nz, hipMemcpyDeviceToHost, k->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  }
+  (void)hipFree(stage);
+  HIPCHK(k, e);
   return HSK_OK;
 }
 extern "C" int hsk_flush_weights(hsk_ctx* k) {
@@ -1109,7 +1123,23 @@ extern "C" int hsk_flush_weights(hsk_ctx* k) {
 extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
   if (!k || !in) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  HIPCHK(k, hipMemcpyAsync(k->d_vol, in, k->vol_bytes, hipMemcpyHostToDevice, k->stream));
+  {
+    const size_t plane_bytes = (size_t)k->vp.X * k->vp.Y * 4;
+    const int batch = k->vp.nzs < HSK_COPY_PLANES ? k->vp.nzs : HSK_COPY_PLANES;
+    void* stage = nullptr;
+    HIPCHK(k, hipMalloc(&stage, plane_bytes * (size_t)batch));
+    hipError_t e = hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream);  // (the padding planes of the last block row)
+    for (int zz0 = 0; zz0 < k->vp.nzs && e == hipSuccess; zz0 += batch) {
+      const int nz = k->vp.nzs - zz0 < batch ? k->vp.nzs - zz0 : batch;
+      e = hipMemcpyAsync(stage, (const char*)in + (size_t)zz0 * plane_bytes, plane_bytes * (size_t)nz, hipMemcpyHostToDevice, k->stream);
+      if (e == hipSuccess) {
+        launch_vol_from_linear(k->stream, k->d_vol, k->vp, zz0, nz, stage);
+        e = hipStreamSynchronize(k->stream);
+      }
+    }
+    (void)hipFree(stage);
+    HIPCHK(k, e);
+  }
   HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
   launch_rebuild_flags(k->stream, k->d_vol, k->vp, k->d_flags);
   launch_rebuild_uniform(k->stream, k->d_vol, k->vp, k->d_uni);

@@ -327,15 +327,12 @@ static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams&
          (size_t)((zb >> 2) & 1);
 }
 // Where the 16-B vector of voxels x0 .. x0 + 3 (x0 a multiple of 4) of row y, stored plane zb + u (zb a multiple of 4,
-// u in 0 .. 3) sits in the volume, in vectors.  VIDX needs `vp`, `x0`, `y` and (linear form) `idx0`, `plane_vec` in scope.
-#ifdef HSK_BLOCKED_VOL
+// u in 0 .. 3) sits in the volume, in vectors: the four vectors of a lane-block are consecutive (hsk_dev.h: hsk_vox_index).
+// VIDX needs `vp`, `x0`, `y` in scope.
 static __device__ __forceinline__ size_t hsk_bbase(const VolParams& vp, int x0, int y, int zb) {
   return ((((size_t)(zb >> 2) * vp.Y + (size_t)y) * (size_t)(vp.X >> 2)) + (size_t)(x0 >> 2)) << 2;
 }
 #define VIDX(zbv, u) (hsk_bbase(vp, x0, y, (zbv)) + (size_t)(u))
-#else
-#define VIDX(zbv, u) (idx0 + (size_t)((zbv) + (u)) * plane_vec)
-#endif
 static __device__ __forceinline__ unsigned hsk_uniform_code(unsigned word) {
   const unsigned w = word >> 16;
   if (word == 0u) return 1u;
@@ -431,7 +428,6 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
   static_assert(U == 1 || U == 2 || U == 4, "planes per trip");
   const int lane = threadIdx.x & 63;
   (void)lane;
-  const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
   const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
   unsigned cnt = 0;
   float ax[4], ay[4], az[4], pn[4];
@@ -444,7 +440,6 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
     az[j] = P.i20 * gx + P.i21 * gy;
     pn[j] = gx * gx + gy * gy;
   }
-  const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
   // The brick flag of the lane-block (its 4 planes lie in one brick: zb is a multiple of 4, a brick's edge of 8 or more) is
   // requested HERE, with the trip's first loads, and acted on once after the last plane.  Looked up where a plane turns
   // out to hold a new negative value, it was a load whose result the very next branch needs: a full drain of the
@@ -668,8 +663,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
       // (gx^2 at the centre is 0.25 cell^2 below the mean of the two middle voxels': the first level's 2.3-cell margin holds it)
       c.pnc = gxc * gxc + gy * gy;
     }
-    const size_t plane_vec = (size_t)vp.X * vp.Y / 4;
-    const size_t idx0 = ((size_t)y * vp.X + x0) / 4;
     // Pass A.  A lane's 4(x) x 4(z) block is classified ONCE against the tile table: dead blocks cost nothing
     // more, deep-free-space blocks get four batched vector updates right here (loads in flight together), and the
     // uncertain ones (near a surface, at the frustum rim, close to the camera) are appended to a queue that pass B
@@ -1128,10 +1121,31 @@ __global__ void k_rebuild_flags(const short2* __restrict__ vol, VolParams vp, un
   const size_t n = (size_t)vp.X * vp.Y * vp.nzs;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (vol[i].x < 0) {
-    const int x = (int)(i % vp.X), y = (int)((i / vp.X) % vp.Y), zz = (int)(i / ((size_t)vp.X * vp.Y));
-    mark_brick_negative(flags, vp, x, y, zz);
-  }
+  const int x = (int)(i % vp.X), y = (int)((i / vp.X) % vp.Y), zz = (int)(i / ((size_t)vp.X * vp.Y));
+  if (vol[hsk_vox_index(vp, x, y, zz)].x < 0) mark_brick_negative(flags, vp, x, y, zz);
+}
+// stored planes [zz0, zz0 + nz) between the volume's 64-B blocks and a row-major array (x fastest, then y, then plane):
+// the host's view of the volume (hsk_download_tsdf / hsk_upload_tsdf).  One thread per 16-B vector.
+template <bool TO_LINEAR>
+__global__ void k_vol_convert(uint4* __restrict__ vol, VolParams vp, int zz0, int nz, uint4* __restrict__ lin) {
+  const int qx = vp.X >> 2;
+  const size_t n = (size_t)qx * vp.Y * nz;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xl = (int)(i % qx), y = (int)((i / qx) % vp.Y), zr = (int)(i / ((size_t)qx * vp.Y));
+  const size_t at = hsk_vox_index(vp, xl * 4, y, zz0 + zr) >> 2;
+  if (TO_LINEAR)
+    lin[i] = vol[at];
+  else
+    vol[at] = lin[i];
+}
+void launch_vol_to_linear(hipStream_t s, const void* vol, const VolParams& vp, int zz0, int nz, void* lin) {
+  const size_t n = (size_t)(vp.X >> 2) * vp.Y * nz;
+  hipLaunchKernelGGL(k_vol_convert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)const_cast<void*>(vol), vp, zz0, nz, (uint4*)lin);
+}
+void launch_vol_from_linear(hipStream_t s, void* vol, const VolParams& vp, int zz0, int nz, const void* lin) {
+  const size_t n = (size_t)(vp.X >> 2) * vp.Y * nz;
+  hipLaunchKernelGGL(k_vol_convert<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)vol, vp, zz0, nz, (uint4*)const_cast<void*>(lin));
 }
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags) {
   const size_t n = (size_t)vp.X * vp.Y * vp.nzs;
@@ -1149,9 +1163,7 @@ __global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char
   if (i >= n) return;
   const int xl = (int)(i % qx), y = (int)((i / qx) % vp.Y), zb = (int)(i / ((size_t)qx * vp.Y)) * 4;
   const size_t ui = hsk_sum_index(vp, xl * 4, y, zb);
-  const size_t plane_vec = (size_t)vp.X * vp.Y / 4, idx0 = (size_t)y * qx + xl;
   const int x0 = xl * 4;
-  (void)x0; (void)plane_vec; (void)idx0;
   if (!MATERIALIZE) {
     unsigned code = 0u;
     if (zb + 3 < vp.nzs) {
@@ -1201,7 +1213,7 @@ static __device__ __forceinline__ int vox_of_q(float quot) {
 static __device__ __forceinline__ int raw_at(const short2* __restrict__ vol, const VolParams& vp, int x, int y, int z) {
   const int zz = z - vp.zs0;
   if (zz < 0 || zz >= vp.nzs) return 0;
-  return (int)vol[((size_t)zz * vp.Y + y) * vp.X + x].x;
+  return (int)vol[hsk_vox_index(vp, x, y, zz)].x;
 }
 
 // trilinear TSDF sample (A.6).  Branch-free: indices are clamped for the loads and the NaN of the spec
@@ -1227,10 +1239,13 @@ static __device__ __forceinline__ float trilinear(const short2* __restrict__ vol
   // halo is sized as DESIGN.md prescribes)
   const int z0 = gz - vp.zs0, z1 = z0 + 1;
   const bool in0 = z0 >= 0 && z0 < vp.nzs, in1 = z1 >= 0 && z1 < vp.nzs;
-  const size_t row0 = ((size_t)(in0 ? z0 : 0) * vp.Y + gy) * vp.X + gx;
-  const size_t row1 = ((size_t)(in1 ? z1 : 0) * vp.Y + gy) * vp.X + gx;
-  const int r000 = vol[row0].x, r100 = vol[row0 + 1].x, r010 = vol[row0 + vp.X].x, r110 = vol[row0 + vp.X + 1].x;
-  const int r001 = vol[row1].x, r101 = vol[row1 + 1].x, r011 = vol[row1 + vp.X].x, r111 = vol[row1 + vp.X + 1].x;
+  // (the index is a sum of one term per axis: two terms per axis, eight additions; the two z taps of a cell share a
+  // 64-B block three times out of four)
+  const size_t tx0 = hsk_vox_xterm(gx), tx1 = hsk_vox_xterm(gx + 1);
+  const size_t ty0 = hsk_vox_yterm(vp, gy), ty1 = hsk_vox_yterm(vp, gy + 1);
+  const size_t tz0 = hsk_vox_zterm(vp, in0 ? z0 : 0), tz1 = hsk_vox_zterm(vp, in1 ? z1 : 0);
+  const int r000 = vol[tz0 + ty0 + tx0].x, r100 = vol[tz0 + ty0 + tx1].x, r010 = vol[tz0 + ty1 + tx0].x, r110 = vol[tz0 + ty1 + tx1].x;
+  const int r001 = vol[tz1 + ty0 + tx0].x, r101 = vol[tz1 + ty0 + tx1].x, r011 = vol[tz1 + ty1 + tx0].x, r111 = vol[tz1 + ty1 + tx1].x;
   const float f000 = hsk_tsdf_unpack(in0 ? r000 : 0), f100 = hsk_tsdf_unpack(in0 ? r100 : 0);
   const float f010 = hsk_tsdf_unpack(in0 ? r010 : 0), f110 = hsk_tsdf_unpack(in0 ? r110 : 0);
   const float f001 = hsk_tsdf_unpack(in1 ? r001 : 0), f101 = hsk_tsdf_unpack(in1 ? r101 : 0);
@@ -1904,9 +1919,7 @@ void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vm
 // ------------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ int crossing_count(const short2* __restrict__ vol, const VolParams& vp, int x, int y,
                                                      int z, float* pts /* up to 9 floats or null */) {
-  const size_t sx = 1, sy = (size_t)vp.X, sz = (size_t)vp.X * vp.Y;
-  const size_t i = ((size_t)(z - vp.zs0) * vp.Y + y) * vp.X + x;
-  const short2 c = vol[i];
+  const short2 c = vol[hsk_vox_index(vp, x, y, z - vp.zs0)];
   if (c.y == 0 || c.x == HSK_DIVISOR) return 0;
   const float F = (float)c.x / 32767.0f;
   const float V0 = ((float)x + 0.5f) * vp.cell[0], V1 = ((float)y + 0.5f) * vp.cell[1], V2 = ((float)z + 0.5f) * vp.cell[2];
@@ -1917,7 +1930,7 @@ static __device__ __forceinline__ int crossing_count(const short2* __restrict__ 
     const int dim = k == 0 ? vp.X : (k == 1 ? vp.Y : vp.Z);
     if (g + 1 >= dim) continue;
     if (k == 2 && (z + 1 - vp.zs0) >= vp.nzs) continue;  // neighbour plane not stored (cannot happen with halo >= 1)
-    const short2 nb = vol[i + (k == 0 ? sx : (k == 1 ? sy : sz))];
+    const short2 nb = vol[hsk_vox_index(vp, x + (k == 0 ? 1 : 0), y + (k == 1 ? 1 : 0), z - vp.zs0 + (k == 2 ? 1 : 0))];
     if (nb.y == 0 || nb.x == HSK_DIVISOR) continue;
     if (!((c.x > 0 && nb.x < 0) || (c.x < 0 && nb.x > 0))) continue;
     if (pts) {
@@ -2074,7 +2087,7 @@ static __device__ int cube_triangles(const short2* __restrict__ vol, const VolPa
   unsigned m8 = 0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    v[c] = vol[((size_t)(z + (c >> 2) - vp.zs0) * vp.Y + (y + ((c >> 1) & 1))) * vp.X + (x + (c & 1))];
+    v[c] = vol[hsk_vox_index(vp, x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2) - vp.zs0)];
     ok = ok && v[c].y != 0;
     m8 |= (v[c].x < 0 ? 1u : 0u) << c;
   }
