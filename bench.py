@@ -161,7 +161,7 @@ def pmc_counters(volume, total, passes, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false>", "void k_integrate_detail2<false>")
+INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false", "void k_integrate_detail2<false")   # (name prefixes: pass A is k_integrate<false, 2 | 4>)
 
 
 def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
@@ -175,7 +175,8 @@ def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
         return None, why, None
 
     def mean(kernel, ctr, first, last):
-        vals = per.get(kernel, {}).get(ctr, [])[first:last]
+        names = [k for k in per if k.startswith(kernel)]
+        vals = per[names[0]].get(ctr, [])[first:last] if names else []
         return float(np.mean(vals)) if vals else 0.0
     # one launch of each integrate kernel per frame, frame 0 included: index = frame number
     kernels = {}
@@ -183,7 +184,7 @@ def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
     for name in INTEGRATE_KERNELS:
         f = mean(name, "FETCH_SIZE", window_first, total) * 1024 * 2
         w = mean(name, "WRITE_SIZE", window_first, total) * 1024
-        kernels[name.replace("void ", "")] = {"fetch_bytes_corrected_x2": int(f), "write_bytes": int(w)}
+        kernels[name.replace("void ", "") + (">" if name.endswith("<false") else "")] = {"fetch_bytes_corrected_x2": int(f), "write_bytes": int(w)}
         fetch += f
         write += w
     info = {"fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write), "per_kernel": kernels,
@@ -191,7 +192,7 @@ def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
                       "timed region; mean per frame of the three integrate kernels"}
     ray = None
     if with_raycast:   # the raycast runs from frame 1 on: launch index = frame - 1
-        rk = "void k_raycast<false>"
+        rk = "void k_raycast<false"
         fr = mean(rk, "FETCH_SIZE", window_first - 1, total - 1) * 1024
         hit, miss = mean(rk, "TCC_HIT_sum", window_first - 1, total - 1), mean(rk, "TCC_MISS_sum", window_first - 1, total - 1)
         ray = {"fetch_bytes_raw": int(fr), "fetch_bytes_x2": int(2 * fr), "write_bytes": int(mean(rk, "WRITE_SIZE", window_first - 1, total - 1) * 1024),

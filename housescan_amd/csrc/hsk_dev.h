@@ -41,7 +41,8 @@ struct VolParams {
   int bshift;      // log2 of the brick edge of the "has held a negative TSDF" bitfield (3 => 8^3 voxels)
   double icell[3]; // correctly rounded binary64 reciprocals of cell[] (hsk_div_by_cell)
   int stream_nt;   // free-space updates stream the volume with non-temporal accesses (volumes >> Infinity Cache)
-  int pad_;
+  int zchunk;      // planes a pass-A workgroup takes: 8, or 16 for volumes whose launch stays large with half the workgroups
+                   // (hsk_pass_a_zchunk); also the unit of the lane-block summaries' layout (kernels_volume.hip)
 };
 
 // ---- where a voxel lives (round 4) ------------------------------------------------------------------------------------
@@ -63,6 +64,14 @@ __host__ __device__ static inline size_t hsk_vox_index(const VolParams& vp, int 
 }
 __host__ __device__ static inline size_t hsk_vol_words(const VolParams& vp) {  // allocation, in voxels (4 B each)
   return (size_t)vp.X * vp.Y * (size_t)((vp.nzs + 3) & ~3);
+}
+
+// Pass A's chunk of planes per workgroup.  Sixteen planes halve the waves and what each of them spends before its
+// first useful instruction (pose, footprint tables, column terms, queue ticket): -13 us at 1024^3 (65 k workgroups left),
+// +2.6 us at 512^3 (8 k left: the launch's tail grows) -- so the size decides (profiles/r04/integrate_notes.md).
+__host__ static inline int hsk_pass_a_zchunk(int X, int Y, int nzs) {
+  const long wgs16 = (long)((X + 63) / 64) * ((Y + 15) / 16) * ((nzs + 15) / 16);
+  return wgs16 >= 16384 ? 16 : 8;
 }
 
 #ifndef HSK_FLAG_WORDS_MAX

@@ -341,7 +341,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   vp.cell[2] = vp.size[2] / (float)vp.Z;
   for (int a = 0; a < 3; ++a) vp.icell[a] = 1.0 / (double)vp.cell[a];
   vp.stream_nt = 0;  // decided below, once the stored plane count is known
-  vp.pad_ = 0;
+  vp.zchunk = 8;  // (decided below as well)
   float m = vp.cell[0] > vp.cell[1] ? vp.cell[0] : vp.cell[1];
   m = m > vp.cell[2] ? m : vp.cell[2];
   const float lo = 2.1f * m;
@@ -357,6 +357,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   // memory
   k->vol_bytes = hsk_vol_words(vp) * 4;  // (stored planes padded to whole 64-B blocks of 4 planes: hsk_dev.h, hsk_vox_index)
   vp.stream_nt = k->vol_bytes > ((size_t)1 << 30) ? 1 : 0;  // > 1 GiB: four times the Infinity Cache and more
+  vp.zchunk = hsk_pass_a_zchunk(vp.X, vp.Y, vp.nzs);
   CK(hipMalloc(&k->d_vol, k->vol_bytes));
   const size_t P0 = (size_t)c->width * c->height;
   for (auto& b : k->ib) {

@@ -26,7 +26,7 @@
                          // way; told so, the compiler schedules it a little tighter: 69.9 -> 69.5 us at 512^3, 332 -> 327 at 1024^3)
 #endif
 #ifndef INTEGRATE_ZCHUNK
-#define INTEGRATE_ZCHUNK 8
+#define INTEGRATE_ZCHUNK 8  // (historical: the chunk is VolParams::zchunk now, 8 or 16 planes, chosen by hsk_pass_a_zchunk)
 #endif
 
 __global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax,
@@ -317,14 +317,16 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
 // 246 MB of its 278 MB through this path.
 // What the calls return is bit for bit what it was without the summaries; they are a representation of the weights of
 // deep free space, kept by: pass A, hsk_reset (all 1), hsk_upload_tsdf (k_rebuild_uniform).
-// Layout: the two groups of a chunk of 8 planes sit side by side, so a pass-A lane fetches (and rewrites) both of its
-// summaries with ONE 16-bit access, and the 128 bytes of a wave (16 lanes in x by 4 rows by 2 groups) are contiguous.
+// Layout: the groups of a pass-A chunk (vp.zchunk planes: 2 or 4 groups) sit side by side, so a pass-A lane fetches
+// (and rewrites) all of its summaries with ONE 16- or 32-bit access, and the bytes of a wave (16 lanes in x by 4 rows by
+// the chunk's groups) are contiguous.
 #define HSK_SUM_RAGGED 130u
 #define HSK_SUM_MAX 255u
 static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams& vp, int x0, int y, int zb) {
   const size_t tiles_x = (size_t)(vp.X + 63) / 64, tiles_y = (size_t)(vp.Y + 3) / 4;
-  return (((((size_t)(zb >> 3) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 + (size_t)((x0 >> 2) & 15)) * 2 +
-         (size_t)((zb >> 2) & 1);
+  const int ns = vp.zchunk >> 2;  // groups, i.e. summary bytes, per lane and chunk (2 or 4)
+  return (((((size_t)(zb / vp.zchunk) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 +
+          (size_t)((x0 >> 2) & 15)) * (size_t)ns + (size_t)((zb >> 2) % ns);
 }
 // Where the 16-B vector of voxels x0 .. x0 + 3 (x0 a multiple of 4) of row y, stored plane zb + u (zb a multiple of 4,
 // u in 0 .. 3) sits in the volume, in vectors: the four vectors of a lane-block are consecutive (hsk_dev.h: hsk_vox_index).
@@ -573,7 +575,7 @@ extern "C" int hsk_debug_pa_times(unsigned long long* out, int n) {
 // (below, lane predicates are joined by & and |, without short-circuit evaluation: `a && b` on lane-varying conditions is
 // compiled into a lane-mask branch round b -- s_and_saveexec / s_cbranch_execz, scalar instructions, which pass A is short of)
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
-template <bool COUNT_ONLY>
+template <bool COUNT_ONLY, int NS>
 __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const int2* __restrict__ wgz,
                                                    const int2* __restrict__ zint, int zchunk, unsigned gxa, unsigned gmagic,
                                                    double* __restrict__ icp_slot0, unsigned char* __restrict__ uni,
@@ -674,8 +676,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
     // dependent memory round trips (tile table -> fine tile table -> volume -> queue counter); stage by stage over both
     // groups the chain is four trips long instead of eight, and pass A is bound by exactly that (its 65 k waves pass
     // through 6 resident slots per SIMD in about eleven rounds).
-    static_assert(INTEGRATE_ZCHUNK % 4 == 0 && INTEGRATE_ZCHUNK <= 16, "pass A stages the chunk's groups of 4 planes together");
-    constexpr int NS = INTEGRATE_ZCHUNK / 4;
+    static_assert(NS == 2 || NS == 4, "pass A stages the chunk's groups of 4 planes together; a lane's summaries of a chunk are one 16- or 32-bit word");
     const int zb0 = wl & ~3;
     int zbs[NS];
     bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS];
@@ -690,7 +691,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
     // ---- stage 1: first level (16-px dilated tile table).  Both groups' look-ups are requested first, the lane's summaries
     // behind them: loads return in the order they were issued, and requested ahead of the look-ups the summaries -- an
     // 8 MiB table that misses where the 9.6 KB tile table hits -- made the first level wait for a byte that stage 3 uses.
-    static_assert(NS == 2, "the summaries of a chunk's two groups are fetched as one 16-bit word");
     float2 Dt_s[NS];
     bool ok_s[NS], in_any_s[NS];
 #pragma unroll
@@ -709,9 +709,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
       Dt_s[sidx] = dtab[tv * tw + tu];
       dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
     }
-    unsigned sum16 = 0u;  // both summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
-    unsigned short* const sum_at = (unsigned short*)(uni + hsk_sum_index(vp, x0, y, zbeg));
-    if (!COUNT_ONLY && uni != nullptr && active && (actv[0] || actv[1])) sum16 = *sum_at;
+    unsigned sum16 = 0u;  // all summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
+    unsigned char* const sum_at = uni + hsk_sum_index(vp, x0, y, zbeg);
+    {
+      bool any_actv = false;
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) any_actv = any_actv || actv[sidx];
+      if (!COUNT_ONLY && uni != nullptr && active && any_actv) sum16 = NS == 2 ? (unsigned)*(const unsigned short*)sum_at : *(const unsigned*)sum_at;
+    }
     PA_STAMP(6);
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
@@ -894,7 +899,12 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
           }
         }
       }
-      if (new16 != sum16) *sum_at = (unsigned short)new16;
+      if (new16 != sum16) {
+        if (NS == 2)
+          *(unsigned short*)sum_at = (unsigned short)new16;
+        else
+          *(unsigned*)sum_at = new16;
+      }
     }
 #ifdef HSK_PA_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp below sees the loads back and the stores acknowledged
@@ -1065,7 +1075,7 @@ unsigned long long integrate_queue_entries(const unsigned* counter_words) {
 }
 // words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
 size_t integrate_queue_words(const VolParams& vp) {
-  const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
+  const int zchunk = vp.nzs >= vp.zchunk ? vp.zchunk : vp.nzs;
   const size_t nblk = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16) * ((vp.nzs + zchunk - 1) / zchunk);
   const size_t qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (size_t)((zchunk + 3) / 4);
   return (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE + (size_t)HSK_NQUEUES * qcap;
@@ -1074,7 +1084,7 @@ size_t integrate_queue_words(const VolParams& vp) {
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
                       const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final, unsigned char* uni) {
-  const int zchunk = vp.nzs >= INTEGRATE_ZCHUNK ? INTEGRATE_ZCHUNK : vp.nzs;
+  const int zchunk = vp.nzs >= vp.zchunk ? vp.zchunk : vp.nzs;
   const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int ncols = (vp.X / 4) * vp.Y;
@@ -1104,13 +1114,21 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned gmagic = grid.x > 1u ? (unsigned)(0x100000000ull / grid.x) + 1u : 0u;
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
-    hipLaunchKernelGGL(k_integrate<true>, grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                       W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+    if (vp.zchunk == 16)
+      hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+    else
+      hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   } else {
-    hipLaunchKernelGGL(k_integrate<false>, grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                       (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+    if (vp.zchunk == 16)
+      hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+    else
+      hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   }
@@ -1154,7 +1172,9 @@ void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, u
 
 // lane-block summaries of a volume that was uploaded rather than integrated (one thread per lane-block; a block that
 // reaches beyond the last stored plane has no summary), and the reverse: the volume's weights brought up to date
-size_t uniform_bytes(const VolParams& vp) { return (size_t)((vp.nzs + 7) / 8) * ((vp.Y + 3) / 4) * ((vp.X + 63) / 64) * 128; }
+size_t uniform_bytes(const VolParams& vp) {
+  return (size_t)((vp.nzs + vp.zchunk - 1) / vp.zchunk) * ((vp.Y + 3) / 4) * ((vp.X + 63) / 64) * (size_t)(64 * (vp.zchunk >> 2));
+}
 template <bool MATERIALIZE>
 __global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
   const int qx = vp.X / 4;

@@ -29,5 +29,7 @@ for k, ((p, ok), (po, oko)) in enumerate(zip(got, want)):
         if bad < 4: print("frame", k, "differs", ok, oko)
 vol = trk.download_tsdf()
 dv = int((vol != ot.volume()).any(axis=-1).sum())
-print(f"n={n} frames={frames}: pose mismatches {bad}, differing voxels {dv}, oracle {t1 - t0:.1f} s")
+from housescan_amd import _lib
+print(f"build {_lib.load().hsk_build_id().decode()}  n={n} frames={frames}: pose mismatches {bad} of {frames}, differing voxels {dv} of {vol.shape[0] * vol.shape[1] * vol.shape[2]}, "
+      f"lost frames {sum(1 for _, ok in got[1:] if not ok)}, oracle {t1 - t0:.1f} s")
 sys.exit(1 if (bad or dv) else 0)

@@ -12,6 +12,18 @@ cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 grep -o '{"metric.*' $OUT/bench_profiled.log > $OUT/bench_profiled.json
 cd $ROOT && tools/pmc.sh gpurun_out/round/pmc > $OUT/pmc_summary.txt 2>&1
 cp $OUT/pmc/integrate_traffic.json $OUT/ 2>/dev/null
+# the same at 1024^3 (the HBM measurement): kernel averages of a 40-frame run
+rm -rf $OUT/trace1024
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1024 -- python3 $ROOT/bench.py --quick --volume 1024 --steps 40 --warmup 5 > $OUT/bench_profiled_1024.log 2>&1)
+cp $OUT/trace1024/*/*_kernel_stats.csv $OUT/kernel_stats_1024.csv
+grep -o '{"metric.*' $OUT/bench_profiled_1024.log > $OUT/bench_profiled_1024.json
+rm -rf $OUT/trace1024
+# long-horizon parity of THIS build against the oracle's tracker: every pose and the final TSDF, bit for bit
+for job in "256 300" "512 300" "1024 100"; do
+  set -- $job
+  (cd $ROOT && timeout 1200 python3 tools/long_parity.py $1 $2 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_$1.txt)
+  cat $OUT/long_parity_$1.txt
+done
 # the raw per-dispatch CSVs exceed what gpurun copies back (64 MiB): only the summaries travel
 rm -rf $OUT/trace $OUT/pmc/p[0-9]*
 tail -5 $OUT/pmc_summary.txt
