@@ -1775,7 +1775,11 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
       const float Ft = trilinear(vol, vp, t0 + d0 * time_curr, t1 + d1 * time_curr, t2 + d2 * time_curr);
       if (!hsk_isnan(Ftdt) && !hsk_isnan(Ft)) {
         const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
-        if (Ts >= time_curr - time_step && Ts <= time_curr + 2.0f * time_step) {  // (D3: two steps round the far sample)
+#ifndef HSK_D3_LO
+#define HSK_D3_LO 1.0f
+#define HSK_D3_HI 2.0f
+#endif
+        if (Ts >= time_curr - HSK_D3_LO * time_step && Ts <= time_curr + HSK_D3_HI * time_step) {  // (D3: two steps round the far sample)
           vx = t0 + d0 * Ts;
           vy = t1 + d1 * Ts;
           vz = t2 + d2 * Ts;
