@@ -226,6 +226,12 @@ def readout_block(trk, n, with_download=True):
     out["extract_mesh_ms"] = round((t2b - t2) * 1e3, 3)
     out["mesh_triangles"] = int(n_tri)
     del tris
+    t2 = time.perf_counter()
+    tris, n_tri = trk.extract_mesh(cubes=True)   # hsk_extract_mesh_cubes: marching cubes, the form upstream's .ply has
+    t2b = time.perf_counter()
+    out["extract_mesh_cubes_ms"] = round((t2b - t2) * 1e3, 3)
+    out["mesh_cubes_triangles"] = int(n_tri)
+    del tris
     if with_download:
         t3 = time.perf_counter()
         vol = trk.download_tsdf()

@@ -71,6 +71,7 @@ SYMBOLS = {
     "hsk_download_scaled_depth": (C.c_int, [_P, _P]),
     "hsk_extract_cloud": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_extract_mesh": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "hsk_extract_mesh_cubes": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsk_mgpu_frame_begin": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "hsk_mgpu_prefetch": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "hsk_mgpu_frame_front": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),

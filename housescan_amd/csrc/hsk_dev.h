@@ -106,6 +106,13 @@ struct TetTable {
   unsigned char edge[6][16][2][3];
 };
 
+// marching-cubes lookup (hsk_build_cube_table): per 8-bit inside mask 0..5 triangles; triangle corners coded like TetTable's
+#define HSK_MC_MAXT 5
+struct CubeTable {
+  unsigned char ntri[256];
+  unsigned char edge[256][HSK_MC_MAXT][3];
+};
+
 // levels 1 and 2 of the model maps, written by the raycast itself when it can (launch_raycast)
 struct MapPyramid {
   float *v1, *n1, *v2, *n2;

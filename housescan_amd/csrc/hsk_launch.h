@@ -61,6 +61,9 @@ void launch_icp_fused(hipStream_t s, float* const* vcur, float* const* ncur, flo
 bool host_solve6(const double* in27, float* x6);
 void host_pose_update(float* R, float* t, const float* x6);
 void hsk_build_tet_table(TetTable* tt);
+int hsk_build_cube_table(CubeTable* ct);  // marching cubes; returns the most triangles of a case (HSK_MC_MAXT)
 int hsk_mesh_z_end(const VolParams& vp);
 void launch_extract_mesh(hipStream_t s, const void* vol, const VolParams& vp, const TetTable& tt, unsigned* row_count,
                          unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass);
+void launch_extract_mesh_mc(hipStream_t s, const void* vol, const VolParams& vp, const CubeTable* ct_dev, unsigned* row_count,
+                            unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass);

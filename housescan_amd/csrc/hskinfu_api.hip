@@ -64,6 +64,7 @@ struct hsk_ctx {
   bool weights_pending = false;      // an integrate has been enqueued since the summaries' weights were last written back
   size_t flags_bytes = 0;
   unsigned* d_queue = nullptr;       // integrate pass A -> pass B: count (4 words) + uncertain lane-block ids
+  CubeTable* d_cube_tab = nullptr;   // marching-cubes table (hsk_extract_mesh_cubes; filled on first use)
   int2* d_zint = nullptr;            // per lane column: stored-plane range inside the padded frustum
   uint16_t* h_stage = nullptr;  // pinned staging for the incoming depth frame (HSK_MAX_IN_FLIGHT + 1 frames, used in turn)
   unsigned stage_turn = 0;
@@ -234,6 +235,7 @@ static void free_all(hsk_ctx* k) {
   F(k->d_uni);
   F(k->d_zint);
   F(k->d_queue);
+  F(k->d_cube_tab);
   F(k->d_counter);
   F(k->d_rowcnt);
   F(k->d_rowoff);
@@ -1237,6 +1239,40 @@ extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles
   float* d_tri = nullptr;
   HIPCHK(k, hipMalloc((void**)&d_tri, nw * 36));
   launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, d_tri, nw, 1);
+  hipError_t e = hipMemcpyAsync(tri_xyz, d_tri, nw * 36, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  (void)hipFree(d_tri);
+  HIPCHK(k, e);
+  return HSK_OK;
+}
+
+// The same level set by MARCHING CUBES (the form upstream's .ply export has, README.md:16-17): about half the triangles
+// of the tetrahedra form.  Table generated by hsk_build_cube_table (PCL's own is not in the reference).
+extern "C" int hsk_extract_mesh_cubes(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles) {
+  if (!k || !n_triangles) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // >= the mesh rows; shared with hsk_extract_cloud
+  if (!k->d_rowcnt) {
+    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
+    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
+  }
+  if (!k->d_cube_tab) {
+    CubeTable ct;
+    if (hsk_build_cube_table(&ct) != HSK_MC_MAXT) return fail(k, HSK_ERR_STATE, "marching-cubes table: a case with more triangles than the table holds");
+    HIPCHK(k, hipMalloc((void**)&k->d_cube_tab, sizeof(CubeTable)));
+    HIPCHK(k, hipMemcpy(k->d_cube_tab, &ct, sizeof(CubeTable), hipMemcpyHostToDevice));
+  }
+  flush_weights(k);
+  launch_extract_mesh_mc(k->stream, k->d_vol, k->vp, k->d_cube_tab, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
+  unsigned long long total = 0;
+  HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  *n_triangles = (size_t)total;
+  if (!tri_xyz || cap_triangles == 0 || total == 0) return HSK_OK;
+  const size_t nw = total < cap_triangles ? (size_t)total : cap_triangles;
+  float* d_tri = nullptr;
+  HIPCHK(k, hipMalloc((void**)&d_tri, nw * 36));
+  launch_extract_mesh_mc(k->stream, k->d_vol, k->vp, k->d_cube_tab, k->d_rowcnt, k->d_rowoff, k->d_counter, d_tri, nw, 1);
   hipError_t e = hipMemcpyAsync(tri_xyz, d_tri, nw * 36, hipMemcpyDeviceToHost, k->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
   (void)hipFree(d_tri);

@@ -2102,6 +2102,136 @@ void hsk_build_tet_table(TetTable* tt) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Marching cubes (the form PCL's KinFu exports its .ply from, README.md:16-17): one table entry per 8-bit inside mask.
+// PCL's 256-case table is not in the reference and cannot be fetched, so the table is GENERATED: on every face of the
+// cube the cut edges are joined by segments -- two cut edges: one segment; four (the two diagonal corners inside): two
+// segments, each cutting ONE INSIDE corner off, a rule that depends on the face's four signs only, so the two cubes that
+// share the face draw the same segments and the surface is closed wherever the cubes are valid.  Every cut edge then has
+// exactly two segments: they chain into closed loops, each loop is wound so that its normal points from the inside
+// corners to the outside ones and is cut into a fan of triangles from its lowest edge (or the next whose fan keeps out of
+// the cube's faces).  820 triangles over the 256
+// cases, at most 5 per cube (the classic table's counts).  Vertices as in the tetrahedra form: from the LOWER corner.
+// ------------------------------------------------------------------------------------------------------
+int hsk_build_cube_table(CubeTable* ct) {
+  struct Edge {
+    int a, b;  // corners, a < b
+  };
+  auto code = [](int a, int b) { return a < b ? (a | (b << 4)) : (b | (a << 4)); };
+  int worst = 0;
+  for (int m = 0; m < 256; ++m) {
+    // segments between cut edges, found face by face; link[e][0..1]: the two edges an edge is joined to
+    int link[256][2], nlink[256];
+    bool cut_edge[256];
+    for (int i = 0; i < 256; ++i) nlink[i] = 0, cut_edge[i] = false;
+    auto join = [&](int e0, int e1) {
+      link[e0][nlink[e0]++] = e1;
+      link[e1][nlink[e1]++] = e0;
+      cut_edge[e0] = cut_edge[e1] = true;
+    };
+    for (int ax = 0; ax < 3; ++ax) {
+      const int u = ax == 0 ? 1 : 0, v = ax == 2 ? 1 : 2;
+      for (int side = 0; side < 2; ++side) {
+        int cyc[4];
+        const int uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+        for (int i = 0; i < 4; ++i) cyc[i] = (side << ax) | (uv[i][0] << u) | (uv[i][1] << v);
+        int fe[4], ncut = 0;
+        bool cut[4], in[4];
+        for (int i = 0; i < 4; ++i) in[i] = ((m >> cyc[i]) & 1) != 0;
+        for (int i = 0; i < 4; ++i) {
+          fe[i] = code(cyc[i], cyc[(i + 1) & 3]);
+          cut[i] = in[i] != in[(i + 1) & 3];
+          ncut += cut[i] ? 1 : 0;
+        }
+        if (ncut == 2) {
+          int e0 = -1, e1 = -1;
+          for (int i = 0; i < 4; ++i)
+            if (cut[i]) (e0 < 0 ? e0 : e1) = fe[i];
+          join(e0, e1);
+        } else if (ncut == 4) {
+          for (int i = 0; i < 4; ++i)
+            if (in[i]) join(fe[(i + 3) & 3], fe[i]);  // the two edges that meet in inside corner i
+        }
+      }
+    }
+    int nt = 0;
+    bool used[256];
+    for (int i = 0; i < 256; ++i) used[i] = false;
+    for (int start = 0; start < 256; ++start) {  // (edge codes in ascending order: the loops' order, and each loop's first edge)
+      if (!cut_edge[start] || used[start]) continue;
+      int loop[12], len = 0, prev = -1, cur = start;
+      for (;;) {
+        loop[len++] = cur;
+        used[cur] = true;
+        int next = -1;
+        for (int q = 0; q < 2; ++q)
+          if (link[cur][q] != prev && !used[link[cur][q]]) {
+            next = link[cur][q];
+            break;
+          }
+        if (next < 0) break;
+        prev = cur;
+        cur = next;
+      }
+      // winding: Newell normal of the loop of edge midpoints against the summed inside -> outside edge directions
+      double mid[12][3], nrm[3] = {0, 0, 0}, dir[3] = {0, 0, 0};
+      for (int i = 0; i < len; ++i) {
+        const int a = loop[i] & 15, b = loop[i] >> 4;
+        const bool a_in = ((m >> a) & 1) != 0;
+        for (int k = 0; k < 3; ++k) {
+          const double pa = (a >> k) & 1, pb = (b >> k) & 1;
+          mid[i][k] = 0.5 * (pa + pb);
+          dir[k] += a_in ? pb - pa : pa - pb;
+        }
+      }
+      for (int i = 0; i < len; ++i) {
+        const double* p = mid[i];
+        const double* q = mid[(i + 1) % len];
+        nrm[0] += p[1] * q[2] - p[2] * q[1];
+        nrm[1] += p[2] * q[0] - p[0] * q[2];
+        nrm[2] += p[0] * q[1] - p[1] * q[0];
+      }
+      if (nrm[0] * dir[0] + nrm[1] * dir[1] + nrm[2] * dir[2] < 0)
+        for (int i = 1, j = len - 1; i < j; ++i, --j) {
+          const int t = loop[i];
+          loop[i] = loop[j];
+          loop[j] = t;
+        }
+      // the fan's origin: the first edge of the wound loop none of whose diagonals lies IN a face of the cube (both edges on
+      // one face: the neighbour across that face could draw the same line, and the welded mesh would use it four times);
+      // one of the first three always qualifies
+      auto in_one_face = [](int e, int f) {
+        for (int k = 0; k < 3; ++k) {
+          const int b = ((e & 15) >> k) & 1;
+          if ((((e >> 4) >> k) & 1) == b && (((f & 15) >> k) & 1) == b && (((f >> 4) >> k) & 1) == b) return true;
+        }
+        return false;
+      };
+      int origin = 0;
+      for (int o = 0; o < len; ++o) {
+        bool clean = true;
+        for (int k = 2; k + 1 < len; ++k) clean = clean && !in_one_face(loop[o], loop[(o + k) % len]);
+        if (clean) {
+          origin = o;
+          break;
+        }
+      }
+      for (int i = 1; i + 1 < len; ++i) {
+        if (nt < HSK_MC_MAXT) {
+          ct->edge[m][nt][0] = (unsigned char)loop[origin];
+          ct->edge[m][nt][1] = (unsigned char)loop[(origin + i) % len];
+          ct->edge[m][nt][2] = (unsigned char)loop[(origin + i + 1) % len];
+        }
+        ++nt;
+      }
+    }
+    worst = nt > worst ? nt : worst;
+    ct->ntri[m] = (unsigned char)(nt < HSK_MC_MAXT ? nt : HSK_MC_MAXT);
+    for (int t = nt; t < HSK_MC_MAXT; ++t) ct->edge[m][t][0] = ct->edge[m][t][1] = ct->edge[m][t][2] = 0;
+  }
+  return worst;  // 5: the table's row length (checked by the caller)
+}
+
 // triangles of the cube at (x, y, z); when WRITE, stores 9 floats per triangle at tri + 9 * (at + i) while at + i < cap
 template <bool WRITE>
 static __device__ int cube_triangles(const short2* __restrict__ vol, const VolParams& vp, const TetTable& tt, int x, int y, int z,
@@ -2208,6 +2338,100 @@ void launch_extract_mesh(hipStream_t s, const void* vol, const VolParams& vp, co
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_count, row_offset, nrows, total);
   } else {
     hipLaunchKernelGGL(k_extract_mesh<true>, grid, block, 0, s, (const short2*)vol, vp, tt, row_count, row_offset, tri, cap, z_end);
+  }
+}
+
+// ... and the marching-cubes form: the cube's triangles straight from the table (in device memory: 4 KiB)
+template <bool WRITE>
+static __device__ int cube_triangles_mc(const short2* __restrict__ vol, const VolParams& vp, const CubeTable* __restrict__ ct, int x, int y,
+                                        int z, float* __restrict__ tri, unsigned long long at, unsigned long long cap) {
+  short2 v[8];
+  bool ok = true;
+  unsigned m8 = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v[c] = vol[hsk_vox_index(vp, x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2) - vp.zs0)];
+    ok = ok && v[c].y != 0;
+    m8 |= (v[c].x < 0 ? 1u : 0u) << c;
+  }
+  if (!ok || m8 == 0u || m8 == 255u) return 0;
+  const int nt = ct->ntri[m8];
+  if (WRITE) {
+    for (int k = 0; k < nt; ++k) {
+      const unsigned long long slot = at + (unsigned long long)k;
+      if (slot >= cap) continue;
+      for (int q = 0; q < 3; ++q) {
+        const unsigned code = ct->edge[m8][k][q];
+        const int a = (int)(code & 15u), b = (int)(code >> 4);
+        short fa = 0, fb = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          fa = c == a ? v[c].x : fa;
+          fb = c == b ? v[c].x : fb;
+        }
+        const float Fa = (float)fa / 32767.0f, Fb = (float)fb / 32767.0f;
+        const float w = Fa / (Fa - Fb);
+        const int ga[3] = {x + (a & 1), y + ((a >> 1) & 1), z + (a >> 2)};
+        const int gb[3] = {x + (b & 1), y + ((b >> 1) & 1), z + (b >> 2)};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          const float pa = ((float)ga[ax] + 0.5f) * vp.cell[ax];
+          const float pb = ((float)gb[ax] + 0.5f) * vp.cell[ax];
+          tri[9 * slot + 3 * q + ax] = pa + w * (pb - pa);
+        }
+      }
+    }
+  }
+  return nt;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_extract_mesh_mc(const short2* __restrict__ vol, VolParams vp, const CubeTable* __restrict__ ct,
+                                                         unsigned* __restrict__ row_count,
+                                                         const unsigned long long* __restrict__ row_offset,
+                                                         float* __restrict__ tri, unsigned long long cap, int z_end) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int ny = vp.Y - 1;
+  const int nrows = ny * (z_end - vp.zo0);
+  if (row >= nrows) return;
+  const int y = row % ny, z = vp.zo0 + row / ny;
+  unsigned long long base = WRITE ? row_offset[row] : 0;
+  unsigned total = 0;
+  for (int xb = 0; xb < vp.X - 1; xb += 64) {
+    const int x = xb + lane;
+    const int n = x < vp.X - 1 ? cube_triangles_mc<false>(vol, vp, ct, x, y, z, nullptr, 0, 0) : 0;
+    int scan = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(scan, o, 64);
+      if (lane >= o) scan += u;
+    }
+    const int wave_total = __shfl(scan, 63, 64);
+    if (WRITE) {
+      if (n) cube_triangles_mc<true>(vol, vp, ct, x, y, z, tri, base + (unsigned long long)(scan - n), cap);
+      base += wave_total;
+    }
+    total += wave_total;
+  }
+  if (!WRITE && lane == 0) row_count[row] = total;
+}
+
+void launch_extract_mesh_mc(hipStream_t s, const void* vol, const VolParams& vp, const CubeTable* ct_dev, unsigned* row_count,
+                            unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass) {
+  const int z_end = hsk_mesh_z_end(vp);
+  const int nrows = (vp.Y - 1) * (z_end - vp.zo0);
+  if (nrows <= 0) {
+    if (pass == 0) (void)hipMemsetAsync(total, 0, 8, s);
+    return;
+  }
+  const dim3 grid((unsigned)((nrows + 3) / 4));
+  if (pass == 0) {
+    hipLaunchKernelGGL(k_extract_mesh_mc<false>, grid, dim3(256), 0, s, (const short2*)vol, vp, ct_dev, row_count, (const unsigned long long*)nullptr,
+                       (float*)nullptr, 0ull, z_end);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_count, row_offset, nrows, total);
+  } else {
+    hipLaunchKernelGGL(k_extract_mesh_mc<true>, grid, dim3(256), 0, s, (const short2*)vol, vp, ct_dev, row_count, row_offset, tri, cap, z_end);
   }
 }
 

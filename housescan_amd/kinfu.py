@@ -215,15 +215,17 @@ class KinfuTracker:
             self._ck(self.lib.hsk_extract_cloud(self.h, out.ctypes.data, m, C.byref(n)))
         return out, total
 
-    def extract_mesh(self, cap=None):
-        """TSDF zero level set as triangles [n, 3, 3] (marching tetrahedra, voxel order) -> (triangles, total)"""
+    def extract_mesh(self, cap=None, cubes=False):
+        """TSDF zero level set as triangles [n, 3, 3], voxel order -> (triangles, total): marching tetrahedra, or
+        (cubes=True) marching cubes, the form upstream's .ply export has"""
+        fn = self.lib.hsk_extract_mesh_cubes if cubes else self.lib.hsk_extract_mesh
         n = C.c_size_t()
-        self._ck(self.lib.hsk_extract_mesh(self.h, None, 0, C.byref(n)))
+        self._ck(fn(self.h, None, 0, C.byref(n)))
         total = n.value
         m = total if cap is None else min(cap, total)
         out = np.empty((m, 3, 3), np.float32)
         if m:
-            self._ck(self.lib.hsk_extract_mesh(self.h, out.ctypes.data, m, C.byref(n)))
+            self._ck(fn(self.h, out.ctypes.data, m, C.byref(n)))
         return out, total
 
     # ---- streams / profiling -----------------------------------------------------------------------

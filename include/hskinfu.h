@@ -124,6 +124,11 @@ int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_point
  * deterministic voxel order, normals towards free space.  Edge vertices shared by neighbouring cubes are bit-identical,
  * so hsk_write_ply_mesh can weld them by exact comparison.  Two-call protocol like hsk_extract_cloud. */
 int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles);
+/* the same level set by MARCHING CUBES, the form the .ply of upstream's KinFu export has (/root/reference/README.md:16-17):
+ * about half the triangles.  PCL's 256-case table is not in the reference; this one is generated (segments between cut
+ * edges face by face, ambiguous faces cut one inside corner off each, loops fanned from their lowest edge) and has the
+ * classic table's counts (820 triangles, at most 5 per cube); same validity rule, vertices and order as hsk_extract_mesh */
+int hsk_extract_mesh_cubes(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles);
 
 /* Multi-GPU (z-slab) building blocks; device pointers so that the host's collective (RCCL through
  * torch.distributed) can run on them without a host round trip.  All work is enqueued on hsk_stream(). */

@@ -1036,6 +1036,155 @@ size_t ora_extract_mesh(const int16_t* vol, const int dims[3], const float size[
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* A.8b extractMesh, marching cubes (the form upstream's .ply export has; PCL's table is not in /root/reference, so   */
+/* this build generates one and states the rule): same cube validity, inside test, edge vertices and voxel order as  */
+/* above.  Per cube: every cut edge is a node; on each of the six faces the cut edges are paired -- 2 cut edges: with  */
+/* each other; 4 cut edges: each with its neighbour ACROSS AN INSIDE CORNER -- so every node has two partners and the   */
+/* nodes fall into closed loops.  Loops are taken in order of their smallest edge code (low corner | high corner << 4), */
+/* start there, run so that the Newell normal of the edge midpoints has a positive product with the sum of the          */
+/* (outside end - inside end) vectors of its edges, and are fanned (e0, e_i, e_i+1) from that first edge -- or from the   */
+/* next one along the loop none of whose fan diagonals lies in a face of the cube (one of the first three does).        */
+/* (Written independently of the product's hsk_build_cube_table: there the faces are walked as corner cycles, here a   */
+/* node's partners are found by flipping axis bits of its end corners.)                                                */
+/* ------------------------------------------------------------------------------------------------ */
+static int ora_mc_is_in(int m, int c) { return (m >> c) & 1; }
+
+/* partner of cut edge (a, b) [b = a ^ (1 << ax)] on the face spanned by axes ax and w, on the side both corners lie on */
+static int ora_mc_partner(int m, int a, int b, int w) {
+  const int a2 = a ^ (1 << w), b2 = b ^ (1 << w); /* the face's other two corners, next to a and b */
+  const int ia = ora_mc_is_in(m, a), ia2 = ora_mc_is_in(m, a2), ib2 = ora_mc_is_in(m, b2);
+  /* the face's edges besides (a, b): (a, a2), (b, b2), (a2, b2) */
+  const int cut_a = ia != ia2, cut_b = (!ia) != ib2, cut_far = ia2 != ib2; /* (b is the opposite of a: the edge is cut) */
+  int lo, hi;
+  if (cut_a && cut_b && cut_far) { /* all four cut: across the inside corner of this edge */
+    if (ia) { lo = a; hi = a2; } else { lo = b; hi = b2; }
+  } else if (cut_a) { lo = a; hi = a2; }
+  else if (cut_b) { lo = b; hi = b2; }
+  else { lo = a2; hi = b2; }
+  if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+  return lo | (hi << 4);
+}
+
+/* triangles of inside-mask m as edge codes; returns their number (at most 5) */
+static int ora_mc_case(int m, int tri[5][3]) {
+  int nodes[12], n_nodes = 0, done[12] = {0}, nt = 0;
+  for (int a = 0; a < 8; ++a)
+    for (int ax = 0; ax < 3; ++ax) {
+      const int b = a | (1 << ax);
+      if (b == a) continue; /* a has the bit: the edge is listed from its lower corner */
+      if (ora_mc_is_in(m, a) != ora_mc_is_in(m, b)) nodes[n_nodes++] = a | (b << 4);
+    }
+  /* ascending edge code */
+  for (int i = 0; i < n_nodes; ++i)
+    for (int j = i + 1; j < n_nodes; ++j)
+      if (nodes[j] < nodes[i]) { const int t = nodes[i]; nodes[i] = nodes[j]; nodes[j] = t; }
+  for (int s0 = 0; s0 < n_nodes; ++s0) {
+    if (done[s0]) continue;
+    /* walk the cycle: leave every node by the partner it was not entered from (the first by its w1 partner: the winding
+     * rule below fixes the direction afterwards, so either way round is the same loop) */
+    int loop[12], len = 0, cur = nodes[s0], from = -1;
+    do {
+      loop[len++] = cur;
+      for (int i = 0; i < n_nodes; ++i)
+        if (nodes[i] == cur) done[i] = 1;
+      const int a = cur & 15, b = cur >> 4;
+      int ax = 0;
+      while (((a ^ b) >> ax) != 1) ++ax;
+      const int p1 = ora_mc_partner(m, a, b, (ax + 1) % 3), p2 = ora_mc_partner(m, a, b, (ax + 2) % 3);
+      const int next = p1 != from ? p1 : p2;
+      from = cur;
+      cur = next;
+    } while (cur != loop[0] && len < 12);
+    double mid[12][3], nrm[3] = {0, 0, 0}, dir[3] = {0, 0, 0};
+    for (int i = 0; i < len; ++i) {
+      const int a = loop[i] & 15, b = loop[i] >> 4;
+      for (int k = 0; k < 3; ++k) {
+        const double pa = (a >> k) & 1, pb = (b >> k) & 1;
+        mid[i][k] = (pa + pb) / 2;
+        dir[k] += ora_mc_is_in(m, a) ? pb - pa : pa - pb;
+      }
+    }
+    for (int i = 0; i < len; ++i) {
+      const int j = i + 1 == len ? 0 : i + 1;
+      nrm[0] += mid[i][1] * mid[j][2] - mid[i][2] * mid[j][1];
+      nrm[1] += mid[i][2] * mid[j][0] - mid[i][0] * mid[j][2];
+      nrm[2] += mid[i][0] * mid[j][1] - mid[i][1] * mid[j][0];
+    }
+    /* the loop as it is wound: from its first edge onwards, or backwards */
+    int w[12];
+    const int flip = nrm[0] * dir[0] + nrm[1] * dir[1] + nrm[2] * dir[2] < 0;
+    for (int i = 0; i < len; ++i) w[i] = loop[flip ? (len - i) % len : i];
+    /* fan origin: the first position whose diagonals all leave the cube's faces (two edges lie in one face when some
+     * coordinate is the same at all four of their ends) */
+    int o0 = 0;
+    for (int o = 0; o < len; ++o) {
+      int bad = 0;
+      for (int k = 2; k + 1 < len; ++k) {
+        const int e = w[o], f = w[(o + k) % len];
+        const int all_and = (e & 15) & (e >> 4) & (f & 15) & (f >> 4), all_or = (e & 15) | (e >> 4) | (f & 15) | (f >> 4);
+        if ((all_and & 7) != 0 || (all_or & 7) != 7) bad = 1; /* a bit set in all four corners, or clear in all four */
+      }
+      if (!bad) { o0 = o; break; }
+    }
+    for (int i = 1; i + 1 < len; ++i) {
+      if (nt < 5) { tri[nt][0] = w[o0]; tri[nt][1] = w[(o0 + i) % len]; tri[nt][2] = w[(o0 + i + 1) % len]; }
+      ++nt;
+    }
+  }
+  return nt;
+}
+
+size_t ora_extract_mesh_mc(const int16_t* vol, const int dims[3], const float size[3], float* tri, size_t cap) {
+  const int X = dims[0], Y = dims[1], Z = dims[2];
+  const float cell[3] = {size[0] / (float)X, size[1] / (float)Y, size[2] / (float)Z};
+  static int table_n[256], table[256][5][3], have = 0;
+  if (!have) {
+    for (int m = 0; m < 256; ++m) table_n[m] = ora_mc_case(m, table[m]);
+    have = 1;
+  }
+  size_t n = 0;
+  for (int z = 0; z + 1 < Z; ++z)
+    for (int y = 0; y + 1 < Y; ++y)
+      for (int x = 0; x + 1 < X; ++x) {
+        int16_t f[8];
+        int ok = 1, m8 = 0;
+        for (int c = 0; c < 8; ++c) {
+          const size_t i = ((size_t)(z + (c >> 2)) * Y + (y + ((c >> 1) & 1))) * X + (x + (c & 1));
+          f[c] = vol[2 * i];
+          if (vol[2 * i + 1] == 0) ok = 0;
+          if (f[c] < 0) m8 |= 1 << c;
+        }
+        if (!ok || m8 == 0 || m8 == 255) continue;
+        for (int k = 0; k < table_n[m8]; ++k) {
+          if (n < cap)
+            for (int q = 0; q < 3; ++q) {
+              const int a = table[m8][k][q] & 15, b = table[m8][k][q] >> 4;
+              const float Fa = (float)f[a] / 32767.0f, Fb = (float)f[b] / 32767.0f;
+              const float w = Fa / (Fa - Fb);
+              const int ga[3] = {x + (a & 1), y + ((a >> 1) & 1), z + (a >> 2)};
+              const int gb[3] = {x + (b & 1), y + ((b >> 1) & 1), z + (b >> 2)};
+              for (int ax = 0; ax < 3; ++ax) {
+                const float pa = ((float)ga[ax] + 0.5f) * cell[ax];
+                const float pb = ((float)gb[ax] + 0.5f) * cell[ax];
+                tri[9 * n + 3 * q + ax] = pa + w * (pb - pa);
+              }
+            }
+          ++n;
+        }
+      }
+  return n;
+}
+/* the table itself, for the tests: ntri[256], codes[256][5][3] */
+void ora_mc_table(int* ntri, int* codes) {
+  for (int m = 0; m < 256; ++m) {
+    int t[5][3] = {{0}};
+    ntri[m] = ora_mc_case(m, t);
+    for (int k = 0; k < 5; ++k)
+      for (int q = 0; q < 3; ++q) codes[(m * 5 + k) * 3 + q] = k < ntri[m] ? t[k][q] : 0;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* A.2 tracker state machine                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
 struct ora_tracker {

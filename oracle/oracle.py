@@ -250,15 +250,25 @@ def extract_cloud(cfg, vol, cap=None):
     return out, int(n)
 
 
-def extract_mesh(cfg, vol, cap=None):
+def extract_mesh(cfg, vol, cap=None, cubes=False):
+    """triangle soup of the zero level set: marching tetrahedra (A.8), or marching cubes (A.8b) with cubes=True"""
     dims = (C.c_int * 3)(*cfg.vol)
     size = (C.c_float * 3)(*cfg.size)
-    n = lib().ora_extract_mesh(_p(vol), dims, size, None, 0)
+    fn = lib().ora_extract_mesh_mc if cubes else lib().ora_extract_mesh
+    n = fn(_p(vol), dims, size, None, 0)
     m = n if cap is None else min(cap, n)
     out = np.empty((m, 3, 3), np.float32)
     if m:
-        lib().ora_extract_mesh(_p(vol), dims, size, _f(out), m)
+        fn(_p(vol), dims, size, _f(out), m)
     return out, int(n)
+
+
+def mc_table():
+    """the oracle's generated marching-cubes table: (ntri[256], codes[256, 5, 3]) -- edge code = low corner | high corner << 4"""
+    ntri = np.zeros(256, np.int32)
+    codes = np.zeros((256, 5, 3), np.int32)
+    lib().ora_mc_table(ntri.ctypes.data_as(C.POINTER(C.c_int)), codes.ctypes.data_as(C.POINTER(C.c_int)))
+    return ntri, codes
 
 
 class Tracker:

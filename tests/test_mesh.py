@@ -1,8 +1,9 @@
-"""Mesh extraction: the oracle's marching tetrahedra on analytic volumes (CPU), the welded .ply
-writer, and -- on the GPU -- hsk_extract_mesh bit-exact against the oracle.
+"""Mesh extraction: the oracle's marching tetrahedra and marching cubes on analytic volumes (CPU), the
+welded .ply writer, and -- on the GPU -- hsk_extract_mesh / hsk_extract_mesh_cubes bit-exact against the oracle.
 
-The specification is this build's own: PCL's marching-cubes tables are not in the reference,
-so the checks are geometric properties of the result, not golden triangles."""
+The specification is this build's own: PCL's marching-cubes tables are not in the
+reference -- the cubes table is GENERATED (and has the classic table's counts) -- so the checks are geometric properties
+of the result, not golden triangles."""
 import os
 import struct
 
@@ -85,6 +86,78 @@ def test_oracle_mesh_skips_cubes_with_unobserved_corners_and_orders_by_voxel(ora
     assert oracle.extract_mesh(cfg, full)[1] == 0
 
 
+def test_marching_cubes_table_properties(oracle):
+    """all 256 cases of the generated table: the classic counts (820 triangles, at most 5), every triangle corner a cut
+    edge, every cut edge used, the case's triangles close up into loops that run along the cube's faces (fan diagonals
+    are used once in each direction and cancel)"""
+    ntri, codes = oracle.mc_table()
+    assert int(ntri.sum()) == 820 and int(ntri.max()) == 5 and ntri[0] == ntri[255] == 0
+    assert np.bincount(ntri).tolist() == [2, 16, 50, 80, 76, 32]
+    for m in range(256):
+        tris = [tuple(int(c) for c in codes[m, k]) for k in range(ntri[m])]
+        cut = {a | (b << 4) for a in range(8) for ax in range(3) for b in [a | (1 << ax)] if b != a and ((m >> a) & 1) != ((m >> b) & 1)}
+        assert {c for t in tris for c in t} == cut, m
+        directed = {}
+        for t in tris:
+            for i in range(3):
+                e = (t[i], t[(i + 1) % 3])
+                directed[e] = directed.get(e, 0) + 1
+        assert all(v == 1 for v in directed.values()), m
+        # the triangles' outline (directed edges whose reverse is not there: the fans' diagonals cancel) is the case's
+        # loops: every cut edge is left once and entered once, and every outline step runs along one face of the cube
+        outline = [e for e in directed if (e[1], e[0]) not in directed]
+        assert sorted(p for p, _ in outline) == sorted(cut) == sorted(q for _, q in outline), m
+        for (p, q) in outline:
+            pa, pb, qa, qb = p & 15, p >> 4, q & 15, q >> 4
+            assert any(((pa >> k) & 1) == ((pb >> k) & 1) == ((qa >> k) & 1) == ((qb >> k) & 1) for k in range(3)), (m, p, q)
+    # (no complement symmetry: an ambiguous face cuts its INSIDE corners off, so mask 6 -- two diagonal corners of a face
+    # inside -- is two caps, 2 triangles, and its complement 249 one saddle, 4 triangles)
+    assert (ntri[6], ntri[249]) == (2, 4)
+
+
+def test_oracle_marching_cubes_closed_oriented_manifolds(oracle, hsk):
+    from housescan_amd import products as P
+    n, size, r, tau = 48, 3.0, 0.8, 0.2
+    centre = np.array([1.45, 1.52, 1.57])
+    cfg = oracle.default_config(n)
+    vol = sphere_volume(n, size, centre, r, tau)
+    tris, total = oracle.extract_mesh(cfg, vol, cubes=True)
+    mt_total = oracle.extract_mesh(cfg, vol)[1]
+    assert total == len(tris) > 1000 and 0.25 * mt_total < total < 0.45 * mt_total     # a third of the tetrahedra form's triangles
+    verts, idx = P.weld_triangles(tris)
+    census = edge_census(idx)
+    assert all(v == 1 for v in census.values()) and all((b, a) in census for (a, b) in census)
+    good = np.array([len({a, b, c}) == 3 for a, b, c in idx])
+    V, E, F = len(np.unique(idx[good])), len(census) // 2, int(good.sum())
+    assert V - E + F == 2
+    cell = size / n
+    assert np.abs(np.linalg.norm(verts - centre, axis=1) - r).max() < 0.25 * cell
+    t = tris[good]
+    nrm = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+    assert np.all(np.einsum("ij,ij->i", nrm, t.mean(axis=1) - centre) > 0)
+    assert abs(0.5 * np.linalg.norm(nrm, axis=1).sum() / (4 * np.pi * r * r) - 1) < 0.01
+    # a rough field with every kind of ambiguous face and no surface at the volume's border: still closed and consistently
+    # wound everywhere (what the face rule of the generated table guarantees), and the same vertices as the tetrahedra form
+    rng = np.random.default_rng(7)
+    m = 24
+    f = rng.standard_normal((m, m, m))
+    for _ in range(2):
+        f = (f + np.roll(f, 1, 0) + np.roll(f, 1, 1) + np.roll(f, 1, 2)) / 4
+    f = f / np.abs(f).max()
+    f[[0, -1], :, :] = f[:, [0, -1], :] = f[:, :, [0, -1]] = 1.0
+    rough = np.zeros((m, m, m, 2), np.int16)
+    rough[..., 0] = np.where(f < 0, np.minimum(np.rint(f * 30000), -1), np.maximum(np.rint(f * 30000), 1)).astype(np.int16)
+    rough[..., 1] = 3
+    cfg2 = oracle.default_config(m)
+    tr2, tot2 = oracle.extract_mesh(cfg2, rough, cubes=True)
+    assert tot2 > 3000
+    v2, i2 = P.weld_triangles(tr2)
+    c2 = edge_census(i2)
+    assert all(v == 1 for v in c2.values()) and all((b, a) in c2 for (a, b) in c2)
+    v_mt = P.weld_triangles(oracle.extract_mesh(cfg2, rough)[0])[0]
+    assert {tuple(p) for p in v2.tolist()} <= {tuple(p) for p in v_mt.tolist()}      # cubes' vertices are edge vertices of the tetrahedra form too
+
+
 def test_ply_mesh_writer_welds_and_drops_degenerate_faces(hsk, tmp_path):
     from housescan_amd import products as P
     # two triangles sharing an edge + one zero-area triangle + a -0.0 / +0.0 pair that must weld
@@ -125,6 +198,44 @@ def test_gpu_mesh_matches_oracle_bit_for_bit(oracle, hsk, synth_frames):
     trk.upload_tsdf(sv)
     want, _ = oracle.extract_mesh(cfg, sv)
     got, _ = trk.extract_mesh()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    trk.close()
+
+
+@pytest.mark.gpu
+def test_gpu_marching_cubes_matches_oracle_bit_for_bit(oracle, hsk, synth_frames):
+    """hsk_extract_mesh_cubes against the oracle's separately written generator and extraction: a tracked scan, an
+    analytic sphere, and a volume of random signs and weights in which every one of the 256 cases occurs"""
+    n = 96
+    trk = hsk.KinfuTracker(n=n)
+    for k in range(6):
+        trk.process_frame(synth_frames(k)[1])
+    vol = trk.download_tsdf()
+    cfg = oracle.default_config(n)
+    want, total_o = oracle.extract_mesh(cfg, vol, cubes=True)
+    got, total_g = trk.extract_mesh(cubes=True)
+    assert total_g == total_o > 5000 and total_g < 0.62 * trk.extract_mesh()[1]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    head, total_h = trk.extract_mesh(cap=555, cubes=True)
+    assert total_h == total_o and np.array_equal(head, want[:555])
+    sv = sphere_volume(n, 3.0, np.array([1.4, 1.6, 1.5]), 0.7, 0.12)
+    trk.upload_tsdf(sv)
+    want, _ = oracle.extract_mesh(cfg, sv, cubes=True)
+    got, _ = trk.extract_mesh(cubes=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    rng = np.random.default_rng(11)
+    noise = np.zeros((n, n, n, 2), np.int16)
+    noise[..., 0] = rng.integers(1, 32767, (n, n, n)) * rng.choice([-1, 1], (n, n, n))
+    noise[..., 1] = (rng.random((n, n, n)) > 0.02) * rng.integers(1, 100, (n, n, n))
+    masks = set()
+    neg = noise[..., 0] < 0
+    code = sum(neg[(c >> 2):n - 1 + (c >> 2), ((c >> 1) & 1):n - 1 + ((c >> 1) & 1), (c & 1):n - 1 + (c & 1)].astype(np.int32) << c for c in range(8))
+    masks.update(np.unique(code).tolist())
+    assert len(masks) == 256
+    trk.upload_tsdf(noise)
+    want, total_o = oracle.extract_mesh(cfg, noise, cubes=True)
+    got, total_g = trk.extract_mesh(cubes=True)
+    assert total_g == total_o > 1000000
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     trk.close()
 
