@@ -322,11 +322,16 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
 // the chunk's groups) are contiguous.
 #define HSK_SUM_RAGGED 130u
 #define HSK_SUM_MAX 255u
-static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams& vp, int x0, int y, int zb) {
+// (NS = groups, i.e. summary bytes, per lane and chunk: 2 or 4 -- vp.zchunk / 4; a power of two, so shifts and masks)
+template <int NS>
+static __host__ __device__ __forceinline__ size_t hsk_sum_index_ns(const VolParams& vp, int x0, int y, int zb) {
+  static_assert(NS == 2 || NS == 4, "8 or 16 planes per chunk");
   const size_t tiles_x = (size_t)(vp.X + 63) / 64, tiles_y = (size_t)(vp.Y + 3) / 4;
-  const int ns = vp.zchunk >> 2;  // groups, i.e. summary bytes, per lane and chunk (2 or 4)
-  return (((((size_t)(zb / vp.zchunk) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 +
-          (size_t)((x0 >> 2) & 15)) * (size_t)ns + (size_t)((zb >> 2) % ns);
+  return (((((size_t)(zb >> (NS == 4 ? 4 : 3)) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 +
+          (size_t)((x0 >> 2) & 15)) * (size_t)NS + (size_t)((zb >> 2) & (NS - 1));
+}
+static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams& vp, int x0, int y, int zb) {
+  return vp.zchunk == 16 ? hsk_sum_index_ns<4>(vp, x0, y, zb) : hsk_sum_index_ns<2>(vp, x0, y, zb);
 }
 // Where the 16-B vector of voxels x0 .. x0 + 3 (x0 a multiple of 4) of row y, stored plane zb + u (zb a multiple of 4,
 // u in 0 .. 3) sits in the volume, in vectors: the four vectors of a lane-block are consecutive (hsk_dev.h: hsk_vox_index).
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackSta
       dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
     }
     unsigned sum16 = 0u;  // all summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
-    unsigned char* const sum_at = uni + hsk_sum_index(vp, x0, y, zbeg);
+    unsigned char* const sum_at = uni + hsk_sum_index_ns<NS>(vp, x0, y, zbeg);
     {
       bool any_actv = false;
 #pragma unroll

@@ -34,7 +34,7 @@ def scan_room(hsk, variant, n, frames, device_id=0, with_mesh=False):
         worst = max(worst, float(np.linalg.norm(pose[:3, 3] - gt[:3, 3])))
     dt = time.perf_counter() - t0
     cloud, total = trk.extract_cloud()
-    mesh = trk.extract_mesh()[0] if with_mesh else None
+    mesh = trk.extract_mesh(cubes=True)[0] if with_mesh else None   # marching cubes: the form upstream's .ply export has
     trk.close()
     if with_mesh:
         return cloud, worst, lost, len(depth) / dt, mesh
