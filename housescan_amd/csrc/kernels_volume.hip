@@ -1,13 +1,14 @@
 // kernels_volume.hip -- TSDF volume kernels for gfx950: integrate, raycast (A.6),
 // zero-crossing cloud extraction (A.7).  Hand-written for wave64 / 16-B-per-lane HBM access; no MFMA (none
-// of these is a contraction).  The volume is an array of (int16 tsdf*32767, int16 weight) pairs, x fastest.
+// of these is a contraction).  The volume holds (int16 tsdf*32767, int16 weight) pairs in 64-B blocks of one lane-block
+// (4 x-voxels x 4 planes: hsk_dev.h, hsk_vox_index); the host's arrays are row-major, x fastest (k_vol_convert).
 #pragma clang fp contract(off)
 #include "hsk_dev.h"
 #include "hsk_launch.h"
 
 // ------------------------------------------------------------------------------------------------------
-// integrate (A.4).  Layout: each lane owns 4 x-adjacent voxels (one 16-B vector), a wave covers 256 voxels =
-// 1 KiB of a row, a block covers 4 consecutive rows and walks a chunk of z planes.
+// integrate (A.4).  Layout: each lane owns 4 x-adjacent voxels (one 16-B vector per plane, the four planes of a group
+// consecutive: a 64-B block), a wave covers 64 voxels of 4 consecutive rows, a block 16 rows and a chunk of 8 or 16 planes.
 //
 // Only vectors that hold at least one rewritten voxel are read or written, so HBM traffic tracks the
 // algorithmic 8 B x V_upd, not the 8 B x N^3 sweep.  Three conservative culls keep the
@@ -24,9 +25,6 @@
 #ifndef INTEGRATE_WPE
 #define INTEGRATE_WPE 8  // waves per SIMD the register allocator must leave room for (pass A takes 48 VGPRs: 8 waves fit either
                          // way; told so, the compiler schedules it a little tighter: 69.9 -> 69.5 us at 512^3, 332 -> 327 at 1024^3)
-#endif
-#ifndef INTEGRATE_ZCHUNK
-#define INTEGRATE_ZCHUNK 8  // (historical: the chunk is VolParams::zchunk now, 8 or 16 planes, chosen by hsk_pass_a_zchunk)
 #endif
 
 __global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax,
@@ -1780,11 +1778,7 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
       const float Ft = trilinear(vol, vp, t0 + d0 * time_curr, t1 + d1 * time_curr, t2 + d2 * time_curr);
       if (!hsk_isnan(Ftdt) && !hsk_isnan(Ft)) {
         const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
-#ifndef HSK_D3_LO
-#define HSK_D3_LO 1.0f
-#define HSK_D3_HI 2.0f
-#endif
-        if (Ts >= time_curr - HSK_D3_LO * time_step && Ts <= time_curr + HSK_D3_HI * time_step) {  // (D3: two steps round the far sample)
+        if (Ts >= time_curr - time_step && Ts <= time_curr + 2.0f * time_step) {  // (D3: two steps round the far sample)
           vx = t0 + d0 * Ts;
           vy = t1 + d1 * Ts;
           vz = t2 + d2 * Ts;
