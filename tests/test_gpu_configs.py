@@ -211,3 +211,51 @@ def test_config5_four_concurrent_512_contexts_from_four_threads(hsk, synth_frame
         trks[c].close()
     # the four trajectories really differ
     assert not np.array_equal(want[0][0][-1][0], want[1][0][-1][0])
+
+
+def test_tracker_with_every_parameter_off_its_default(hsk, oracle):
+    """every field of the configuration away from its default at once -- anisotropic cells in a non-cubic volume, a longer
+    truncation distance, fx != fy and an off-centre principal point on a 320x240 image, other ICP iteration counts and
+    gates, a start pose that is not the default -- through the tracker, synchronously and pipelined: poses, verdicts, TSDF
+    and model maps the oracle's, bit for bit (the kernels take these as data; the tests elsewhere vary them one or two at
+    a time)"""
+    W, H = 320, 240
+    fx, fy, cx, cy = 262.5 * 1.04, 262.5 * 0.97, W / 2 - 0.5 + 3.25, H / 2 - 0.5 - 2.5
+    vol, size = (160, 96, 200), (3.0, 2.4, 3.2)            # cells 18.75 / 25 / 16 mm
+    iters = (6, 3, 2)
+    start = hsk.synth_pose(0).copy()
+    start[:3, 3] += np.array([0.02, -0.03, 0.01], np.float32)
+    kw_o = dict(vol=vol, size=size, trunc=0.07, W=W, H=H, fx=fx, fy=fy, cx=cx, cy=cy, icp_iters=iters, dist_thresh=0.07,
+                angle_thresh=float(np.sin(np.radians(15.0))), init_R=start[:3, :3], init_t=start[:3, 3])
+    kw_h = dict(vol_y=vol[1], vol_z=vol[2], own_z1=vol[2], vol_size_m=size, trunc_dist_m=0.07, width=W, height=H, fx=fx, fy=fy, cx=cx, cy=cy,
+                icp_iters=iters, icp_dist_thresh_m=0.07, icp_angle_thresh_sin=float(np.sin(np.radians(15.0))), init_pose=start)
+    cfg_o = oracle.default_config(vol[0], **kw_o)
+    ot = oracle.Tracker(cfg_o, omp=True)
+    trk = hsk.KinfuTracker(hsk.default_config(vol[0], **kw_h))
+    pipe = hsk.KinfuTracker(hsk.default_config(vol[0], **kw_h))
+    frames = [hsk.synth_depth(hsk.synth_pose(2 * k), W, H, fx, fy, cx, cy) for k in range(10)]
+    want = []
+    for k, d in enumerate(frames):
+        po, oko = ot.process(d)
+        ph, okh = trk.process_frame(d)
+        assert oko == okh, k
+        assert_same_bits(ph, po, f"pose frame {k}")
+        want.append((po, oko))
+    assert sum(ok for _, ok in want) >= 8                   # it does track
+    assert_same_bits(trk.download_tsdf(), ot.volume(), "TSDF, every parameter off its default")
+    for kind in (2, 3):
+        for level in range(3):
+            assert_same_bits(trk.download_map(kind, level), ot.model_map(kind, level), f"model map {kind} level {level}")
+    pipe.submit_frame(frames[0])
+    got = []
+    for d in frames[1:]:
+        pipe.submit_frame(d)
+        got.append(pipe.wait_frame())
+    got.append(pipe.wait_frame())
+    for k, ((p, ok), (po, oko)) in enumerate(zip(got, want)):
+        assert ok == oko
+        assert_same_bits(p, po, f"pipelined pose frame {k}")
+    assert_same_bits(pipe.download_tsdf(), ot.volume(), "pipelined TSDF")
+    for t in (trk, pipe):
+        t.close()
+    ot.close()
