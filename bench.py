@@ -13,6 +13,7 @@ JSON line (the task contract) with, beside the contract's keys (SURVEY.md 8(d), 
   stage_us, icp_us_per_iter, frame_ms (median / p10 / p90), raycast (rays/s, algorithmic GB/s from oracle-counted steps)
   pcie_inclusive  the same frames handed over as HOST buffers (the real shape of HoniHelper.hs:20), pipelined
   cpu_baseline    the CPU oracle (kind "port") on this box's host cores: all cores and one thread, built -O3 -march=native
+  concurrent_rooms_one_gpu   2 and 4 independent rooms scanned at once on the one GPU (BASELINE configs[4] on a single device)
 
   python bench.py                                   # 1 GPU, 512^3
   python bench.py --gpus N                          # bare, or under python -m torch.distributed.run --nproc-per-node N
@@ -239,6 +240,47 @@ def readout_block(trk, n, with_download=True):
         out["download_tsdf_ms"] = round((t4 - t3) * 1e3, 1)
         out["download_GBps_pageable_host"] = round(vol.nbytes / (t4 - t3) / 1e9, 2)
         del vol
+    return out
+
+
+def concurrent_rooms(hsk, n, dev_frames, local_rank, counts=(2, 4)):
+    """M independent rooms on ONE GPU at once (M contexts in this process, a host thread and a stream pair each; BASELINE
+    configs[4] scans four 512^3 rooms concurrently): one room's frame is a chain of dependent stages that leaves most of the
+    chip idle for half of its time (19 ICP iterations at one wave per SIMD), so rooms interleave -- frames/s in all"""
+    import threading
+    total = len(dev_frames)
+    out = {}
+    for M in counts:
+        trks = [hsk.KinfuTracker(n=n, device_id=local_rank) for _ in range(M)]
+        lost = [0] * M
+        for t in trks:
+            for k in range(min(6, total - 2)):
+                t.process_frame_dev(dev_frames[k].data_ptr())
+        first = min(6, total - 2)
+        gate = threading.Barrier(M + 1)
+
+        def run(i):
+            t = trks[i]
+            gate.wait()
+            t.submit_frame_dev(dev_frames[first].data_ptr())
+            for k in range(first + 1, total):
+                t.submit_frame_dev(dev_frames[k].data_ptr())
+                lost[i] += not t.wait_frame()[1]
+            lost[i] += not t.wait_frame()[1]
+
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(M)]
+        for th in threads:
+            th.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for th in threads:
+            th.join()
+        dt = time.perf_counter() - t0
+        for t in trks:
+            t.close()
+        out["%d_rooms" % M] = {"frames_per_s_in_all": round(M * (total - first) / dt, 1), "per_room": round((total - first) / dt, 1), "lost_frames": int(sum(lost))}
+    out["note"] = ("M independent %d^3 rooms scanned at once on ONE GPU (contexts of one process, a host thread each, %d pipelined frames per room): "
+                   "the stages of different rooms overlap, those of one room cannot" % (n, total - first))
     return out
 
 
@@ -472,6 +514,8 @@ def run_single(args, hsk, torch, local_rank):
     if not args.no_readout:
         out["readout_ms"] = readout_block(trk, n)
     trk.close()
+    if not args.no_rooms and n <= 512:
+        out["concurrent_rooms_one_gpu"] = concurrent_rooms(hsk, n, dev_frames, local_rank)
     # ---- SURVEY.md 8(d) cfg2 / BASELINE configs[1]: the 300-frame scripted stream at 256^3, from a recorded file ----
     if not args.no_trajectory:
         tmpd = tempfile.mkdtemp(prefix="hsk_stream_")
@@ -1105,7 +1149,7 @@ def main():
     ap.add_argument("--stream", default=None, metavar="FILE.hskd",
                     help="time the replay of a recorded depth stream through hsk_track_stream instead of the synthetic in-HBM frames "
                          "(a missing FILE is first recorded from the 300-frame synthetic stream)")
-    ap.add_argument("--no-rooms", action="store_true", help="N > 1, --mode slab: skip the one-room-per-GPU and room-per-GPU-pair (weak scaling) blocks")
+    ap.add_argument("--no-rooms", action="store_true", help="skip the concurrent-room blocks (N = 1: 2 and 4 rooms at once on the one GPU; N > 1, --mode slab: one room per GPU, a room per GPU pair)")
     ap.add_argument("--quick", action="store_true", help="all of the above")
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
