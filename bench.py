@@ -928,8 +928,10 @@ class Launcher:
             path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
             t0 = time.time()
             while not os.path.exists(path):
-                if time.time() - t0 > self.STEP_FILE_S:
-                    return 0   # the director is gone; nothing of this rank's is left running
+                # the director removes the scratch directory when it has printed the line: that, too, says "done" (a
+                # follower whose last worker exits late must not wait for a file that will never come)
+                if not os.path.isdir(self.dir) or time.time() - t0 > self.STEP_FILE_S:
+                    return 0   # the director is done or gone; nothing of this rank's is left running
                 time.sleep(0.05)
             step = json.load(open(path))
             self.step_no += 1
