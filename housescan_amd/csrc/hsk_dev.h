@@ -27,8 +27,8 @@ struct TrackState {
   int n_iter;
   int need_reset;      // sticky after a tracking loss: later frames already in flight are dropped until the host resets
   double sums[27];     // last reduced normal equations (debug / hsk_icp_accumulate)
-  unsigned ring_mark;  // in a host ring slot: sequence number of the frame that wrote it, stored last (RingOut)
-  unsigned pad_;
+  unsigned ring_mark;  // in a host ring slot: sequence number of the frame that wrote it, stored last (RingOut): the frame's inputs are consumed
+  unsigned pose_mark;  // in a host ring slot: the same number, stored as soon as the frame's ICP has ended (its pose and verdict are final)
 };
 
 struct VolParams {

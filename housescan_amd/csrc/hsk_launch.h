@@ -7,7 +7,7 @@
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
                       const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr,
-                      unsigned char* uni = nullptr);
+                      unsigned char* uni = nullptr, const RingOut* early = nullptr);
 size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (kernels_volume.hip: hsk_uniform_code)
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni);  // before anything reads weights

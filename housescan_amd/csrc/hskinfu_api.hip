@@ -444,7 +444,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   return HSK_OK;
 }
 
-static int wait_slot(hsk_ctx* k, int slot);
+static int wait_slot(hsk_ctx* k, int slot, bool pose_only = false);
 extern "C" int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked);
 
 extern "C" void hsk_destroy(hsk_ctx* k) {
@@ -504,11 +504,15 @@ static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
                    (k->prof && k->prof_levels && !fin) ? k->ev_icp : nullptr);
 }
 
-static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr) {
+// report_early: a pipelined frame -- the integrate's first kernel, which ends the frame's ICP, tells the host the pose at
+// once (pose_mark of the frame's ring slot); the raycast's report, an integrate later, then says that the frame's inputs
+// are consumed (ring_mark)
+static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr, bool report_early = false) {
   k->weights_pending = true;
+  const RingOut ring = {k->d_ring_view, k->d_fifo_view, k->d_ring_seq};
   launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
                    k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue, (fin && fin->slots) ? fin : nullptr,
-                   k->d_uni);
+                   k->d_uni, report_early ? &ring : nullptr);
 }
 
 static void enqueue_raycast_and_resize(hsk_ctx* k, int* keys, bool report = false) {
@@ -568,7 +572,7 @@ static void enqueue_tracked_frame(hsk_ctx* k, bool with_events) {
 static void enqueue_tracked_rest(hsk_ctx* k) {
   IcpFinal fin;
   enqueue_icp(k, &fin);  // its first iteration also starts the frame (previous pose <- pose, lost flag)
-  enqueue_integrate(k, &fin);  // ... and its last solve happens in the first kernel of the integrate
+  enqueue_integrate(k, &fin, true);  // ... and its last solve happens in the first kernel of the integrate, which reports the pose
   enqueue_raycast_and_resize(k, nullptr, true);  // pipelined frames report their state through the ring
 }
 
@@ -722,7 +726,9 @@ static double frame_timeout_s() {
   }();
   return t;
 }
-static int wait_slot(hsk_ctx* k, int slot) {
+// pose_only: the caller wants the frame's pose and verdict (final once its ICP has ended: pose_mark); otherwise that the
+// frame has consumed its inputs and the stream has passed its integrate (ring_mark: buffer-set reuse, resets)
+static int wait_slot(hsk_ctx* k, int slot, bool pose_only) {
   if (k->ring_expect[slot] == 0u) {
     HIPCHK(k, hipEventSynchronize(k->ring_ev[slot]));
     return HSK_OK;
@@ -731,7 +737,8 @@ static int wait_slot(hsk_ctx* k, int slot) {
   const auto t0 = std::chrono::steady_clock::now();
   // a frame takes well under 2 ms: spin that long before giving the core away (a yield can cost a whole time slice when
   // other threads of the process are runnable -- measured: 2620 -> 1450 frames/s with host frames under torch's threads)
-  for (unsigned long spin = 0; w->ring_mark != k->ring_expect[slot]; ++spin) {
+  volatile unsigned* mark = pose_only ? &w->pose_mark : &w->ring_mark;
+  for (unsigned long spin = 0; *mark != k->ring_expect[slot]; ++spin) {
     __builtin_ia32_pause();
     if ((spin & 4095u) == 4095u) {
       const auto dt = std::chrono::steady_clock::now() - t0;
@@ -813,6 +820,7 @@ static int submit_frame(hsk_ctx* k, const void* depth_dev, hipMemcpyKind kind, i
   k->ring_seq += 1;
   k->ring_expect[slot] = k->ring_seq | 0x80000000u;  // never 0 (0 = "this slot completes through its event")
   ((volatile TrackState*)&k->h_ring[slot])->ring_mark = 0u;
+  ((volatile TrackState*)&k->h_ring[slot])->pose_mark = 0u;
   hipError_t e = hipSuccess;
   // no events on the main stream: the host itself sees, in the pinned ring, that the previous user of this buffer set has
   // finished (it normally has: its pose was collected before this call)
@@ -860,7 +868,7 @@ extern "C" int hsk_wait_frame(hsk_ctx* k, float pose_out[16], int* tracked) {
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   const int slot = k->ring_head;
   {
-    const int rw = wait_slot(k, slot);
+    const int rw = wait_slot(k, slot, true);  // (the pose: the frame's volume work may still be running)
     if (rw != HSK_OK) return rw;
   }
   const TrackState& st = k->h_ring[slot];
@@ -1509,6 +1517,7 @@ extern "C" int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, co
   k->ring_seq += 1;
   k->ring_expect[slot] = k->ring_seq | 0x80000000u;
   ((volatile TrackState*)&k->h_ring[slot])->ring_mark = 0u;
+  ((volatile TrackState*)&k->h_ring[slot])->pose_mark = 0u;
   const RingOut ring = {k->d_ring_view, k->d_fifo_view, k->d_ring_seq};
   launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
                       k->d_nmod[2], k->d_st, &ring);

@@ -295,8 +295,9 @@ __global__ void k_resize_maps2(const float* __restrict__ v0, const float* __rest
     TrackState* dst = ring.slots + ring.slot_fifo[n % HSK_RING_FIFO];
     const int* src_w = (const int*)st;
     int* dst_w = (int*)dst;
-    for (unsigned i = 0; i < sizeof(TrackState) / 4; ++i) dst_w[i] = src_w[i];
+    for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
     __threadfence_system();
+    __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (st->lost) return;

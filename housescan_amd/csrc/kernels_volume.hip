@@ -130,7 +130,7 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, const float* __restrict__ tmin,
                                 float2* __restrict__ dtab, int tw, int th, int dil_blocks, unsigned* __restrict__ qcount,
                                 const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
-                                int2* __restrict__ zint, TrackState* __restrict__ st_out, int2* __restrict__ wgz) {
+                                int2* __restrict__ zint, TrackState* __restrict__ st_out, int2* __restrict__ wgz, RingOut early) {
   // fin.slots != null: the frame's ICP has left its last solve to this launch (launch_icp_fused).  The first wave of
   // EVERY block reads the sharded sums of the last iteration and solves (deterministic: all blocks get the same pose),
   // the block then works with that pose; block 0 also publishes it -- what k_icp_final does in a launch of its own.
@@ -175,6 +175,19 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
             for (int i = 0; i < 3; ++i) st_out->t[i] = p.t[i];
           }
           st_out->n_iter = p.n_iter;
+          if (early.slots) {
+            // The frame's pose and verdict are final HERE -- nothing after the ICP writes them -- so the host is told now,
+            // a whole integrate earlier than by the raycast's report (which stays: its mark says that the frame's
+            // inputs are consumed).  A caller that takes one frame at a time gets its pose back while the volume work
+            // is still running, and its next frame's filtering runs under that.
+            const unsigned n = *early.seq;  // (counted up by the raycast's report, not here)
+            TrackState* dst = early.slots + early.slot_fifo[n % HSK_RING_FIFO];
+            const int* src_w = (const int*)st_out;
+            int* dst_w = (int*)dst;
+            for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
+            __threadfence_system();
+            __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
     }
@@ -1086,7 +1099,7 @@ size_t integrate_queue_words(const VolParams& vp) {
 
 void launch_integrate(hipStream_t s, void* vol, const float* scaled, const TrackState* st, const VolParams& vp, int W,
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
-                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final, unsigned char* uni) {
+                      const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final, unsigned char* uni, const RingOut* early) {
   const int zchunk = vp.nzs >= vp.zchunk ? vp.zchunk : vp.nzs;
   const int zchunks = (vp.nzs + zchunk - 1) / zchunk;
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
@@ -1101,9 +1114,11 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const IcpFinal none = {nullptr, nullptr, 0};
   const IcpFinal fin = (icp_final && !count_only) ? *icp_final : none;
   int2* wgz = zint + ncols;  // behind the column table: one entry per pass-A workgroup footprint (integrate_zint_entries)
+  const RingOut quiet_ring = {nullptr, nullptr, nullptr};
+  const RingOut early_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, fin, tmax,
                      tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, dil_blocks, qcount, st, vp, W, H, in, zint,
-                     const_cast<TrackState*>(st), wgz);
+                     const_cast<TrackState*>(st), wgz, early_ring);
   dim3 block(64, 4, 1);
   dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
@@ -1459,8 +1474,10 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
     TrackState* dst = ring.slots + ring.slot_fifo[n % HSK_RING_FIFO];
     const int* src_w = (const int*)st;
     int* dst_w = (int*)dst;
-    for (unsigned i = 0; i < sizeof(TrackState) / 4; ++i) dst_w[i] = src_w[i];
-    __threadfence_system();     // the state words reach the host before the mark that announces them
+    for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
+    __threadfence_system();     // the state words reach the host before the marks that announce them
+    // (pose_mark: already there when the integrate's first kernel reported early; set here for the frames it did not)
+    __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // Lanes outside the image (a ragged last tile) and lanes whose ray misses the volume stay in the wave as rays that have
