@@ -17,9 +17,10 @@
  *
  * ORA_LITERAL (libkinfu_oracle_literal.so; oracle/Makefile): the SAME pipeline with this build's deliberate deviations
  * from Appendix-A-literal arithmetic taken back out -- FMA contraction allowed (-ffp-contract=fast -mfma: what nvcc does
- * by default), one expf per bilateral tap over the exclusively clipped window with a zero centre filtered like any other
- * (D1), plain binary64 products and sums in the ICP (no 2^-26 snap, D4), LLT Cholesky with square roots (D4), libm
- * sinf / cosf for the pose increment, no rejection of extrapolated hit times (D3), "1 / z < 0" as the only in-front test
+ * by default), one expf per bilateral tap with a zero centre filtered like any other (D1; the window's exclusive clip
+ * is the specification's own since round 4, like pyrDown's), plain binary64 products and sums in the ICP (no 2^-26 snap,
+ * D4), LLT Cholesky with square roots (D4), libm sinf / cosf for the pose increment, every interpolated hit time accepted
+ * (D3: the specification keeps [t - step, t + 2 step]), "1 / z < 0" as the only in-front test
  * (D6), and integrate's camera coordinates advanced incrementally along z as upstream does (A.4's closing note).  It is the yardstick for the north_star's "within a stated tolerance" (tools/spec_vs_literal.py,
  * tests/test_spec_vs_literal.py): how far the bit-reproducible specification moves TSDF values and poses from the
  * PCL-form arithmetic.  Still a recollection of PCL (parity unpinned), still test infrastructure.
