@@ -1251,7 +1251,11 @@ static __device__ __forceinline__ int vox_of_q(float quot) {
 static __device__ __forceinline__ int raw_at(const short2* __restrict__ vol, const VolParams& vp, int x, int y, int z) {
   const int zz = z - vp.zs0;
   if (zz < 0 || zz >= vp.nzs) return 0;
-  return (int)vol[hsk_vox_index(vp, x, y, zz)].x;
+  // (block row and pitch are below 2^24 each: one 24-bit multiply-add forms the row, one widening multiply-add the index --
+  // hsk_vox_index in the fewest instructions: these sit on the march's gather chain)
+  const unsigned row = __umul24((unsigned)zz >> 2, (unsigned)vp.Y) + (unsigned)y;
+  const unsigned low = ((((unsigned)x & ~3u) | ((unsigned)zz & 3u)) << 2) | ((unsigned)x & 3u);
+  return (int)vol[(size_t)row * (unsigned)((vp.X >> 2) << 4) + low].x;
 }
 
 // trilinear TSDF sample (A.6).  Branch-free: indices are clamped for the loads and the NaN of the spec
@@ -1279,9 +1283,14 @@ static __device__ __forceinline__ float trilinear(const short2* __restrict__ vol
   const bool in0 = z0 >= 0 && z0 < vp.nzs, in1 = z1 >= 0 && z1 < vp.nzs;
   // (the index is a sum of one term per axis: two terms per axis, eight additions; the two z taps of a cell share a
   // 64-B block three times out of four)
-  const size_t tx0 = hsk_vox_xterm(gx), tx1 = hsk_vox_xterm(gx + 1);
-  const size_t ty0 = hsk_vox_yterm(vp, gy), ty1 = hsk_vox_yterm(vp, gy + 1);
-  const size_t tz0 = hsk_vox_zterm(vp, in0 ? z0 : 0), tz1 = hsk_vox_zterm(vp, in1 ? z1 : 0);
+  // the upper neighbours' terms by steps from the lower ones: +1 word in x (or to the next block: +13), one row pitch in y,
+  // +4 words in z (or to the next block row of planes: + the plane-group pitch - 12); a z tap outside the stored planes
+  // reads plane 0 (term 0: z0 = -1 gives z1 = 0) and is discarded
+  const size_t pitch = (size_t)((vp.X >> 2) << 4);
+  const size_t tx0 = hsk_vox_xterm(gx), tx1 = tx0 + ((gx & 3) == 3 ? 13u : 1u);
+  const size_t ty0 = (size_t)gy * pitch, ty1 = ty0 + pitch;
+  const size_t tz0 = in0 ? hsk_vox_zterm(vp, z0) : 0;
+  const size_t tz1 = (in0 && in1) ? tz0 + ((z0 & 3) == 3 ? (size_t)vp.Y * pitch - 12u : 4u) : 0;
   const int r000 = vol[tz0 + ty0 + tx0].x, r100 = vol[tz0 + ty0 + tx1].x, r010 = vol[tz0 + ty1 + tx0].x, r110 = vol[tz0 + ty1 + tx1].x;
   const int r001 = vol[tz1 + ty0 + tx0].x, r101 = vol[tz1 + ty0 + tx1].x, r011 = vol[tz1 + ty1 + tx0].x, r111 = vol[tz1 + ty1 + tx1].x;
   const float f000 = hsk_tsdf_unpack(in0 ? r000 : 0), f100 = hsk_tsdf_unpack(in0 ? r100 : 0);
