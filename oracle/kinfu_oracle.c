@@ -874,7 +874,11 @@ void ora_raycast(const int16_t* vol, const int dims[3], const float size[3], flo
 #ifdef ORA_LIT_D3
               if (!isnan(Ts)) { /* A.6 as written: whatever the interpolation gives (also an extrapolated time) */
 #else
-              if (Ts >= time_curr - time_step && Ts <= time_curr + 2.0f * time_step) {
+#ifndef ORA_D3_LO /* (study builds: tools/spec_vs_literal.py --d3-window) */
+#define ORA_D3_LO 1.0f
+#define ORA_D3_HI 2.0f
+#endif
+              if (Ts >= time_curr - ORA_D3_LO * time_step && Ts <= time_curr + ORA_D3_HI * time_step) {
 #endif
                 const float vtx[3] = {t[0] + dir[0] * Ts, t[1] + dir[1] * Ts, t[2] + dir[2] * Ts};
                 vmap[i] = vtx[0];
