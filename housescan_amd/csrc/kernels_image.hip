@@ -21,6 +21,7 @@ extern "C" int hsk_debug_icp_times(unsigned long long* out, int n) {
 #define BIL_R 6
 #define BIL_T 16
 #define BIL_S (BIL_T + 2 * BIL_R)
+#define BIL_OUT (1u << 20)  // a tap outside the image, in the tile's units of a quarter millimetre
 
 struct BilateralWs {
   float w[13 * 13];  // spatial weights: tap-position constants, passed by value so they sit in scalar registers
@@ -30,9 +31,17 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
                                                          const float* __restrict__ wc_tab,
                                                          unsigned short* __restrict__ dst, float* __restrict__ scaled,
                                                          float* __restrict__ tmax, float* __restrict__ tmin) {
-  __shared__ int tile[BIL_S][BIL_S + 1];  // -1 marks "outside the image"
+  // The tile holds 4 x depth: the tap's |difference| then IS the byte offset of its range weight (one v_sad_u32, one
+  // v_min_u32, no shift), and sum1 comes out scaled by exactly 4: a power of two passes through the rounding of every
+  // normal product and sum, and in the subnormal range (weights down to exp(-145) are in the table) an integer depth times
+  // a weight, and any sum of such, is a multiple of 2^-149 and exact either way (binary32 denormals are on: the kernel
+  // descriptors' float_denorm_mode_32 = 3).  A tap outside the image is BIL_OUT: its difference from any 16-bit depth is
+  // beyond the table, its weight +0, and +0 terms leave both sums as they were -- no test per tap.  Six vector
+  // instructions a tap (v_sad_u32, v_min_u32, v_cvt, two v_mul, one v_pk_add for both sums) where there were thirteen and
+  // a lane-mask branch.
+  __shared__ unsigned tile[BIL_S][BIL_S + 1];
   __shared__ float shx[4], shn[4];
-  __shared__ float wc[512];
+  __shared__ float wc[513];  // wc[512] = 0: every difference of 512 and more
   const int tid = threadIdx.y * BIL_T + threadIdx.x;
   const int bx = blockIdx.x * BIL_T, by = blockIdx.y * BIL_T;
   for (int i = tid; i < BIL_S * BIL_S; i += 256) {
@@ -40,9 +49,9 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
     const int gx = bx + lx - BIL_R, gy = by + ly - BIL_R;
     // (the windows' upper clip is exclusive of the image's last column and row -- upstream's loop bounds,
     // cx < min(x - 6 + 13, W - 1): those pixels are in no window, not even their own)
-    tile[ly][lx] = (gx >= 0 && gy >= 0 && gx < W - 1 && gy < H - 1) ? (int)src[gy * W + gx] : -1;
+    tile[ly][lx] = (gx >= 0 && gy >= 0 && gx < W - 1 && gy < H - 1) ? 4u * (unsigned)src[gy * W + gx] : BIL_OUT;
   }
-  for (int i = tid; i < 512; i += 256) wc[i] = wc_tab[i];
+  for (int i = tid; i < 513; i += 256) wc[i] = i < 512 ? wc_tab[i] : 0.0f;
   __syncthreads();
   const int x = bx + threadIdx.x, y = by + threadIdx.y;
   const bool inside = x < W && y < H;
@@ -80,22 +89,25 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
     dst[y * W + x] = 0;
     return;
   }
-  float sum1 = 0.0f, sum2 = 0.0f;
-#pragma unroll
+  float sum1 = 0.0f, sum2 = 0.0f;  // sum1: 4 x the specification's
+  const unsigned value4 = 4u * (unsigned)value;
+  // (a row of taps per trip: unrolled over all 169 the loop is ONE basic block, the scheduler requests every tap first
+  // and the kernel needs 340 registers)
+#pragma unroll 1
   for (int dy = 0; dy < 13; ++dy) {
 #pragma unroll
     for (int dx = 0; dx < 13; ++dx) {
-      const int tmp = tile[threadIdx.y + dy][threadIdx.x + dx];
-      if (tmp >= 0) {
-        int dd = value - tmp;
-        dd = dd < 0 ? -dd : dd;
-        const float wcv = dd < 512 ? wc[dd] : 0.0f;
-        const float w = ws.w[dy * 13 + dx] * wcv;
-        sum1 = sum1 + (float)tmp * w;
-        sum2 = sum2 + w;
-      }
+      const unsigned tmp4 = tile[threadIdx.y + dy][threadIdx.x + dx];
+      unsigned ad;  // 4 |value - tmp|
+      asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ad) : "v"(value4), "v"(tmp4));
+      const unsigned off = min(ad, 2048u);  // 4 x 512 from there on
+      const float wcv = *(const float*)((const char*)wc + off);
+      const float w = ws.w[dy * 13 + dx] * wcv;
+      sum1 = sum1 + (float)tmp4 * w;
+      sum2 = sum2 + w;
     }
   }
+  sum1 = sum1 * 0.25f;
   int res = sum2 > 0.0f ? __float2int_rn(sum1 / sum2) : 0;  // (0 / 0: a last-column / last-row pixel whose window holds no weight)
   res = res < 0 ? 0 : (res > 32767 ? 32767 : res);
   dst[y * W + x] = (unsigned short)res;

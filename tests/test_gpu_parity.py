@@ -246,6 +246,27 @@ def test_preprocess_bit_exact(hsk, oracle, synth_frames):
     trk.close()
 
 
+def test_bilateral_extreme_range_weights_bit_exact(hsk, oracle):
+    """Range weights at the far end of the table: differences of 380 - 511 mm (weights in and below binary32's subnormal
+    range), the cut-off at 512, 16-bit extremes, and windows without a weighty tap (the image's last column and row are in
+    no window, their own included) -- the kernel's tile of 4 x depth and its +0 terms for outside taps must not show."""
+    cfg_o = oracle.default_config(64)
+    trk = hsk.KinfuTracker(n=64)
+    rng = np.random.default_rng(11)
+    H, W = 480, 640
+    imgs = []
+    base = np.full((H, W), 2000, np.int64)
+    imgs.append(base + rng.integers(380, 516, (H, W)) * rng.integers(0, 2, (H, W)))        # every other tap far down the table
+    imgs.append(base + (np.arange(W)[None, :] % 2) * rng.integers(395, 440, (H, W)))       # columns alternate: subnormal weights only, but for the own column
+    imgs.append(rng.integers(0, 65536, (H, W)))                                             # anything 16 bits hold
+    imgs.append(np.where(rng.random((H, W)) < 0.5, 65535, 65535 - rng.integers(0, 600, (H, W))))
+    for img in imgs:
+        d = img.clip(0, 65535).astype(np.uint16)
+        trk.preprocess(d)
+        assert_same_bits(trk.download_depth_level(0), oracle.bilateral(cfg_o, d), "bilateral")
+    trk.close()
+
+
 def test_bilateral_tables_match_oracle(hsk, oracle):
     import ctypes as C
     ws, wc = hsk.bilateral_tables()

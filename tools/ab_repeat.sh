@@ -8,7 +8,7 @@ reps=$1; shift
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical"
 i=0
 for defs in "$@"; do
-  make -s -C housescan_amd/csrc FLAGS="$BASE $defs" 2>&1 | grep -E "error"
+  make -s -j8 -C housescan_amd/csrc FLAGS="$BASE $defs" 2>&1 | grep -E "error"
   cp housescan_amd/libhskinfu.so /tmp/libhsk_v$i.so
   echo "v$i = [$defs]"
   # PARITY="128 256": integrate parity of every variant against the oracle before it is timed (tools/quick_parity.py)
