@@ -547,7 +547,13 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = a; b < 7; ++b) acc[k++] += rint(rs[a] * rd[b]);
+        for (int b = a; b < 7; ++b, ++k) {
+          // (the lane's first pixel starts the sums: no 27 doubles of zeros to write and add to -- 81 instructions of a
+          // wave's ~540 at the coarse level.  A rejected first pixel leaves -0 where the sum of zeros was +0: the block
+          // sums start from +0 and an all-zero block adds nothing, so no sign of zero gets out)
+          const double p = rint(rs[a] * rd[b]);
+          acc[k] = q == 0 ? p : acc[k] + p;
+        }
     }
   }
 }
@@ -576,12 +582,13 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_accumulate(const float* __res
                                                               double* __restrict__ partials) {
   __shared__ double sh[ICP_BLOCK / 64][32];
   double acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   if (!st->lost) {
     IcpLaneIn<ICP_PX> L;
     icp_load_current<ICP_PX>(vcur, ncur, W, H, row0, row1, L);
     icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, st->R, st->t, st->Rp, st->tp, dist_thresh, angle_thresh, acc);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   }
   icp_block_sums(acc, sh, partials + (size_t)blockIdx.x * 27);
 }
@@ -815,14 +822,15 @@ __global__ __launch_bounds__(ICP_BLOCK) void k_icp_iter(double* __restrict__ slo
   }
   __syncthreads();
   ICP_STAMP(2);
-  double acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  if (!sp.lost)
+  // (a lost frame adds nothing: its sums stay the zeros the slot was cleared to.  `sp.lost` is the block's, so the barrier
+  // inside the block sums is taken by all of its threads or by none)
+  if (!sp.lost) {
+    double acc[27];
     icp_accumulate_pixels<ICP_PX>(L, vprev, nprev, W, H, in, sp.R, sp.t, Rp, tp, dist_thresh, angle_thresh, acc);
-  ICP_STAMP(3);
-  // (no barrier here: `sh` has no other user in this kernel since the sums of the previous iteration are gathered by one wave)
-  icp_block_sums_atomic(acc, (double (*)[32])sh, slot_add);
+    ICP_STAMP(3);
+    // (no barrier here: `sh` has no other user in this kernel since the sums of the previous iteration are gathered by one wave)
+    icp_block_sums_atomic(acc, (double (*)[32])sh, slot_add);
+  }
   ICP_STAMP(4);
 }
 

@@ -26,6 +26,11 @@
 #define INTEGRATE_WPE 8  // waves per SIMD the register allocator must leave room for (pass A takes 48 VGPRs: 8 waves fit either
                          // way; told so, the compiler schedules it a little tighter: 69.9 -> 69.5 us at 512^3, 332 -> 327 at 1024^3)
 #endif
+#ifndef INTEGRATE_WPE_LONG
+#define INTEGRATE_WPE_LONG 7  // ... of the form that takes four groups of planes through the stages together (16-plane chunks,
+                              // 1024^3): under 64 registers it spilled 36 bytes; with 72 the stage takes 269 us where it took 279
+                              // (with 6 waves and 80 registers: 277)
+#endif
 
 __global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax,
                            float* __restrict__ tmin, int tw) {
@@ -592,7 +597,7 @@ extern "C" int hsk_debug_pa_times(unsigned long long* out, int n) {
 // compiled into a lane-mask branch round b -- s_and_saveexec / s_cbranch_execz, scalar instructions, which pass A is short of)
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
 template <bool COUNT_ONLY, int NS>
-__global__ __launch_bounds__(256, INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const int2* __restrict__ wgz,
+__global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const int2* __restrict__ wgz,
                                                    const int2* __restrict__ zint, int zchunk, unsigned gxa, unsigned gmagic,
                                                    double* __restrict__ icp_slot0, unsigned char* __restrict__ uni,
                                                    const float2* __restrict__ dtab, int W, int H, int tw, int th, unsigned gya,
