@@ -187,6 +187,17 @@ static __device__ __forceinline__ float hsk_div_small_exact(float a, float n) {
   return __builtin_fmaf(r, y, q0);
 }
 
+// ---- buffer loads (gfx950): address = descriptor base (scalar) + byte offset (one 32-bit register) + scalar offset ------
+// For planes of one array read at the same pixel: the pixel's offset is computed once, the plane's offset is scalar, and no
+// 64-bit address is formed per load (a global load takes a 64-bit address register pair: two instructions per plane).
+// Raw descriptor, no stride, no bound to rely on (the callers clamp their indices as they did for global loads).
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t hsk_buf(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);  // (32-bit data format: gfx90a / gfx94x / gfx950)
+}
+static __device__ __forceinline__ float hsk_buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned scalar_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)scalar_off, 0));
+}
+
 static __device__ __forceinline__ float hsk_dot3(float ax, float ay, float az, float bx, float by, float bz) {
   return (ax * bx + ay * by) + az * bz;
 }

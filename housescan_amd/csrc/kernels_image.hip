@@ -457,18 +457,19 @@ struct IcpLaneIn {
 template <int ICP_PX>
 static __device__ __forceinline__ void icp_load_current(const float* __restrict__ vcur, const float* __restrict__ ncur,
                                                         int W, int H, int row0, int row1, IcpLaneIn<ICP_PX>& L) {
-  const size_t P = (size_t)W * H;
+  const int P4 = W * H * 4;  // bytes of one map plane
+  const __amdgpu_buffer_rsrc_t nbuf = hsk_buf(ncur), vbuf = hsk_buf(vcur);
   const int npx = (row1 - row0) * W;
   const int base = blockIdx.x * (ICP_BLOCK * ICP_PX) + threadIdx.x;
 #pragma unroll
   for (int q = 0; q < ICP_PX; ++q) {
     const int li = base + q * ICP_BLOCK;
     L.ok[q] = li < npx;
-    const size_t i = (size_t)row0 * W + (L.ok[q] ? li : 0);
+    const unsigned i4 = (unsigned)(row0 * W + (L.ok[q] ? li : 0)) * 4u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      L.nc[q][c] = ncur[c * P + i];
-      L.vc[q][c] = vcur[c * P + i];
+      L.nc[q][c] = hsk_buf_load_f32(nbuf, i4, (unsigned)(c * P4));
+      L.vc[q][c] = hsk_buf_load_f32(vbuf, i4, (unsigned)(c * P4));
     }
   }
 }
@@ -480,7 +481,8 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
                                                              const float* R, const float* tt, const float* Rp,
                                                              const float* tp, float dist_thresh, float angle_thresh,
                                                              double* acc) {
-  const size_t P = (size_t)W * H;
+  const int P4 = W * H * 4;  // bytes of one map plane
+  const __amdgpu_buffer_rsrc_t nbuf = hsk_buf(nprev), vbuf = hsk_buf(vprev);
   const float t0 = tt[0], t1 = tt[1], t2 = tt[2];
   const float p0 = tp[0], p1 = tp[1], p2 = tp[2];
   auto& nc = L.nc;
@@ -504,11 +506,13 @@ static __device__ __forceinline__ void icp_accumulate_pixels(IcpLaneIn<ICP_PX>& 
     const bool inr = (fu > -1.0e6f) & (fu < 1.0e6f) & (fv > -1.0e6f) & (fv < 1.0e6f);  // hsk_rint_guard of both
     const int u = __float2int_rn(inr ? fu : 0.0f), v = __float2int_rn(inr ? fv : 0.0f);
     ok[q] = ok[q] & !hsk_isnan(nc[q][0]) & (cpz > 0.0f) & inr & (u >= 0) & (v >= 0) & (u < W) & (v < H);
-    const size_t j = ok[q] ? (size_t)v * W + u : 0;
+    // (buffer loads: the pixel's byte offset in ONE register for all six planes, the plane's offset scalar -- one shift per
+    // pixel where six 64-bit address sums were)
+    const unsigned j4 = ok[q] ? (unsigned)(v * W + u) * 4u : 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      np_[q][c] = nprev[c * P + j];
-      vp_[q][c] = vprev[c * P + j];
+      np_[q][c] = hsk_buf_load_f32(nbuf, j4, (unsigned)(c * P4));
+      vp_[q][c] = hsk_buf_load_f32(vbuf, j4, (unsigned)(c * P4));
     }
   }
   // phase C: gates, the 7-vector row, 27 scaled products
