@@ -418,6 +418,29 @@ def test_icp_sums_and_solve_bit_exact(hsk, oracle, synth_frames):
     trk.close()
 
 
+def test_icp_sums_extremes_bit_exact(hsk, oracle):
+    """the exact accumulation's edge cases through the C ABI: scaled products that are exact ties, products of 2^45, sums close
+    to 2^27 -- whole image and row-sharded"""
+    from icp_extremes import extreme_maps
+    n = 64
+    cfg_o = oracle.default_config(n)
+    trk = hsk.KinfuTracker(n=n)
+    eye = np.eye(4, dtype=np.float32)
+    for level in (0, 1, 2):
+        W, H = cfg_o.W >> level, cfg_o.H >> level
+        s = float(1 << level)
+        vcur, ncur, vmod, nmod = extreme_maps(W, H, cfg_o.fx / s, cfg_o.fy / s, cfg_o.cx / s, cfg_o.cy / s, seed=5 + level)
+        for kind, arr in enumerate((vcur, ncur, vmod, nmod)):
+            trk.upload_map(kind, level, arr)
+        trk.set_pose(eye)
+        osum, nvalid = oracle.icp_accumulate(cfg_o, level, vcur, ncur, vmod, nmod, eye, eye)
+        assert nvalid > 1000
+        assert_same_bits(trk.icp_accumulate(level, eye), osum, f"extreme ICP sums level {level}")
+        parts = [trk.icp_accumulate(level, eye, r0, r1) for r0, r1 in ((0, H // 3), (H // 3, H // 2), (H // 2, H))]
+        assert_same_bits(parts[0] + parts[1] + parts[2], osum, "row-sharded extreme ICP sums")
+    trk.close()
+
+
 @pytest.mark.parametrize("graph", [0, 1])
 def test_tracker_bit_exact_and_accurate(hsk, oracle, synth_frames, graph):
     """whole pipeline, 12 frames: poses and TSDF identical to the oracle; trajectory within 3 mm / 0.1 deg of truth"""

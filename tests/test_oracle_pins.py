@@ -84,6 +84,22 @@ def test_twin_icp_sums(oracle, hsk):
     assert np.linalg.norm(new[:3, 3] - p1[:3, 3]) < np.linalg.norm(est[:3, 3] - p1[:3, 3])
 
 
+def test_twin_icp_sums_extremes(oracle):
+    """ties of the scaled products (k + 1/2: rint must go to even), products of 2^45, sums up to 2^27: oracle and twin agree
+    bit for bit"""
+    from icp_extremes import extreme_maps
+    cfg = small_cfg(oracle)
+    W, H = cfg.W, cfg.H
+    vcur, ncur, vmod, nmod = extreme_maps(W, H, FX, FX, CX, CY)
+    eye = np.eye(4, dtype=np.float32)
+    s_o, n_o = oracle.icp_accumulate(cfg, 0, vcur, ncur, vmod, nmod, eye, eye)
+    s_t, n_t = T.icp_sums(vcur, ncur, vmod, nmod, FX, FX, CX, CY, eye, eye, cfg.dist_thresh, cfg.angle_thresh)
+    total = int((~np.isnan(ncur[0])).sum())
+    assert n_o == n_t and n_o == total
+    assert np.array_equal(s_o.view(np.uint64), s_t.view(np.uint64))
+    assert np.all(np.abs(s_o) < 2.0 ** 27)                      # the exactness bound of the snapped sums
+
+
 def test_sincos_matches_libm(oracle):
     for x in np.concatenate([np.linspace(-0.2, 0.2, 41), np.linspace(-7, 7, 57), [1e-9, 0.0, 1234.5]]):
         s, c = oracle.sincos(float(x))
