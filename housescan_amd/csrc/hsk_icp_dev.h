@@ -148,8 +148,10 @@ struct IcpPose {
 
 
 
-static __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+// lane Q of every quad to the quad's four lanes (DPP quad_perm [Q, Q, Q, Q]: a plain vector move, no scalar register)
+template <int Q>
+static __device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), Q * 0x55, 0xf, 0xf, true));
 }
 // Row `i` of hsk_pose_update_sc: the same expressions in the same order, element by element (the three 3x3 products
 // are row-separable), so three lanes produce the rows of the new rotation and translation with the bits one lane would.
@@ -170,10 +172,10 @@ static __device__ __forceinline__ void hsk_pose_update_row(int i, const float* R
   for (int j = 0; j < 3; ++j) rn[j] = (inc[0] * R[j] + inc[1] * R[3 + j]) + inc[2] * R[6 + j];
 }
 
-// Executed by the whole first wave: lane 0 solves; lanes 0..2 evaluate one sine/cosine pair each (the three polynomial
-// evaluations are the longest serial piece after the factorisation) and then one row each of the pose update (three
-// 3x3 products on one lane were 150 dependent instructions); the rows are broadcast, so every lane of the wave
-// leaves with the whole new pose.
+// Executed by the whole first wave: every lane solves; the lanes of a quad evaluate one sine/cosine pair each (the three
+// polynomial evaluations are the longest serial piece after the factorisation) and then one row each of the pose update
+// (three 3x3 products on one lane were 150 dependent instructions); the rows travel inside the quad, so every lane of the
+// wave leaves with the whole new pose.
 static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose& p, int g_icp_iter = 99) {
   (void)g_icp_iter;  // only the timing build's stamps use it
   const int lane = threadIdx.x & 63;
@@ -190,22 +192,29 @@ static __device__ __forceinline__ void icp_solve_step(const double* tot, IcpPose
     if (!go) p.lost = 1;
     ICP_STAMP(6);
   }
+  // Every QUAD of lanes does what lanes 0..2 would: lane q of a quad (the fourth doubles as the third) evaluates one
+  // sine / cosine pair and one row of the pose update, and the values travel inside the quad by DPP moves -- the 18
+  // broadcasts were v_readlane, each a trip through a scalar register with its wait states on the solve's chain.
+  const int qi = (lane & 3) < 3 ? (lane & 3) : 2;
   double sd, cd;
-  hsk_sincos((double)(lane == 0 ? x6[0] : (lane == 1 ? x6[1] : x6[2])), &sd, &cd);
+  hsk_sincos((double)(qi == 0 ? x6[0] : (qi == 1 ? x6[1] : x6[2])), &sd, &cd);
   const float sf = (float)sd, cf = (float)cd;
-  const float sa = lane_bcast(sf, 0), ca = lane_bcast(cf, 0);
-  const float sb = lane_bcast(sf, 1), cb = lane_bcast(cf, 1);
-  const float sg = lane_bcast(sf, 2), cg = lane_bcast(cf, 2);
+  const float sa = quad_bcast<0>(sf), ca = quad_bcast<0>(cf);
+  const float sb = quad_bcast<1>(sf), cb = quad_bcast<1>(cf);
+  const float sg = quad_bcast<2>(sf), cg = quad_bcast<2>(cf);
   ICP_STAMP(7);
   if (go) {  // wave-uniform
     float rn[3], tn;
-    hsk_pose_update_row(lane < 3 ? lane : 2, p.R, p.t, x6, sa, ca, sb, cb, sg, cg, rn, &tn);
+    hsk_pose_update_row(qi, p.R, p.t, x6, sa, ca, sb, cb, sg, cg, rn, &tn);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) p.R[r * 3 + j] = lane_bcast(rn[j], r);
-      p.t[r] = lane_bcast(tn, r);
+    for (int j = 0; j < 3; ++j) {
+      p.R[0 * 3 + j] = quad_bcast<0>(rn[j]);
+      p.R[1 * 3 + j] = quad_bcast<1>(rn[j]);
+      p.R[2 * 3 + j] = quad_bcast<2>(rn[j]);
     }
+    p.t[0] = quad_bcast<0>(tn);
+    p.t[1] = quad_bcast<1>(tn);
+    p.t[2] = quad_bcast<2>(tn);
     p.n_iter += 1;
   }
   ICP_STAMP(8);
