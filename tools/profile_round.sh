@@ -31,6 +31,9 @@ for job in "512 300 2 direct" "512 300 8 direct" "512 100 4 composite" "512 100 
   (cd $ROOT && timeout 1200 python3 tools/long_parity_slabs.py $1 $2 $3 $4 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_slabs_$1_$3_$4.txt)
   cat $OUT/long_parity_slabs_$1_$3_$4.txt
 done
+# ... and with every configuration field off its default (non-cubic, non-power-of-two volume, fx != fy, other gates and iteration counts)
+(cd $ROOT && timeout 1200 python3 tools/long_parity_nondefault.py 300 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_nondefault.txt)
+cat $OUT/long_parity_nondefault.txt
 # the raw per-dispatch CSVs exceed what gpurun copies back (64 MiB): only the summaries travel
 rm -rf $OUT/trace $OUT/pmc/p[0-9]*
 tail -5 $OUT/pmc_summary.txt
