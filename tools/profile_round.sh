@@ -26,7 +26,7 @@ for job in "256 300" "512 300" "1024 100"; do
 done
 # ... and of the z-slab group on this one device: 2 and 8 slabs with the direct exchange, 4 with the staged composites,
 # 2 with the row-sharded ICP (N slabs = one volume, bit for bit, at length)
-for job in "512 300 2 direct" "512 300 8 direct" "512 100 4 composite" "512 100 2 icp_allreduce"; do
+for job in "512 300 2 direct" "512 300 8 direct" "512 100 4 composite" "512 100 2 icp_allreduce" "1024 60 4 direct" "1024 60 8 direct"; do
   set -- $job
   (cd $ROOT && timeout 1200 python3 tools/long_parity_slabs.py $1 $2 $3 $4 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_slabs_$1_$3_$4.txt)
   cat $OUT/long_parity_slabs_$1_$3_$4.txt
