@@ -793,6 +793,26 @@ def child_main(args):
     hb("done")
 
 
+def visible_gpu_count():
+    """GPUs this process's workers could open, WITHOUT a HIP call (the launcher must stay a process that has never touched the
+    GPU): the kfd topology's nodes with SIMDs, cut down by a *_VISIBLE_DEVICES list.  0 = cannot tell (no kfd here)."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(path):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if n and v is not None and v.strip():
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 class Launcher:
     """see the comment block above"""
     # seconds without a sign of life before the workers of a form are killed: while torch / the library are being paged
@@ -1203,6 +1223,12 @@ def main():
             raise SystemExit("bench.py: --gpus %d under a launch of %d ranks" % (args.gpus, world))
         if args.mode == "pairs" and args.gpus % 2:
             raise SystemExit("--mode pairs needs an even number of GPUs")
+        seen = visible_gpu_count()
+        if 0 < seen < args.gpus and not args.share_gpu:
+            # (said at once, by the launcher: the workers would each find it out after their imports, a minute and a half later)
+            sys.stderr.write("bench.py: --gpus %d, but this box shows %d GPU%s; --share-gpu runs the ranks on one device (a correctness "
+                             "run of the N > 1 paths, not a measurement)\n" % (args.gpus, seen, "" if seen == 1 else "s"))
+            raise SystemExit(2)
         L = Launcher(args, sys.argv)
         if not L.director:
             return L.follow()

@@ -135,3 +135,25 @@ def test_launcher_pairs_and_single_form_selection(tmp_path):
     assert r.returncode == 0 and out["headline_form"] == "pairs" and out["scaling"] == "weak" and out["config"]["parallelism"] == "pairs2"
     r, out, _ = run_bench(tmp_path, {}, ["--gpus", "3", "--mode", "pairs"])
     assert r.returncode != 0 and "even number" in r.stderr
+
+
+def test_visible_gpu_count_reads_the_topology_without_a_gpu_call(tmp_path, monkeypatch):
+    """the launcher's device count: kfd topology nodes with SIMDs (CPU nodes have none), cut down by a *_VISIBLE_DEVICES
+    list; 0 (cannot tell) where there is no kfd, in which case the launcher lets the workers find out"""
+    sys.path.insert(0, ROOT)
+    import bench
+    import glob as globmod
+    nodes = []
+    for i, simds in enumerate((0, 256, 256, 0, 256)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (96 if simds == 0 else 0, simds))
+        nodes.append(str(d / "properties"))
+    monkeypatch.setattr(globmod, "glob", lambda pattern: nodes if "kfd" in pattern else [])
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setattr(globmod, "glob", lambda pattern: [])
+    assert bench.visible_gpu_count() == 0
