@@ -42,7 +42,7 @@ struct VolParams {
   double icell[3]; // correctly rounded binary64 reciprocals of cell[] (hsk_div_by_cell)
   int stream_nt;   // free-space updates stream the volume with non-temporal accesses (volumes >> Infinity Cache)
   int zchunk;      // planes a pass-A workgroup takes: 8, or 16 for volumes whose launch stays large with half the workgroups
-                   // (hsk_pass_a_zchunk); also the unit of the lane-block summaries' layout (kernels_volume.hip)
+                   // (hsk_pass_a_zchunk); also the unit of the lane-block summaries' layout (integrate.hip)
 };
 
 // ---- where a voxel lives (round 4) ------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // hsk_icp_dev.h -- device pieces of the fused ICP that more than one translation unit needs: the 6x6 solve and pose
 // update (also the host mirror), the sharded-sum read-back and the solve step of one wave.  kernels_image.hip owns the
-// iterations; kernels_volume.hip runs the LAST solve of a frame in the prologue of its first integrate kernel.
+// iterations; integrate.hip runs the LAST solve of a frame in the prologue of its first integrate kernel.
 #pragma once
 #include "hsk_dev.h"
 

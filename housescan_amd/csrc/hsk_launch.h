@@ -8,7 +8,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
                       int H, Intr in, bool count_only, unsigned long long* counter, unsigned* flags,
                       const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr,
                       unsigned char* uni = nullptr, const RingOut* early = nullptr);
-size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (kernels_volume.hip: hsk_uniform_code)
+size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (integrate.hip: hsk_uniform_code)
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni);  // before anything reads weights
 size_t integrate_queue_words(const VolParams& vp);

@@ -59,7 +59,7 @@ struct hsk_ctx {
   float* d_wc = nullptr;
   int* d_keys = nullptr;
   unsigned* d_flags = nullptr;       // bitfield, one bit per brick: ever held a negative TSDF
-  unsigned char* d_uni = nullptr;    // lane-block summaries (kernels_volume.hip: hsk_uniform_code), one byte per 4x1x4 voxels
+  unsigned char* d_uni = nullptr;    // lane-block summaries (integrate.hip: hsk_uniform_code), one byte per 4x1x4 voxels
   size_t uni_bytes = 0;
   bool weights_pending = false;      // an integrate has been enqueued since the summaries' weights were last written back
   size_t flags_bytes = 0;

@@ -1,7 +1,8 @@
-// kernels_volume.hip -- TSDF volume kernels for gfx950: integrate, raycast (A.6),
-// zero-crossing cloud extraction (A.7).  Hand-written for wave64 / 16-B-per-lane HBM access; no MFMA (none
-// of these is a contraction).  The volume holds (int16 tsdf*32767, int16 weight) pairs in 64-B blocks of one lane-block
-// (4 x-voxels x 4 planes: hsk_dev.h, hsk_vox_index); the host's arrays are row-major, x fastest (k_vol_convert).
+// integrate.hip -- TSDF integration for gfx950: the per-frame tables (tiles, column z ranges, the coarse
+// free-space level), pass A (classification of lane-blocks), pass B (per-voxel path), the lane-block summaries and the
+// conversion between the volume's 64-B blocks and the host's row-major arrays.  Hand-written for wave64 / 16-B-per-lane
+// HBM access; no MFMA (nothing here is a contraction).  The volume holds (int16 tsdf*32767, int16 weight) pairs in 64-B
+// blocks of one lane-block (4 x-voxels x 4 planes: hsk_dev.h, hsk_vox_index).
 #pragma clang fp contract(off)
 #include "hsk_dev.h"
 #include "hsk_launch.h"
@@ -1238,1242 +1239,4 @@ void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp,
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni) {
   const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
   hipLaunchKernelGGL(k_summaries<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)vol, vp, uni);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// raycast (A.6).  One ray per lane; a wave covers an 8x8 pixel tile so that neighbouring rays walk
-// neighbouring voxels (L1/L2 locality of the 4-B gathers).  Steps are owned by the slab that contains the
-// far sample's z plane; a single-device context owns all of them.
-// ------------------------------------------------------------------------------------------------------
-// voxel index from the quotient q = p / cell (floor, with the spec's range guards)
-static __device__ __forceinline__ int vox_of_q(float quot) {
-  const float q = floorf(quot);
-  if (!(q >= 0.0f)) return -1;
-  if (q > 1.0e6f) return 1000000;
-  return (int)q;
-}
-
-static __device__ __forceinline__ int raw_at(const short2* __restrict__ vol, const VolParams& vp, int x, int y, int z) {
-  const int zz = z - vp.zs0;
-  if (zz < 0 || zz >= vp.nzs) return 0;
-  // (block row and pitch are below 2^24 each: one 24-bit multiply-add forms the row, one widening multiply-add the index --
-  // hsk_vox_index in the fewest instructions: these sit on the march's gather chain)
-  const unsigned row = __umul24((unsigned)zz >> 2, (unsigned)vp.Y) + (unsigned)y;
-  const unsigned low = ((((unsigned)x & ~3u) | ((unsigned)zz & 3u)) << 2) | ((unsigned)x & 3u);
-  return (int)vol[(size_t)row * (unsigned)((vp.X >> 2) << 4) + low].x;
-}
-
-// trilinear TSDF sample (A.6).  Branch-free: indices are clamped for the loads and the NaN of the spec
-// (sample on the outer shell of the grid) is selected at the end, so that the 8 taps of several calls can be
-// in flight together.
-static __device__ __forceinline__ float trilinear(const short2* __restrict__ vol, const VolParams& vp, float px, float py,
-                                                  float pz) {
-  // floor(p / cell) and the fractional offsets below are the spec's f32 quotients, obtained as binary64 products
-  // (hsk_div_by_const): 3 instructions each instead of a ~10-instruction correctly rounded division
-  int gx = vox_of_q(hsk_div_by_const(px, vp.icell[0])), gy = vox_of_q(hsk_div_by_const(py, vp.icell[1])),
-      gz = vox_of_q(hsk_div_by_const(pz, vp.icell[2]));
-  const bool ok = gx > 0 && gx < vp.X - 1 && gy > 0 && gy < vp.Y - 1 && gz > 0 && gz < vp.Z - 1;
-  gx = min(max(gx, 1), vp.X - 2);
-  gy = min(max(gy, 1), vp.Y - 2);
-  gz = min(max(gz, 1), vp.Z - 2);
-  if (px < ((float)gx + 0.5f) * vp.cell[0]) gx -= 1;
-  if (py < ((float)gy + 0.5f) * vp.cell[1]) gy -= 1;
-  if (pz < ((float)gz + 0.5f) * vp.cell[2]) gz -= 1;
-  const float a = hsk_div_by_const(px - ((float)gx + 0.5f) * vp.cell[0], vp.icell[0]);
-  const float b = hsk_div_by_const(py - ((float)gy + 0.5f) * vp.cell[1], vp.icell[1]);
-  const float c = hsk_div_by_const(pz - ((float)gz + 0.5f) * vp.cell[2], vp.icell[2]);
-  // stored planes: a tap outside the slab reads plane 0 of the slab and is discarded (cannot happen when the
-  // halo is sized as DESIGN.md prescribes)
-  const int z0 = gz - vp.zs0, z1 = z0 + 1;
-  const bool in0 = z0 >= 0 && z0 < vp.nzs, in1 = z1 >= 0 && z1 < vp.nzs;
-  // (the index is a sum of one term per axis: two terms per axis, eight additions; the two z taps of a cell share a
-  // 64-B block three times out of four)
-  // the upper neighbours' terms by steps from the lower ones: +1 word in x (or to the next block: +13), one row pitch in y,
-  // +4 words in z (or to the next block row of planes: + the plane-group pitch - 12); a z tap outside the stored planes
-  // reads plane 0 (term 0: z0 = -1 gives z1 = 0) and is discarded
-  const size_t pitch = (size_t)((vp.X >> 2) << 4);
-  const size_t tx0 = hsk_vox_xterm(gx), tx1 = tx0 + ((gx & 3) == 3 ? 13u : 1u);
-  const size_t ty0 = (size_t)gy * pitch, ty1 = ty0 + pitch;
-  const size_t tz0 = in0 ? hsk_vox_zterm(vp, z0) : 0;
-  const size_t tz1 = (in0 && in1) ? tz0 + ((z0 & 3) == 3 ? (size_t)vp.Y * pitch - 12u : 4u) : 0;
-  const int r000 = vol[tz0 + ty0 + tx0].x, r100 = vol[tz0 + ty0 + tx1].x, r010 = vol[tz0 + ty1 + tx0].x, r110 = vol[tz0 + ty1 + tx1].x;
-  const int r001 = vol[tz1 + ty0 + tx0].x, r101 = vol[tz1 + ty0 + tx1].x, r011 = vol[tz1 + ty1 + tx0].x, r111 = vol[tz1 + ty1 + tx1].x;
-  const float f000 = hsk_tsdf_unpack(in0 ? r000 : 0), f100 = hsk_tsdf_unpack(in0 ? r100 : 0);
-  const float f010 = hsk_tsdf_unpack(in0 ? r010 : 0), f110 = hsk_tsdf_unpack(in0 ? r110 : 0);
-  const float f001 = hsk_tsdf_unpack(in1 ? r001 : 0), f101 = hsk_tsdf_unpack(in1 ? r101 : 0);
-  const float f011 = hsk_tsdf_unpack(in1 ? r011 : 0), f111 = hsk_tsdf_unpack(in1 ? r111 : 0);
-  float res = f000 * (1.0f - a) * (1.0f - b) * (1.0f - c);
-  res = res + f001 * (1.0f - a) * (1.0f - b) * c;
-  res = res + f010 * (1.0f - a) * b * (1.0f - c);
-  res = res + f011 * (1.0f - a) * b * c;
-  res = res + f100 * a * (1.0f - b) * (1.0f - c);
-  res = res + f101 * a * (1.0f - b) * c;
-  res = res + f110 * a * b * (1.0f - c);
-  res = res + f111 * a * b * c;
-  return ok ? res : HSK_NANF;
-}
-
-// floor(p / cell) of the spec without the IEEE division in the common case: q = p * (1/cell) differs from the
-// correctly rounded quotient by < 3 * 2^-24 * |q|, so unless q sits within 2.5e-4 of an integer (|q| < 1100)
-// both have the same floor; the rare lanes that do sit there take the exact division.
-static __device__ __forceinline__ int vox_fast(float p, float cell, float inv_cell) {
-  const float q = p * inv_cell;
-  float f = floorf(q);
-  const float fr = q - f;
-  if (!(fr > 2.5e-4f && fr < 0.99975f && q > -1100.0f && q < 1100.0f)) f = floorf(p / cell);
-  if (!(f >= 0.0f)) return -1;
-  if (f > 1.0e6f) return 1000000;
-  return (int)f;
-}
-
-// one level of the map pyramid inside a wave that holds an 8x8 pixel tile (lane = y * 8 + x): the lane at the top
-// left of each 2x2 group (dx, dy = lane distance to its right / lower neighbour at this level) forms the mean of the
-// vertex taps and the renormalised mean of the normal taps, NaN when any tap is NaN; other lanes' results are unused
-static __device__ __forceinline__ void pyramid_step(const float* m, int dx, int dy, float* out) {
-  float t1[6], t2[6], t3[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    t1[c] = __shfl_down(m[c], dx, 64);
-    t2[c] = __shfl_down(m[c], dy, 64);
-    t3[c] = __shfl_down(m[c], dx + dy, 64);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int b = 3 * h;
-    float a0 = HSK_NANF, a1 = HSK_NANF, a2 = HSK_NANF;
-    if (!(hsk_isnan(m[b]) || hsk_isnan(t1[b]) || hsk_isnan(t2[b]) || hsk_isnan(t3[b]))) {
-      a0 = (((m[b] + t1[b]) + t2[b]) + t3[b]) / 4.0f;
-      a1 = (((m[b + 1] + t1[b + 1]) + t2[b + 1]) + t3[b + 1]) / 4.0f;
-      a2 = (((m[b + 2] + t1[b + 2]) + t2[b + 2]) + t3[b + 2]) / 4.0f;
-      if (h == 1) {
-        const float inv = 1.0f / sqrtf(hsk_dot3(a0, a1, a2, a0, a1, a2));
-        a0 = a0 * inv;
-        a1 = a1 * inv;
-        a2 = a2 * inv;
-      }
-    }
-    out[b] = a0;
-    out[b + 1] = a1;
-    out[b + 2] = a2;
-  }
-}
-
-#ifdef HSK_RC_TIMING
-__device__ unsigned long long g_rc_times[8192 * 8];  // per tile: 4 stamps, march trips, trips in which a lane gathered
-extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rc_times), (size_t)n * 8);
-}
-#define RC_STAMP(k) do { if (lane == 0 && tile_id < 8192) g_rc_times[tile_id * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define RC_STAMP(k) do { } while (0)
-#endif
-#ifndef RC_BLOCK
-#define RC_BLOCK 64     // one wave = one 8x8 tile = one workgroup with its own 4 KiB copy of the brick bitfield: the 4800
-#endif                  // waves of a 640x480 frame spread evenly over the SIMDs.  Measured 512^3 / 1024^3 (us): 64 threads
-                        // 99 / 124, 128: 107 / 126, 256: 99 / 131, 512: 107 / 142.  With 512-thread blocks and a 32 KiB
-                        // bitfield 88 of the 256 CUs got a third block and the kernel waited for them (raycast_analysis.md).
-#ifndef RC_WPE
-#define RC_WPE 5  // waves per SIMD the register allocator must leave room for (96 VGPRs): the 4800 tiles of a 640x480 frame are all resident at five (5120 slots), and six would cost spills
-#endif
-#ifndef RC_EXT
-#define RC_EXT 2       // further clear super-bricks a crossing may run on through
-#endif
-#define RC_SKIP_MAX (64.0f * (RC_EXT + 1))  // most steps crossed at once
-#ifndef RC_MARGIN
-#define RC_MARGIN 0.125f  // steps a crossing stops short of the last face (3 mm: the exit times and the accumulated ray parameter are
-#endif                    // good to micrometres; two whole steps, the first choice, cost every crossing two steps: 57.3 -> 56.5 us)
-#ifndef RC_TIE
-#define RC_TIE 0.0625f  // steps by which the runner-up face must lie behind the first for a crossing to run on through it
-#endif
-#ifndef RC_SKIP
-#define RC_SKIP 2      // fewest steps worth crossing at once inside a clear super-brick
-#endif
-#ifndef RC_GROUP
-#define RC_GROUP 4     // march steps located and gathered together (k_raycast)
-#endif
-#define RC_STAGE_MAX 4  // 16-B loads per thread: 4 KiB / (64 x 16 B); larger bitfields take the loop below
-// minimum over the 64 lanes of a wave whose lanes are ALL active, as a wave-uniform value: four DPP steps inside each row of
-// 16 lanes, two row broadcasts, one v_readlane (six ds_bpermute round trips through the LDS crossbar before)
-static __device__ __forceinline__ int wave_min_i32(int v) {
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror: every lane holds its row's minimum
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
-// What the kernel needs only AFTER the march (the maps it writes, the pyramid levels): kept out of the march loop's
-// scalar registers.  The compiler loads every kernel argument it uses in the entry block and keeps it there; the march
-// loop already needs ~100 SGPRs (uniform volume constants plus a saved lane mask per level of divergent control flow),
-// so the 16 that these pointers took were spilled into VGPR lanes (v_writelane / v_readlane inside the loop, and any
-// further scalar state cost VGPRs the same way: what rounds 2 and 3 took for a wall at 80 VGPRs).  They are therefore
-// the LAST member of the argument block and read through the kernarg segment pointer after the loop.
-struct RcTail {
-  float* vmap;
-  float* nmap;
-  int* keys;
-  MapPyramid pyr;
-  int W, H;
-};
-struct RcArgs {   // (what the kernel needs first comes first: the first 16 dwords arrive in SGPRs with the wave)
-  const unsigned* flags;
-  int flag_words;
-  int W, H;
-  const TrackState* st;
-  const short2* vol;
-  RingOut ring;
-  Intr in;
-  VolParams vp;
-  RcTail tail;   // never touched by name inside the kernel
-};
-// a member of the argument block fetched where it is used (see RcTail)
-#define RC_ARG(type, member) (*(const type*)(rc_kernarg() + offsetof(RcArgs, member)))
-static __device__ __forceinline__ const char* rc_kernarg() {
-  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ka));
-  return ka;
-}
-// SLAB: this context stores / owns only part of the z range (multi-GPU).
-template <bool SLAB>
-__global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
-  const short2* __restrict__ vol = a.vol;
-  const TrackState* __restrict__ st = a.st;
-  const VolParams& vp = a.vp;
-  const int W = a.W, H = a.H;
-  const Intr& in = a.in;
-  const unsigned* __restrict__ flags = a.flags;
-  const int flag_words = a.flag_words;
-  const RingOut& ring = a.ring;
-  // the whole brick bitfield ("this brick has held a negative TSDF") lives in LDS: the march then touches
-  // global memory only next to surfaces
-  extern __shared__ unsigned lflags[];
-#ifdef HSK_RC_TIMING
-  const int tile_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  RC_STAMP(0);
-#endif
-  // The bitfield is REQUESTED here -- 16-B loads, all of a thread's loads in flight at once (a one-word-at-a-time staging
-  // loop cost 9 us per block: profiles/r01/raycast_analysis.md) -- and put into LDS further down, behind the ray set-up,
-  // which needs none of it: at the start of a launch every wave of the chip is at this point at once, and nothing else
-  // is there to run under the loads.
-  const int nq = (flag_words + HSK_SUPER_WORDS) >> 2;  // brick bits + super-brick bits, both multiples of 4 words
-  // (an indexed temporary array here was placed in scratch memory by the compiler: named registers instead)
-  const int q0 = threadIdx.x, q1 = q0 + RC_BLOCK, q2 = q1 + RC_BLOCK, q3 = q2 + RC_BLOCK;
-  static_assert(RC_STAGE_MAX == 4, "the staging is written for four 16-B loads per thread");
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  const uint4 a0 = q0 < nq ? ((const uint4*)flags)[q0] : zero4;
-  const uint4 a1 = q1 < nq ? ((const uint4*)flags)[q1] : zero4;
-  const uint4 a2 = q2 < nq ? ((const uint4*)flags)[q2] : zero4;
-  const uint4 a3 = q3 < nq ? ((const uint4*)flags)[q3] : zero4;
-#ifndef HSK_RC_TIMING
-  const int lane = threadIdx.x & 63;
-#endif
-  const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
-  // Tile rows are dispatched from the top and bottom edges of the image inwards (0, last, 1, last - 1, ...): the rays of
-  // the border rows meet floor and ceiling at grazing angles and march longest, and a wave dispatched last onto a SIMD
-  // that already holds its share of waves finishes last -- with the rows in image order the launch ended with exactly
-  // those tiles (tools/rc_timing.sh).  Scheduling only.  Measured 512^3 / 1024^3: 90.6 / 117.9 -> 86.8 / 110.8 us.
-  const int ty_lin = tile / tiles_x;
-  const int ty = (ty_lin & 1) ? (tiles_y - 1 - (ty_lin >> 1)) : (ty_lin >> 1);
-  const int x = (tile % tiles_x) * 8 + (lane & 7);
-  const int y = ty * 8 + (lane >> 3);
-  if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0) {
-    // the tracker state is final once the ICP has ended (nothing after it writes it): report it to the host now, also
-    // for a lost or dropped frame, which returns just below
-    const unsigned n = *ring.seq;
-    *ring.seq = n + 1u;
-    TrackState* dst = ring.slots + ring.slot_fifo[n % HSK_RING_FIFO];
-    const int* src_w = (const int*)st;
-    int* dst_w = (int*)dst;
-    for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
-    __threadfence_system();     // the state words reach the host before the marks that announce them
-    // (pose_mark: already there when the integrate's first kernel reported early; set here for the frames it did not)
-    __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // Lanes outside the image (a ragged last tile) and lanes whose ray misses the volume stay in the wave as rays that have
-  // ended: every lane is then active at the top of the march loop, which lets its wave-wide decisions use DPP
-  // reductions read from a fixed lane, and takes one level of divergent control flow out of the loop.
-  const bool in_img = x < W && y < H;
-  if (st->lost) return;
-  const size_t P = (size_t)W * H;
-  const size_t i = in_img ? (size_t)y * W + x : 0;
-  float vx = HSK_NANF, vy = HSK_NANF, vz = HSK_NANF, nx = HSK_NANF, ny = HSK_NANF, nz = HSK_NANF;
-  int key = HSK_KEY_NONE_I;
-
-  const float t0 = st->t[0], t1 = st->t[1], t2 = st->t[2];
-  const float rx = ((float)x - in.cx) / in.fx, ry = ((float)y - in.cy) / in.fy;
-  float d0 = (st->R[0] * rx + st->R[1] * ry) + st->R[2] * 1.0f;
-  float d1 = (st->R[3] * rx + st->R[4] * ry) + st->R[5] * 1.0f;
-  float d2 = (st->R[6] * rx + st->R[7] * ry) + st->R[8] * 1.0f;
-  const float inv = 1.0f / sqrtf(hsk_dot3(d0, d1, d2, d0, d1, d2));
-  d0 = d0 * inv;
-  d1 = d1 * inv;
-  d2 = d2 * inv;
-  if (d0 == 0.0f) d0 = 1e-15f;
-  if (d1 == 0.0f) d1 = 1e-15f;
-  if (d2 == 0.0f) d2 = 1e-15f;
-  const float tmin0 = ((d0 > 0.0f ? 0.0f : vp.size[0]) - t0) / d0, tmax0 = ((d0 > 0.0f ? vp.size[0] : 0.0f) - t0) / d0;
-  const float tmin1 = ((d1 > 0.0f ? 0.0f : vp.size[1]) - t1) / d1, tmax1 = ((d1 > 0.0f ? vp.size[1] : 0.0f) - t1) / d1;
-  const float tmin2 = ((d2 > 0.0f ? 0.0f : vp.size[2]) - t2) / d2, tmax2 = ((d2 > 0.0f ? vp.size[2] : 0.0f) - t2) / d2;
-  float t_start = fmaxf(fmaxf(tmin0, tmin1), tmin2);
-  const float t_exit = fminf(fminf(tmax0, tmax1), tmax2);
-  t_start = fmaxf(t_start, 0.0f);
-  {
-    const float ic0 = 1.0f / vp.cell[0], ic1 = 1.0f / vp.cell[1], ic2 = 1.0f / vp.cell[2];
-    const int bs = vp.bshift;
-    const int bxn = vp.X >> bs, byn = vp.Y >> bs;
-    const float time_step = vp.tau * 0.8f;
-    const float max_time = 3.0f * ((vp.size[0] + vp.size[1]) + vp.size[2]);
-    float time_curr = t_start;
-    int step = 0;
-    // near sample of step 0: the entry voxel, clamped into the grid (A.6)
-    int qx = vox_fast(t0 + d0 * time_curr, vp.cell[0], ic0);
-    int qy = vox_fast(t1 + d1 * time_curr, vp.cell[1], ic1);
-    int qz = vox_fast(t2 + d2 * time_curr, vp.cell[2], ic2);
-    int px = qx < 0 ? 0 : (qx > vp.X - 1 ? vp.X - 1 : qx);
-    int py = qy < 0 ? 0 : (qy > vp.Y - 1 ? vp.Y - 1 : qy);
-    int pz = qz < 0 ? 0 : (qz > vp.Z - 1 ? vp.Z - 1 : qz);
-    bool crossing = false;
-    int nux = 0, nuy = 0, nuz = 0;  // unclamped voxel of the near sample at the crossing
-    // brick flag of a voxel inside the grid (0 when its plane is not stored by this slab)
-    auto flag_at = [&](int vx_, int vy_, int vz_) -> unsigned {
-      const int zz = SLAB ? vz_ - vp.zs0 : vz_;
-      const bool stored = !SLAB || (zz >= 0 && zz < vp.nzs);
-      const int bf = __mul24(__mul24(stored ? (zz >> bs) : 0, byn) + (vy_ >> bs), bxn) + (vx_ >> bs);
-      const unsigned w = lflags[bf >> 5];
-      return stored ? ((w >> (bf & 31)) & 1u) : 0u;
-    };
-    {
-      uint4* dst = (uint4*)lflags;
-      if (q0 < nq) dst[q0] = a0;
-      if (q1 < nq) dst[q1] = a1;
-      if (q2 < nq) dst[q2] = a2;
-      if (q3 < nq) dst[q3] = a3;
-      for (int q = threadIdx.x + RC_STAGE_MAX * RC_BLOCK; q < nq; q += RC_BLOCK) ((uint4*)lflags)[q] = ((const uint4*)flags)[q];
-    }
-    __syncthreads();
-    RC_STAMP(1);
-    unsigned fl_prev = flag_at(px, py, pz);  // always the flag of the current near sample
-    // Voxel of a sample: the spec's floor(p / cell).  q = p * (1 / cell) differs from the correctly rounded quotient
-    // by < 3 * 2^-24 * |q|, so both have the same floor unless q lies within eps of an integer -- for every q inside
-    // or within a voxel of the grid; a sample farther out is outside the grid either way (its error is relative).
-    const float eps = 3.0e-7f * (float)max(vp.X, max(vp.Y, vp.Z)) + 1.0e-5f;
-    bool first = true;  // the near sample of the first step is the (clamped) entry voxel; qx,qy,qz hold it unclamped
-    // voxel of the far sample at ray parameter tn (floor(p / cell) of the spec); false when it lies outside the grid
-    auto far_voxel = [&](float tn, int& gx, int& gy, int& gz) -> bool {
-      const float pnx = t0 + d0 * tn, pny = t1 + d1 * tn, pnz = t2 + d2 * tn;
-      const float q0 = pnx * ic0, q1 = pny * ic1, q2 = pnz * ic2;
-      const float r0 = __builtin_amdgcn_fractf(q0), r1 = __builtin_amdgcn_fractf(q1), r2 = __builtin_amdgcn_fractf(q2);
-      float f0 = q0 - r0, f1 = q1 - r1, f2 = q2 - r2;  // floor
-      // distance of the fractional parts from 1/2: far from 1/2 means close to an integer
-      const float far_from_half = fmaxf(fmaxf(fabsf(r0 - 0.5f), fabsf(r1 - 0.5f)), fabsf(r2 - 0.5f));
-      if (!(far_from_half < 0.5f - eps)) {  // rare (or NaN): the exact floor(p / cell) of the spec
-        f0 = floorf(pnx / vp.cell[0]);
-        f1 = floorf(pny / vp.cell[1]);
-        f2 = floorf(pnz / vp.cell[2]);
-      }
-      // v_cvt_i32_f32 saturates; a negative or huge index fails the unsigned bound test
-      gx = (int)f0;
-      gy = (int)f1;
-      gz = (int)f2;
-      return ((unsigned)gx < (unsigned)vp.X) & ((unsigned)gy < (unsigned)vp.Y) & ((unsigned)gz < (unsigned)vp.Z);  // (no short circuit: no lane-mask branch)
-    };
-#ifdef HSK_RC_TIMING
-    unsigned trips = 0, gtrips = 0;        // acted steps; acted steps that compared voxels (per lane)
-    unsigned it_all = 0, it_skip = 0, it_empty = 0;  // loop iterations; crossings; regular trips in which no lane gathered (wave)
-#endif
-    // The march advances RC_GROUP steps per trip.  A step that lies next to a flagged brick needs its two voxels, and a
-    // wave whose lanes reach such bricks at different steps used to stop for a memory round trip (~0.9 us under load) at
-    // every step in which ANY lane gathered (tools/rc_timing.sh: march time = 0.06 us x steps + 0.9 us x gather steps +
-    // 46 us of waiting for other lanes' gathers).  Here the far samples of the next RC_GROUP steps are located first
-    // (voxel + brick flag: arithmetic and LDS only), then every voxel any of those steps will compare is loaded in
-    // one batch -- the same voxels the step-by-step march reads, no others -- and the steps are then acted on in order
-    // with the values in registers: one round trip per RC_GROUP steps instead of up to RC_GROUP.  Same decisions, same
-    // ray parameters ((time_curr + time_step) + time_step ...), so the maps are bit-identical.
-    bool ended = !(in_img && t_start < t_exit);
-    // Crossing clear super-bricks: when the near sample of EVERY marching lane of the wave sits in a super-brick (4^3
-    // bricks) none of whose bricks has held a negative TSDF, and every lane's ray stays inside its super-brick for the
-    // next RC_SKIP steps and RC_MARGIN of a step more, none of those steps can gather or end -- their only effect is to
-    // advance time_curr and step.  So the wave advances them by the same float additions and looks up the new near
-    // sample once.  The decision is wave-wide (the 64 rays of an 8x8 tile are a few centimetres apart, so they cross the
-    // same super-bricks together; per-lane skipping made every trip pay for both paths: raycast_analysis.md).
-    const bool can_skip = !SLAB && hsk_super_ok(vp);
-    const int ss = bs + HSK_SUPER_SHIFT, sxn = hsk_super_dim(vp.X, bs), syn = hsk_super_dim(vp.Y, bs), szn = hsk_super_dim(vp.Z, bs);
-    const float s_edge0 = (float)(1 << ss) * vp.cell[0], s_edge1 = (float)(1 << ss) * vp.cell[1], s_edge2 = (float)(1 << ss) * vp.cell[2];
-    const float id0 = 1.0f / d0, id1 = 1.0f / d1, id2 = 1.0f / d2;
-    const float inv_step = 1.0f / time_step;
-    // (a wave-wide loop: lanes whose ray has ended idle inside it, so that the wave-wide minimum below can use shuffles)
-    RC_STAMP(6);
-    while (__ballot(!ended && time_curr < max_time) != 0ull) {
-      const bool act = !ended && time_curr < max_time;
-#ifdef HSK_RC_TIMING
-      ++it_all;
-#endif
-      if (can_skip) {
-        // Steps every marching lane can cross at once at one level of the block hierarchy (sh: log2 of the block edge in
-        // voxels; xn, yn, zn: blocks per axis; woff: where the level's bits start in lflags; half: its edge is half a
-        // super-brick's): 0 unless the near sample of EVERY marching lane sits in a clear block.
-        auto crossing_steps = [&](const int sh, const int xn, const int yn, const int zn, const int woff, const bool half) -> int {
-          const int s0 = px >> sh, s1 = py >> sh, s2 = pz >> sh;
-          const int sbit = (s2 * yn + s1) * xn + s0;
-          const bool clear = !((lflags[woff + (sbit >> 5)] >> (sbit & 31)) & 1u);
-          // (one ballot settles the common "no": the waves that graze a surface for a hundred steps -- the ones the launch
-          // ends with -- must not pay for exit distances and a wave-wide minimum at every trip)
-          if (__ballot(act && !clear) != 0ull) return 0;
-          const float g0 = half ? 0.5f * s_edge0 : s_edge0, g1 = half ? 0.5f * s_edge1 : s_edge1, g2 = half ? 0.5f * s_edge2 : s_edge2;
-          // ray parameter at which the ray leaves the block (approximate; RC_MARGIN of a step absorbs the error)
-          float e0 = ((float)(s0 + (d0 > 0.0f ? 1 : 0)) * g0 - t0) * id0;
-          float e1 = ((float)(s1 + (d1 > 0.0f ? 1 : 0)) * g1 - t1) * id1;
-          float e2 = ((float)(s2 + (d2 > 0.0f ? 1 : 0)) * g2 - t2) * id2;
-          float te = fminf(fminf(e0, e1), e2);
-#if RC_EXT > 0
-          // ... and on through up to RC_EXT further blocks while they are clear too (open air: the regular trip that used
-          // to carry the march across every face between two clear blocks is most of what a room costs).  The next block
-          // is the one behind the face the ray leaves by; that is certain only when the runner-up face lies clearly later
-          // (near an edge or corner the float exit times may order wrongly, and the ray could cut through a third, flagged
-          // block): RC_TIE = 1/16 step = 1.5 mm, a thousand times what the exit times can be off by (a few ulp of a few
-          // metres); otherwise the crossing ends here.  (Two steps, the first choice, ended a fifth of the crossings early:
-          // 58.9 -> 57.4 us.)
-          {
-            int c0 = s0, c1 = s1, c2 = s2;
-            bool live = act;
-#pragma unroll
-            for (int k = 0; k < RC_EXT; ++k) {
-              const bool a0 = e0 <= e1 && e0 <= e2, a1 = !a0 && e1 <= e2, a2 = !a0 && !a1;
-              const float second = a0 ? fminf(e1, e2) : (a1 ? fminf(e0, e2) : fminf(e0, e1));
-              const int n0 = c0 + (a0 ? (d0 > 0.0f ? 1 : -1) : 0), n1 = c1 + (a1 ? (d1 > 0.0f ? 1 : -1) : 0),
-                        n2 = c2 + (a2 ? (d2 > 0.0f ? 1 : -1) : 0);
-              live = live && (second - te >= RC_TIE * time_step) && (unsigned)n0 < (unsigned)xn && (unsigned)n1 < (unsigned)yn &&
-                     (unsigned)n2 < (unsigned)zn;
-              const int nb = live ? (n2 * yn + n1) * xn + n0 : 0;
-              live = live && !((lflags[woff + (nb >> 5)] >> (nb & 31)) & 1u);
-              if (live) {
-                c0 = n0; c1 = n1; c2 = n2;
-                e0 = a0 ? e0 + g0 * fabsf(id0) : e0;
-                e1 = a1 ? e1 + g1 * fabsf(id1) : e1;
-                e2 = a2 ? e2 + g2 * fabsf(id2) : e2;
-                te = fminf(fminf(e0, e1), e2);
-              }
-            }
-          }
-#endif
-          const float room = (te - time_curr) * inv_step - RC_MARGIN;
-          return wave_min_i32(!act ? 0x7fffffff : (room >= 1.0f ? (int)fminf(room, RC_SKIP_MAX) : 0));
-        };
-        int n = crossing_steps(ss, sxn, syn, szn, flag_words, false);
-        if (n >= RC_SKIP && n != 0x7fffffff) {  // wave-uniform
-          float tc = time_curr;
-          int i_ = 0;
-          for (; i_ + 4 <= n; i_ += 4) tc = (((tc + time_step) + time_step) + time_step) + time_step;  // (the march's own additions, in order)
-          for (; i_ < n; ++i_) tc = tc + time_step;
-          int nx_, ny_, nz_;
-          const bool fine = !act || (far_voxel(tc, nx_, ny_, nz_) && tc < max_time);
-          if (__ballot(!fine) == 0ull) {
-            if (act) {
-              time_curr = tc;
-              step += n;
-              px = nx_; py = ny_; pz = nz_;
-              first = false;
-              fl_prev = flag_at(px, py, pz);
-            }
-#ifdef HSK_RC_TIMING
-            ++it_skip;
-#endif
-            continue;
-          }
-        }
-      }
-      if (!act) continue;
-      float tt[RC_GROUP];
-      int vx_[RC_GROUP], vy_[RC_GROUP], vz_[RC_GROUP];
-      bool okv[RC_GROUP], need[RC_GROUP];
-      unsigned fl[RC_GROUP];
-      bool all_alive;
-      {
-        float tc = time_curr;
-        bool alive = true;
-        unsigned fprev = fl_prev;
-#pragma unroll
-        for (int g = 0; g < RC_GROUP; ++g) {
-          alive = alive && (tc < max_time);
-          tt[g] = tc + time_step;
-          okv[g] = far_voxel(tt[g], vx_[g], vy_[g], vz_[g]);
-          alive = alive && okv[g];
-          fl[g] = flag_at(alive ? vx_[g] : 0, alive ? vy_[g] : 0, alive ? vz_[g] : 0);  // (looked up whether alive or not: no branch)
-          fl[g] = alive ? fl[g] : 0u;
-          const bool owned = !SLAB || (vz_[g] >= vp.zo0 && vz_[g] < vp.zo1);
-          need[g] = alive && owned && ((fprev | fl[g]) != 0u);
-          fprev = fl[g];
-          tc = tt[g];
-        }
-        all_alive = alive;
-      }
-      bool any_need = false;
-#pragma unroll
-      for (int g = 0; g < RC_GROUP; ++g) any_need = any_need || need[g];
-      // Most trips outside the clear super-bricks still compare nothing (a flagged super-brick is mostly unflagged
-      // bricks): when every marching lane's RC_GROUP steps stay inside the grid, before max_time and away from flagged
-      // bricks, acting on them one by one comes to this.
-      if (__ballot(!(all_alive && !any_need)) == 0ull) {
-        px = vx_[RC_GROUP - 1]; py = vy_[RC_GROUP - 1]; pz = vz_[RC_GROUP - 1];
-        first = false;
-        fl_prev = fl[RC_GROUP - 1];
-        time_curr = tt[RC_GROUP - 1];
-        step += RC_GROUP;
-#ifdef HSK_RC_TIMING
-        trips += RC_GROUP;
-        ++it_empty;
-#endif
-        continue;
-      }
-      int raw[RC_GROUP + 1];  // raw[0]: the near sample of the first step; raw[g + 1]: the far sample of step g
-#pragma unroll
-      for (int g = 0; g <= RC_GROUP; ++g) raw[g] = 0;
-      if (any_need) {
-        if (need[0]) raw[0] = raw_at(vol, vp, px, py, pz);
-#pragma unroll
-        for (int g = 0; g < RC_GROUP; ++g)
-          if (need[g] || (g + 1 < RC_GROUP && need[g + 1])) raw[g + 1] = raw_at(vol, vp, vx_[g], vy_[g], vz_[g]);
-      }
-      // Acting on the RC_GROUP steps in order, without branches: a step halts the lane when the march is past max_time, the
-      // far sample lies outside the grid (the ray ends), or the two voxels show a back face or a zero crossing; the steps
-      // before the first halt advance the lane.  (With a divergent branch and a break per step this was 85 instructions a
-      // step, most of them lane-mask bookkeeping; the same decisions as selects are 15.)
-      {
-        bool run = true, e_out = false, e_back = false, e_cross = false;
-        int adv = 0;
-#pragma unroll
-        for (int g = 0; g < RC_GROUP; ++g) {
-          const float tcur = g == 0 ? time_curr : tt[g - 1];
-          const bool on = run && (tcur < max_time);
-          const bool back = need[g] && raw[g] < 0 && raw[g + 1] > 0;
-          const bool cross = need[g] && raw[g] > 0 && raw[g + 1] < 0;
-          e_out = e_out || (on && !okv[g]);
-          e_back = e_back || (on && okv[g] && back);
-          e_cross = e_cross || (on && okv[g] && cross);
-          run = on && okv[g] && !back && !cross;
-          // the far sample of an advancing step is the next step's near sample
-          px = run ? vx_[g] : px;
-          py = run ? vy_[g] : py;
-          pz = run ? vz_[g] : pz;
-          fl_prev = run ? fl[g] : fl_prev;
-          time_curr = run ? tt[g] : time_curr;
-          adv += run ? 1 : 0;
-#ifdef HSK_RC_TIMING
-          trips += on ? 1 : 0;
-          gtrips += (on && okv[g] && need[g]) ? 1 : 0;
-#endif
-        }
-        const bool was_first = first && adv == 0;
-        first = first && adv == 0;
-        step += adv;
-        if (e_back) key = (step << 1) | 1;
-        if (e_cross) {  // zero crossing: refined below with every lane of the wave; (px, py, pz) is the near sample of its step
-          crossing = true;
-          nux = was_first ? qx : px;
-          nuy = was_first ? qy : py;
-          nuz = was_first ? qz : pz;
-        }
-        ended = ended || e_out || e_back || e_cross;
-      }
-    }
-    // Deferred hit processing: lanes hit at different steps, and refining inside the loop would run these
-    // (memory-latency-bound) taps once per distinct step.  Here the wave runs them once, loads batched.
-    RC_STAMP(2);
-#ifdef HSK_RC_TIMING
-    {
-      // wave totals: the longest lane's trips, and the number of lanes-trips with gathers (max over lanes)
-      unsigned tmax = trips, gmax = gtrips, ia = it_all, is = it_skip, ie = it_empty;
-      for (int o = 32; o > 0; o >>= 1) {
-        tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, o, 64));
-        gmax = max(gmax, (unsigned)__shfl_xor((int)gmax, o, 64));
-        ia = max(ia, (unsigned)__shfl_xor((int)ia, o, 64));
-        is = max(is, (unsigned)__shfl_xor((int)is, o, 64));
-        ie = max(ie, (unsigned)__shfl_xor((int)ie, o, 64));
-      }
-      if (lane == (int)__builtin_ctzll(__ballot(true)) && tile_id < 8192) {
-        g_rc_times[tile_id * 8 + 4] = tmax;
-        g_rc_times[tile_id * 8 + 5] = (unsigned long long)(gmax & 0xffffu) | ((unsigned long long)(ia & 0xffffu) << 16) |
-                                      ((unsigned long long)(is & 0xffffu) << 32) | ((unsigned long long)(ie & 0xffffu) << 48);
-      }
-    }
-#endif
-    if (crossing) {
-      key = (step << 1) | 1;
-      const float tn = time_curr + time_step;
-      const float Ftdt = trilinear(vol, vp, t0 + d0 * tn, t1 + d1 * tn, t2 + d2 * tn);
-      const float Ft = trilinear(vol, vp, t0 + d0 * time_curr, t1 + d1 * time_curr, t2 + d2 * time_curr);
-      if (!hsk_isnan(Ftdt) && !hsk_isnan(Ft)) {
-        const float Ts = time_curr - (time_step * Ft) / (Ftdt - Ft);
-        if (Ts >= time_curr - time_step && Ts <= time_curr + 2.0f * time_step) {  // (D3: two steps round the far sample)
-          vx = t0 + d0 * Ts;
-          vy = t1 + d1 * Ts;
-          vz = t2 + d2 * Ts;
-          key = (step << 1);
-          if (nux > 1 && nuy > 1 && nuz > 1 && nux < vp.X - 2 && nuy < vp.Y - 2 && nuz < vp.Z - 2) {
-            const float xp = trilinear(vol, vp, vx + vp.cell[0], vy, vz), xm = trilinear(vol, vp, vx - vp.cell[0], vy, vz);
-            const float yp = trilinear(vol, vp, vx, vy + vp.cell[1], vz), ym = trilinear(vol, vp, vx, vy - vp.cell[1], vz);
-            const float zp = trilinear(vol, vp, vx, vy, vz + vp.cell[2]), zm = trilinear(vol, vp, vx, vy, vz - vp.cell[2]);
-            const float gxn = xp - xm, gyn = yp - ym, gzn = zp - zm;
-            const float ninv = 1.0f / sqrtf(hsk_dot3(gxn, gyn, gzn, gxn, gyn, gzn));
-            nx = gxn * ninv;
-            ny = gyn * ninv;
-            nz = gzn * ninv;
-          }
-        }
-      }
-    }
-  }
-  // the tail of the argument block, fetched now (the empty asm hides where the pointer comes from, so the loads cannot
-  // be moved up across the march)
-  const RcTail tl = RC_ARG(RcTail, tail);
-  float* __restrict__ vmap = tl.vmap;
-  float* __restrict__ nmap = tl.nmap;
-  int* __restrict__ keys = tl.keys;
-  const MapPyramid pyr = tl.pyr;
-  if (in_img) {
-    vmap[i] = vx;
-    vmap[P + i] = vy;
-    vmap[2 * P + i] = vz;
-    nmap[i] = nx;
-    nmap[P + i] = ny;
-    nmap[2 * P + i] = nz;
-    if (keys) keys[i] = key;
-  }
-  RC_STAMP(3);
-  if (!SLAB && pyr.v1) {
-    // Model pyramid (resizeVMap / resizeNMap, A.3) from the wave's own 8x8 tile: level 1 is the 2x2 mean held by
-    // the even-even lanes, level 2 the 2x2 mean of those -- the arithmetic and its order are k_resize_maps2's, the
-    // taps arrive by lane shuffles instead of a second launch reading the maps back.
-    float m[6] = {vx, vy, vz, nx, ny, nz};
-    float l1[6], l2[6];
-    pyramid_step(m, 1, 8, l1);
-    pyramid_step(l1, 2, 16, l2);
-    const int w1 = W >> 1, w2 = W >> 2;
-    const size_t P1 = (size_t)w1 * (H >> 1), P2 = (size_t)w2 * (H >> 2);
-    if (((x | y) & 1) == 0) {
-      const size_t o = (size_t)(y >> 1) * w1 + (x >> 1);
-      pyr.v1[o] = l1[0]; pyr.v1[P1 + o] = l1[1]; pyr.v1[2 * P1 + o] = l1[2];
-      pyr.n1[o] = l1[3]; pyr.n1[P1 + o] = l1[4]; pyr.n1[2 * P1 + o] = l1[5];
-    }
-    if (((x | y) & 3) == 0) {
-      const size_t o = (size_t)(y >> 2) * w2 + (x >> 2);
-      pyr.v2[o] = l2[0]; pyr.v2[P2 + o] = l2[1]; pyr.v2[2 * P2 + o] = l2[2];
-      pyr.n2[o] = l2[3]; pyr.n2[P2 + o] = l2[4]; pyr.n2[2 * P2 + o] = l2[5];
-    }
-  }
-}
-
-void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
-                    float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring) {
-  const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
-  dim3 block(RC_BLOCK);
-  dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
-  const int words = hsk_flag_words(vp);
-  const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
-  const MapPyramid none = {nullptr, nullptr, nullptr, nullptr};
-  const RingOut quiet = {nullptr, nullptr, nullptr};
-  RcArgs a;
-  a.vol = (const short2*)vol;
-  a.st = st;
-  a.vp = vp;
-  a.W = W;
-  a.H = H;
-  a.in = in;
-  a.flags = flags;
-  a.flag_words = words;
-  a.ring = (!slab && ring) ? *ring : quiet;
-  a.tail.vmap = vmap;
-  a.tail.nmap = nmap;
-  a.tail.keys = keys;
-  a.tail.pyr = (!slab && pyramid) ? *pyramid : none;
-  a.tail.W = W;
-  a.tail.H = H;
-  if (slab)
-    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
-  else
-    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
-}
-// the fused pyramid needs complete 8x8 tiles and a single-device volume
-bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H) {
-  const bool slab = vp.zs0 != 0 || vp.nzs != vp.Z || vp.zo0 != 0 || vp.zo1 != vp.Z;
-  return !slab && (W % 8) == 0 && (H % 8) == 0;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// multi-GPU composite helpers: after the MIN all-reduce of the step keys, a slab keeps its
-// maps only where it won; the bit patterns are then SUM-all-reduced as int32 (exact, keeps NaN and -0).
-// ------------------------------------------------------------------------------------------------------
-__global__ void k_resolve(const int* __restrict__ keys_local, const int* __restrict__ keys_min,
-                          const float* __restrict__ vmap, const float* __restrict__ nmap, int* __restrict__ bits, int P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int kl = keys_local[i], km = keys_min[i];
-  const bool mine = (kl == km) && (km != HSK_KEY_NONE_I) && ((km & 1) == 0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    bits[c * P + i] = mine ? __float_as_int(vmap[c * P + i]) : 0;
-    bits[(3 + c) * P + i] = mine ? __float_as_int(nmap[c * P + i]) : 0;
-  }
-}
-__global__ void k_adopt(const int* __restrict__ keys_min, const int* __restrict__ bits, float* __restrict__ vmap,
-                        float* __restrict__ nmap, int P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int km = keys_min[i];
-  const bool hit = (km != HSK_KEY_NONE_I) && ((km & 1) == 0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    vmap[c * P + i] = hit ? __int_as_float(bits[c * P + i]) : HSK_NANF;
-    nmap[c * P + i] = hit ? __int_as_float(bits[(3 + c) * P + i]) : HSK_NANF;
-  }
-}
-// Direct exchange (hskinfu_group's one-hop form, SURVEY.md 8(e) "xGMI fit"): the slab that won a pixel stores the bit
-// patterns of its vertex / normal straight into EVERY device's composite buffer (its own included) -- peer-mapped
-// memory, one hop over xGMI -- and nothing where it lost: a pixel has at most one winner among all slabs (a march step is
-// owned by exactly one slab), so the writers never collide, and k_adopt reads the composite only where the MIN key says
-// "hit".  Replaces the 7.4 MB all-reduce(SUM) by 24 B per won pixel and peer.
-__global__ void k_resolve_push(const int* __restrict__ keys_local, const int* __restrict__ keys_min,
-                               const float* __restrict__ vmap, const float* __restrict__ nmap, PushDests dst, int P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int kl = keys_local[i], km = keys_min[i];
-  if (!((kl == km) && (km != HSK_KEY_NONE_I) && ((km & 1) == 0))) return;
-  int w[6];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    w[c] = __float_as_int(vmap[c * P + i]);
-    w[3 + c] = __float_as_int(nmap[c * P + i]);
-  }
-  for (int d = 0; d < dst.n; ++d) {
-    int* __restrict__ b = dst.p[d];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) b[c * P + i] = w[c];
-  }
-}
-void launch_resolve_push(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
-                         const PushDests& dst, int P) {
-  hipLaunchKernelGGL(k_resolve_push, dim3((P + 255) / 256), dim3(256), 0, s, keys_local, keys_min, vmap, nmap, dst, P);
-}
-void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
-                    int* bits, int P) {
-  hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, keys_local, keys_min, vmap, nmap, bits, P);
-}
-void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vmap, float* nmap, int P) {
-  hipLaunchKernelGGL(k_adopt, dim3((P + 255) / 256), dim3(256), 0, s, keys_min, bits, vmap, nmap, P);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// extractCloud (A.7): a wave per (y,z) row; pass 1 counts, an exclusive scan orders the rows, pass 2 writes
-// the points in voxel order (deterministic, identical to the sequential restatement).
-// ------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ int crossing_count(const short2* __restrict__ vol, const VolParams& vp, int x, int y,
-                                                     int z, float* pts /* up to 9 floats or null */) {
-  const short2 c = vol[hsk_vox_index(vp, x, y, z - vp.zs0)];
-  if (c.y == 0 || c.x == HSK_DIVISOR) return 0;
-  const float F = (float)c.x / 32767.0f;
-  const float V0 = ((float)x + 0.5f) * vp.cell[0], V1 = ((float)y + 0.5f) * vp.cell[1], V2 = ((float)z + 0.5f) * vp.cell[2];
-  int n = 0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int g = k == 0 ? x : (k == 1 ? y : z);
-    const int dim = k == 0 ? vp.X : (k == 1 ? vp.Y : vp.Z);
-    if (g + 1 >= dim) continue;
-    if (k == 2 && (z + 1 - vp.zs0) >= vp.nzs) continue;  // neighbour plane not stored (cannot happen with halo >= 1)
-    const short2 nb = vol[hsk_vox_index(vp, x + (k == 0 ? 1 : 0), y + (k == 1 ? 1 : 0), z - vp.zs0 + (k == 2 ? 1 : 0))];
-    if (nb.y == 0 || nb.x == HSK_DIVISOR) continue;
-    if (!((c.x > 0 && nb.x < 0) || (c.x < 0 && nb.x > 0))) continue;
-    if (pts) {
-      const float Fn = (float)nb.x / 32767.0f;
-      const float cellk = vp.cell[k];
-      const float Vk = k == 0 ? V0 : (k == 1 ? V1 : V2);
-      const float Vn = Vk + cellk;
-      const float d_inv = 1.0f / (fabsf(F) + fabsf(Fn));
-      const float pk = (Vk * fabsf(Fn) + Vn * fabsf(F)) * d_inv;
-      pts[3 * n + 0] = k == 0 ? pk : V0;
-      pts[3 * n + 1] = k == 1 ? pk : V1;
-      pts[3 * n + 2] = k == 2 ? pk : V2;
-    }
-    ++n;
-  }
-  return n;
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_extract(const short2* __restrict__ vol, VolParams vp,
-                                                 unsigned* __restrict__ row_count,
-                                                 const unsigned long long* __restrict__ row_offset,
-                                                 float* __restrict__ xyz, unsigned long long cap) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int nrows = vp.Y * (vp.zo1 - vp.zo0);
-  if (row >= nrows) return;
-  const int y = row % vp.Y, z = vp.zo0 + row / vp.Y;
-  unsigned long long base = WRITE ? row_offset[row] : 0;
-  unsigned total = 0;
-  for (int xb = 0; xb < vp.X; xb += 64) {
-    const int x = xb + lane;
-    float pts[9];
-    int n = 0;
-    if (x < vp.X) n = crossing_count(vol, vp, x, y, z, WRITE ? pts : nullptr);
-    // inclusive wave scan of n
-    int scan = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(scan, o, 64);
-      if (lane >= o) scan += v;
-    }
-    const int wave_total = __shfl(scan, 63, 64);
-    if (WRITE) {
-      unsigned long long at = base + (unsigned long long)(scan - n);
-      for (int q = 0; q < n; ++q, ++at)
-        if (at < cap) {
-          xyz[3 * at] = pts[3 * q];
-          xyz[3 * at + 1] = pts[3 * q + 1];
-          xyz[3 * at + 2] = pts[3 * q + 2];
-        }
-      base += wave_total;
-    }
-    total += wave_total;
-  }
-  if (!WRITE && lane == 0) row_count[row] = total;
-}
-
-// exclusive scan of row counts by one block (rows <= ~1M; not a hot path)
-__global__ __launch_bounds__(1024) void k_scan_rows(const unsigned* __restrict__ cnt, unsigned long long* __restrict__ off,
-                                                    int n, unsigned long long* __restrict__ total) {
-  __shared__ unsigned long long sh[1024];
-  __shared__ unsigned long long carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int b = 0; b < n; b += 1024) {
-    const int i = b + threadIdx.x;
-    const unsigned long long v = i < n ? cnt[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      unsigned long long a = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-      __syncthreads();
-      sh[threadIdx.x] += a;
-      __syncthreads();
-    }
-    if (i < n) off[i] = carry + sh[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += sh[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total = carry;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Mesh extraction ("next" row 3): marching tetrahedra over the TSDF, triangle soup in voxel order.
-// A cube (x..x+1, y..y+1, z..z+1) is cut into the six Kuhn tetrahedra round its main diagonal (the same cut in
-// every cube, so faces of neighbouring cubes agree); corner i sits at offset (i&1, i>>1&1, i>>2&1).  A cube counts
-// only when all eight weights are non-zero; a corner is inside when its TSDF is negative.  An edge vertex is
-// P = Pa + (Fa / (Fa - Fb)) (Pb - Pa) with a the LOWER corner index, so both cubes that share an edge produce the
-// same bits (the mesh can be welded by exact comparison).  Triangles wind so that the normal points to free space.
-// ------------------------------------------------------------------------------------------------------
-void hsk_build_tet_table(TetTable* tt) {
-  static const int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
-  for (int t = 0; t < 6; ++t)
-    for (int m = 0; m < 16; ++m) {
-      int in[4], out[4], ni = 0, no = 0;
-      for (int v = 0; v < 4; ++v) {
-        if ((m >> v) & 1)
-          in[ni++] = tet[t][v];
-        else
-          out[no++] = tet[t][v];
-      }
-      int e[2][3][2];
-      int nt = 0;
-      if (ni == 1 || ni == 3) {
-        const int apex = ni == 1 ? in[0] : out[0];
-        const int* base = ni == 1 ? out : in;
-        for (int q = 0; q < 3; ++q) e[0][q][0] = apex, e[0][q][1] = base[q];
-        nt = 1;
-      } else if (ni == 2) {
-        const int quad[4][2] = {{in[0], out[0]}, {in[0], out[1]}, {in[1], out[1]}, {in[1], out[0]}};
-        const int pick[2][3] = {{0, 1, 2}, {0, 2, 3}};
-        for (int k = 0; k < 2; ++k)
-          for (int q = 0; q < 3; ++q) e[k][q][0] = quad[pick[k][q]][0], e[k][q][1] = quad[pick[k][q]][1];
-        nt = 2;
-      }
-      // orientation: the normal of (p0, p1, p2) (edge midpoints) must point from the inside corners to the outside ones
-      double ci[3] = {0, 0, 0}, co[3] = {0, 0, 0};
-      for (int v = 0; v < ni; ++v)
-        for (int a = 0; a < 3; ++a) ci[a] += ((in[v] >> a) & 1) / (double)(ni ? ni : 1);
-      for (int v = 0; v < no; ++v)
-        for (int a = 0; a < 3; ++a) co[a] += ((out[v] >> a) & 1) / (double)(no ? no : 1);
-      for (int k = 0; k < nt; ++k) {
-        double pnt[3][3];
-        for (int q = 0; q < 3; ++q)
-          for (int a = 0; a < 3; ++a) pnt[q][a] = 0.5 * (((e[k][q][0] >> a) & 1) + ((e[k][q][1] >> a) & 1));
-        const double u[3] = {pnt[1][0] - pnt[0][0], pnt[1][1] - pnt[0][1], pnt[1][2] - pnt[0][2]};
-        const double w[3] = {pnt[2][0] - pnt[0][0], pnt[2][1] - pnt[0][1], pnt[2][2] - pnt[0][2]};
-        const double nrm[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
-        const double dir = nrm[0] * (co[0] - ci[0]) + nrm[1] * (co[1] - ci[1]) + nrm[2] * (co[2] - ci[2]);
-        if (dir < 0)
-          for (int a = 0; a < 2; ++a) {
-            const int tmp = e[k][1][a];
-            e[k][1][a] = e[k][2][a];
-            e[k][2][a] = tmp;
-          }
-      }
-      tt->ntri[t][m] = (unsigned char)nt;
-      for (int k = 0; k < 2; ++k)
-        for (int q = 0; q < 3; ++q) {
-          const int a = k < nt ? e[k][q][0] : 0, b = k < nt ? e[k][q][1] : 0;
-          tt->edge[t][m][k][q] = (unsigned char)((a < b ? a : b) | ((a < b ? b : a) << 4));  // low corner first
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Marching cubes (the form PCL's KinFu exports its .ply from, README.md:16-17): one table entry per 8-bit inside mask.
-// PCL's 256-case table is not in the reference and cannot be fetched, so the table is GENERATED: on every face of the
-// cube the cut edges are joined by segments -- two cut edges: one segment; four (the two diagonal corners inside): two
-// segments, each cutting ONE INSIDE corner off, a rule that depends on the face's four signs only, so the two cubes that
-// share the face draw the same segments and the surface is closed wherever the cubes are valid.  Every cut edge then has
-// exactly two segments: they chain into closed loops, each loop is wound so that its normal points from the inside
-// corners to the outside ones and is cut into a fan of triangles from its lowest edge (or the next whose fan keeps out of
-// the cube's faces).  820 triangles over the 256
-// cases, at most 5 per cube (the classic table's counts).  Vertices as in the tetrahedra form: from the LOWER corner.
-// ------------------------------------------------------------------------------------------------------
-int hsk_build_cube_table(CubeTable* ct) {
-  struct Edge {
-    int a, b;  // corners, a < b
-  };
-  auto code = [](int a, int b) { return a < b ? (a | (b << 4)) : (b | (a << 4)); };
-  int worst = 0;
-  for (int m = 0; m < 256; ++m) {
-    // segments between cut edges, found face by face; link[e][0..1]: the two edges an edge is joined to
-    int link[256][2], nlink[256];
-    bool cut_edge[256];
-    for (int i = 0; i < 256; ++i) nlink[i] = 0, cut_edge[i] = false;
-    auto join = [&](int e0, int e1) {
-      link[e0][nlink[e0]++] = e1;
-      link[e1][nlink[e1]++] = e0;
-      cut_edge[e0] = cut_edge[e1] = true;
-    };
-    for (int ax = 0; ax < 3; ++ax) {
-      const int u = ax == 0 ? 1 : 0, v = ax == 2 ? 1 : 2;
-      for (int side = 0; side < 2; ++side) {
-        int cyc[4];
-        const int uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
-        for (int i = 0; i < 4; ++i) cyc[i] = (side << ax) | (uv[i][0] << u) | (uv[i][1] << v);
-        int fe[4], ncut = 0;
-        bool cut[4], in[4];
-        for (int i = 0; i < 4; ++i) in[i] = ((m >> cyc[i]) & 1) != 0;
-        for (int i = 0; i < 4; ++i) {
-          fe[i] = code(cyc[i], cyc[(i + 1) & 3]);
-          cut[i] = in[i] != in[(i + 1) & 3];
-          ncut += cut[i] ? 1 : 0;
-        }
-        if (ncut == 2) {
-          int e0 = -1, e1 = -1;
-          for (int i = 0; i < 4; ++i)
-            if (cut[i]) (e0 < 0 ? e0 : e1) = fe[i];
-          join(e0, e1);
-        } else if (ncut == 4) {
-          for (int i = 0; i < 4; ++i)
-            if (in[i]) join(fe[(i + 3) & 3], fe[i]);  // the two edges that meet in inside corner i
-        }
-      }
-    }
-    int nt = 0;
-    bool used[256];
-    for (int i = 0; i < 256; ++i) used[i] = false;
-    for (int start = 0; start < 256; ++start) {  // (edge codes in ascending order: the loops' order, and each loop's first edge)
-      if (!cut_edge[start] || used[start]) continue;
-      int loop[12], len = 0, prev = -1, cur = start;
-      for (;;) {
-        loop[len++] = cur;
-        used[cur] = true;
-        int next = -1;
-        for (int q = 0; q < 2; ++q)
-          if (link[cur][q] != prev && !used[link[cur][q]]) {
-            next = link[cur][q];
-            break;
-          }
-        if (next < 0) break;
-        prev = cur;
-        cur = next;
-      }
-      // winding: Newell normal of the loop of edge midpoints against the summed inside -> outside edge directions
-      double mid[12][3], nrm[3] = {0, 0, 0}, dir[3] = {0, 0, 0};
-      for (int i = 0; i < len; ++i) {
-        const int a = loop[i] & 15, b = loop[i] >> 4;
-        const bool a_in = ((m >> a) & 1) != 0;
-        for (int k = 0; k < 3; ++k) {
-          const double pa = (a >> k) & 1, pb = (b >> k) & 1;
-          mid[i][k] = 0.5 * (pa + pb);
-          dir[k] += a_in ? pb - pa : pa - pb;
-        }
-      }
-      for (int i = 0; i < len; ++i) {
-        const double* p = mid[i];
-        const double* q = mid[(i + 1) % len];
-        nrm[0] += p[1] * q[2] - p[2] * q[1];
-        nrm[1] += p[2] * q[0] - p[0] * q[2];
-        nrm[2] += p[0] * q[1] - p[1] * q[0];
-      }
-      if (nrm[0] * dir[0] + nrm[1] * dir[1] + nrm[2] * dir[2] < 0)
-        for (int i = 1, j = len - 1; i < j; ++i, --j) {
-          const int t = loop[i];
-          loop[i] = loop[j];
-          loop[j] = t;
-        }
-      // the fan's origin: the first edge of the wound loop none of whose diagonals lies IN a face of the cube (both edges on
-      // one face: the neighbour across that face could draw the same line, and the welded mesh would use it four times);
-      // one of the first three always qualifies
-      auto in_one_face = [](int e, int f) {
-        for (int k = 0; k < 3; ++k) {
-          const int b = ((e & 15) >> k) & 1;
-          if ((((e >> 4) >> k) & 1) == b && (((f & 15) >> k) & 1) == b && (((f >> 4) >> k) & 1) == b) return true;
-        }
-        return false;
-      };
-      int origin = 0;
-      for (int o = 0; o < len; ++o) {
-        bool clean = true;
-        for (int k = 2; k + 1 < len; ++k) clean = clean && !in_one_face(loop[o], loop[(o + k) % len]);
-        if (clean) {
-          origin = o;
-          break;
-        }
-      }
-      for (int i = 1; i + 1 < len; ++i) {
-        if (nt < HSK_MC_MAXT) {
-          ct->edge[m][nt][0] = (unsigned char)loop[origin];
-          ct->edge[m][nt][1] = (unsigned char)loop[(origin + i) % len];
-          ct->edge[m][nt][2] = (unsigned char)loop[(origin + i + 1) % len];
-        }
-        ++nt;
-      }
-    }
-    worst = nt > worst ? nt : worst;
-    ct->ntri[m] = (unsigned char)(nt < HSK_MC_MAXT ? nt : HSK_MC_MAXT);
-    for (int t = nt; t < HSK_MC_MAXT; ++t) ct->edge[m][t][0] = ct->edge[m][t][1] = ct->edge[m][t][2] = 0;
-  }
-  return worst;  // 5: the table's row length (checked by the caller)
-}
-
-// triangles of the cube at (x, y, z); when WRITE, stores 9 floats per triangle at tri + 9 * (at + i) while at + i < cap
-template <bool WRITE>
-static __device__ int cube_triangles(const short2* __restrict__ vol, const VolParams& vp, const TetTable& tt, int x, int y, int z,
-                                     float* __restrict__ tri, unsigned long long at, unsigned long long cap) {
-  short2 v[8];
-  bool ok = true;
-  unsigned m8 = 0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    v[c] = vol[hsk_vox_index(vp, x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2) - vp.zs0)];
-    ok = ok && v[c].y != 0;
-    m8 |= (v[c].x < 0 ? 1u : 0u) << c;
-  }
-  if (!ok || m8 == 0u || m8 == 255u) return 0;
-  const int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
-  int n = 0;
-  for (int t = 0; t < 6; ++t) {
-    const unsigned m = ((m8 >> tet[t][0]) & 1u) | (((m8 >> tet[t][1]) & 1u) << 1) | (((m8 >> tet[t][2]) & 1u) << 2) |
-                       (((m8 >> tet[t][3]) & 1u) << 3);
-    const int nt = tt.ntri[t][m];
-    if (WRITE) {
-      for (int k = 0; k < nt; ++k) {
-        const unsigned long long slot = at + (unsigned long long)(n + k);
-        if (slot >= cap) continue;
-        for (int q = 0; q < 3; ++q) {
-          const unsigned code = tt.edge[t][m][k][q];
-          const int a = (int)(code & 15u), b = (int)(code >> 4);
-          // dynamic corner selection without a scratch array
-          short fa = 0, fb = 0;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            fa = c == a ? v[c].x : fa;
-            fb = c == b ? v[c].x : fb;
-          }
-          const float Fa = (float)fa / 32767.0f, Fb = (float)fb / 32767.0f;
-          const float w = Fa / (Fa - Fb);
-          const int ga[3] = {x + (a & 1), y + ((a >> 1) & 1), z + (a >> 2)};
-          const int gb[3] = {x + (b & 1), y + ((b >> 1) & 1), z + (b >> 2)};
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            const float pa = ((float)ga[ax] + 0.5f) * vp.cell[ax];
-            const float pb = ((float)gb[ax] + 0.5f) * vp.cell[ax];
-            tri[9 * slot + 3 * q + ax] = pa + w * (pb - pa);
-          }
-        }
-      }
-    }
-    n += nt;
-  }
-  return n;
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_extract_mesh(const short2* __restrict__ vol, VolParams vp, TetTable tt,
-                                                      unsigned* __restrict__ row_count,
-                                                      const unsigned long long* __restrict__ row_offset,
-                                                      float* __restrict__ tri, unsigned long long cap, int z_end) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int ny = vp.Y - 1;
-  const int nrows = ny * (z_end - vp.zo0);
-  if (row >= nrows) return;
-  const int y = row % ny, z = vp.zo0 + row / ny;
-  unsigned long long base = WRITE ? row_offset[row] : 0;
-  unsigned total = 0;
-  for (int xb = 0; xb < vp.X - 1; xb += 64) {
-    const int x = xb + lane;
-    const int n = x < vp.X - 1 ? cube_triangles<false>(vol, vp, tt, x, y, z, nullptr, 0, 0) : 0;
-    int scan = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(scan, o, 64);
-      if (lane >= o) scan += u;
-    }
-    const int wave_total = __shfl(scan, 63, 64);
-    if (WRITE) {
-      if (n) cube_triangles<true>(vol, vp, tt, x, y, z, tri, base + (unsigned long long)(scan - n), cap);
-      base += wave_total;
-    }
-    total += wave_total;
-  }
-  if (!WRITE && lane == 0) row_count[row] = total;
-}
-
-// cubes whose base plane this context owns and whose upper plane is stored
-int hsk_mesh_z_end(const VolParams& vp) {
-  int z_end = vp.zo1;
-  if (z_end > vp.zs0 + vp.nzs - 1) z_end = vp.zs0 + vp.nzs - 1;
-  if (z_end > vp.Z - 1) z_end = vp.Z - 1;
-  return z_end > vp.zo0 ? z_end : vp.zo0;
-}
-
-void launch_extract_mesh(hipStream_t s, const void* vol, const VolParams& vp, const TetTable& tt, unsigned* row_count,
-                         unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass) {
-  const int z_end = hsk_mesh_z_end(vp);
-  const int nrows = (vp.Y - 1) * (z_end - vp.zo0);
-  if (nrows <= 0) {
-    if (pass == 0) (void)hipMemsetAsync(total, 0, 8, s);
-    return;
-  }
-  dim3 block(256), grid((nrows + 3) / 4);
-  if (pass == 0) {
-    hipLaunchKernelGGL(k_extract_mesh<false>, grid, block, 0, s, (const short2*)vol, vp, tt, row_count, row_offset, tri, cap, z_end);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_count, row_offset, nrows, total);
-  } else {
-    hipLaunchKernelGGL(k_extract_mesh<true>, grid, block, 0, s, (const short2*)vol, vp, tt, row_count, row_offset, tri, cap, z_end);
-  }
-}
-
-// ... and the marching-cubes form: the cube's triangles straight from the table (in device memory: 4 KiB)
-template <bool WRITE>
-static __device__ int cube_triangles_mc(const short2* __restrict__ vol, const VolParams& vp, const CubeTable* __restrict__ ct, int x, int y,
-                                        int z, float* __restrict__ tri, unsigned long long at, unsigned long long cap) {
-  short2 v[8];
-  bool ok = true;
-  unsigned m8 = 0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    v[c] = vol[hsk_vox_index(vp, x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2) - vp.zs0)];
-    ok = ok && v[c].y != 0;
-    m8 |= (v[c].x < 0 ? 1u : 0u) << c;
-  }
-  if (!ok || m8 == 0u || m8 == 255u) return 0;
-  const int nt = ct->ntri[m8];
-  if (WRITE) {
-    for (int k = 0; k < nt; ++k) {
-      const unsigned long long slot = at + (unsigned long long)k;
-      if (slot >= cap) continue;
-      for (int q = 0; q < 3; ++q) {
-        const unsigned code = ct->edge[m8][k][q];
-        const int a = (int)(code & 15u), b = (int)(code >> 4);
-        short fa = 0, fb = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          fa = c == a ? v[c].x : fa;
-          fb = c == b ? v[c].x : fb;
-        }
-        const float Fa = (float)fa / 32767.0f, Fb = (float)fb / 32767.0f;
-        const float w = Fa / (Fa - Fb);
-        const int ga[3] = {x + (a & 1), y + ((a >> 1) & 1), z + (a >> 2)};
-        const int gb[3] = {x + (b & 1), y + ((b >> 1) & 1), z + (b >> 2)};
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          const float pa = ((float)ga[ax] + 0.5f) * vp.cell[ax];
-          const float pb = ((float)gb[ax] + 0.5f) * vp.cell[ax];
-          tri[9 * slot + 3 * q + ax] = pa + w * (pb - pa);
-        }
-      }
-    }
-  }
-  return nt;
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_extract_mesh_mc(const short2* __restrict__ vol, VolParams vp, const CubeTable* __restrict__ ct,
-                                                         unsigned* __restrict__ row_count,
-                                                         const unsigned long long* __restrict__ row_offset,
-                                                         float* __restrict__ tri, unsigned long long cap, int z_end) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int ny = vp.Y - 1;
-  const int nrows = ny * (z_end - vp.zo0);
-  if (row >= nrows) return;
-  const int y = row % ny, z = vp.zo0 + row / ny;
-  unsigned long long base = WRITE ? row_offset[row] : 0;
-  unsigned total = 0;
-  for (int xb = 0; xb < vp.X - 1; xb += 64) {
-    const int x = xb + lane;
-    const int n = x < vp.X - 1 ? cube_triangles_mc<false>(vol, vp, ct, x, y, z, nullptr, 0, 0) : 0;
-    int scan = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(scan, o, 64);
-      if (lane >= o) scan += u;
-    }
-    const int wave_total = __shfl(scan, 63, 64);
-    if (WRITE) {
-      if (n) cube_triangles_mc<true>(vol, vp, ct, x, y, z, tri, base + (unsigned long long)(scan - n), cap);
-      base += wave_total;
-    }
-    total += wave_total;
-  }
-  if (!WRITE && lane == 0) row_count[row] = total;
-}
-
-void launch_extract_mesh_mc(hipStream_t s, const void* vol, const VolParams& vp, const CubeTable* ct_dev, unsigned* row_count,
-                            unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass) {
-  const int z_end = hsk_mesh_z_end(vp);
-  const int nrows = (vp.Y - 1) * (z_end - vp.zo0);
-  if (nrows <= 0) {
-    if (pass == 0) (void)hipMemsetAsync(total, 0, 8, s);
-    return;
-  }
-  const dim3 grid((unsigned)((nrows + 3) / 4));
-  if (pass == 0) {
-    hipLaunchKernelGGL(k_extract_mesh_mc<false>, grid, dim3(256), 0, s, (const short2*)vol, vp, ct_dev, row_count, (const unsigned long long*)nullptr,
-                       (float*)nullptr, 0ull, z_end);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_count, row_offset, nrows, total);
-  } else {
-    hipLaunchKernelGGL(k_extract_mesh_mc<true>, grid, dim3(256), 0, s, (const short2*)vol, vp, ct_dev, row_count, row_offset, tri, cap, z_end);
-  }
-}
-
-void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,
-                    unsigned long long* row_offset, unsigned long long* total, float* xyz, unsigned long long cap,
-                    int pass) {
-  const int nrows = vp.Y * (vp.zo1 - vp.zo0);
-  dim3 block(256), grid((nrows + 3) / 4);
-  if (pass == 0) {
-    hipLaunchKernelGGL(k_extract<false>, grid, block, 0, s, (const short2*)vol, vp, row_count, row_offset, xyz, cap);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_count, row_offset, nrows, total);
-  } else {
-    hipLaunchKernelGGL(k_extract<true>, grid, block, 0, s, (const short2*)vol, vp, row_count, row_offset, xyz, cap);
-  }
 }
