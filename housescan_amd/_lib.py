@@ -93,6 +93,7 @@ SYMBOLS = {
     "hsk_stage_ms": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
     "hsk_icp_level_ms": (C.c_int, [_P, _D]),
     "hsk_integrate_queue_entries": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "hsk_integrate_coarse_counts": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hsk_bilateral_tables": (C.c_int, [_F, _F]),
     "hsk_selftest_exact_ops": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "hsk_group_create": (C.c_int, [C.POINTER(HskConfig), C.c_int, _I, C.c_int, C.POINTER(_P)]),

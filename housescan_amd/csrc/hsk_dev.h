@@ -69,9 +69,12 @@ __host__ __device__ static inline size_t hsk_vol_words(const VolParams& vp) {  /
 // Pass A's chunk of planes per workgroup.  Sixteen planes halve the waves and what each of them spends before its
 // first useful instruction (pose, footprint tables, column terms, queue ticket): -13 us at 1024^3 (65 k workgroups left),
 // +2.6 us at 512^3 (8 k left: the launch's tail grows) -- so the size decides (profiles/r04/integrate_notes.md).
+#ifndef HSK_ZCHUNK16_MIN_WGS
+#define HSK_ZCHUNK16_MIN_WGS 16384
+#endif
 __host__ static inline int hsk_pass_a_zchunk(int X, int Y, int nzs) {
   const long wgs16 = (long)((X + 63) / 64) * ((Y + 15) / 16) * ((nzs + 15) / 16);
-  return wgs16 >= 16384 ? 16 : 8;
+  return wgs16 >= HSK_ZCHUNK16_MIN_WGS ? 16 : 8;
 }
 
 #ifndef HSK_FLAG_WORDS_MAX

@@ -9,14 +9,18 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
                       const float* tmax, int2* zint, unsigned* queue, const IcpFinal* icp_final = nullptr,
                       unsigned char* uni = nullptr, const RingOut* early = nullptr);
 size_t uniform_bytes(const VolParams& vp);  // lane-block summaries (integrate.hip: hsk_uniform_code)
+size_t uniform_lane_bytes(const VolParams& vp);  // ... of which the lane-block bytes; the wave-chunk bytes of the coarse level follow
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni);
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni);  // before anything reads weights
 size_t integrate_queue_words(const VolParams& vp);
 size_t integrate_queue_counter_words();  // the head of the queue buffer that holds the counters ...
 unsigned long long integrate_queue_entries(const unsigned* counter_words);  // ... and their sum, from a host copy of it
+size_t integrate_cflag_offset_bytes(const VolParams& vp);  // the coarse level's verdict bytes inside the zint buffer ...
+size_t integrate_chunk_count(const VolParams& vp);         // ... one per wave-chunk
 size_t integrate_zint_entries(const VolParams& vp);  // column z ranges + workgroup z ranges (launch_integrate's zint)
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);
+size_t tile_table_bytes(int W, int H);  // allocation of `tiles` (launch_tile_max + launch_tile_fine fill it)
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);
 // stored planes [zz0, zz0 + nz) of the volume (64-B blocks, hsk_dev.h: hsk_vox_index) to / from a row-major device array
 void launch_vol_to_linear(hipStream_t s, const void* vol, const VolParams& vp, int zz0, int nz, void* lin);

@@ -276,7 +276,9 @@ static int do_reset(hsk_ctx* k) {
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   HIPCHK(k, hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream));
   HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
-  HIPCHK(k, hipMemsetAsync(k->d_uni, 1, k->uni_bytes, k->stream));  // 1: "all 16 voxels never observed"
+  HIPCHK(k, hipMemsetAsync(k->d_uni, 1, uniform_lane_bytes(k->vp), k->stream));  // 1: "all 16 voxels never observed"
+  // ... and the coarse level behind them: 0, "nothing pending, nothing known" (a never-observed block is not quiet)
+  HIPCHK(k, hipMemsetAsync(k->d_uni + uniform_lane_bytes(k->vp), 0, k->uni_bytes - uniform_lane_bytes(k->vp), k->stream));
   memset(k->h_st, 0, sizeof(TrackState));
   memcpy(k->h_st->R, k->init_R, sizeof(k->init_R));
   memcpy(k->h_st->t, k->init_t, sizeof(k->init_t));
@@ -365,8 +367,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
   for (auto& b : k->ib) {
     CK(hipMalloc((void**)&b.d_raw, P0 * 2));
     CK(hipMalloc((void**)&b.d_scaled, P0 * 4));
-    CK(hipMalloc((void**)&b.d_tmax, (size_t)((c->width + 15) / 16) * ((c->height + 15) / 16) * 4 * 4 +
-                                    (size_t)((c->width + 7) / 8) * ((c->height + 7) / 8) * 8 * 50));  // 8-px table + 4-px table (4x), and nine window shapes of each
+    CK(hipMalloc((void**)&b.d_tmax, tile_table_bytes(c->width, c->height)));
     for (int l = 0; l < HSK_NLEVELS; ++l) {
       const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
       CK(hipMalloc((void**)&b.d_dep[l], P * 2));
@@ -1322,6 +1323,24 @@ extern "C" int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries) {
   free(h);
   HIPCHK(k, e);
   *n_entries = n;
+  return HSK_OK;
+}
+extern "C" int hsk_integrate_coarse_counts(hsk_ctx* k, uint64_t counts[4]) {
+  if (!k || !counts) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const size_t n = integrate_chunk_count(k->vp);
+  unsigned char* h = (unsigned char*)malloc(2 * n);
+  if (!h) return fail(k, HSK_ERR_STATE, "out of host memory");
+  hipError_t e = hipMemcpyAsync(h, (const char*)k->d_zint + integrate_cflag_offset_bytes(k->vp), n, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h + n, k->d_uni + uniform_lane_bytes(k->vp), n, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+    if (h[i] < 3) counts[h[i]] += 1;
+    if (h[n + i] != 0) counts[3] += 1;
+  }
+  free(h);
+  HIPCHK(k, e);
   return HSK_OK;
 }
 extern "C" int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]) {

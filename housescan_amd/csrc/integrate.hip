@@ -23,6 +23,9 @@
 #define HSK_TILE 16
 #define HSK_NQUEUES 256       // uncertain lane-blocks are spread over this many queues (pass A -> pass B)
 #define HSK_QCOUNT_STRIDE 64  // words between two queue counters (256 B: one counter per memory-side atomic line)
+#define HSK_CF_MIXED 0u  // verdicts of the coarse level (one byte per wave-chunk and frame: "the coarse level" below)
+#define HSK_CF_SKIP 1u
+#define HSK_CF_FREE 2u
 #ifndef INTEGRATE_WPE
 #define INTEGRATE_WPE 8  // waves per SIMD the register allocator must leave room for (pass A takes 48 VGPRs: 8 waves fit either
                          // way; told so, the compiler schedules it a little tighter: 69.9 -> 69.5 us at 512^3, 332 -> 327 at 1024^3)
@@ -115,6 +118,27 @@ __global__ void k_tile_window(const float2* __restrict__ tab, int tbw, int tbh, 
   win[(size_t)blockIdx.y * tbw * tbh + t] = make_float2(mx, mn);
 }
 
+// The coarse level (k_column_zrange) asks for the (max, min) of the depth over the 16-px tiles a wave-chunk's pixel box
+// touches -- up to 16 x 16 of them for a chunk next to the camera.  A sparse table answers any such range with FOUR
+// look-ups: level (kx, ky), kx, ky in 0 .. 3, holds for every tile the (max, min) over the 2^kx x 2^ky tiles from it on
+// (clipped to the table), and a range of nx x ny tiles is the union of the four blocks of the largest powers of two not
+// above nx, ny that sit in its corners.  Walked tile by tile the look-up was a chain of up to 144 dependent round trips in a
+// kernel of one wave per SIMD: 12 us of the frame's critical path.
+#define HSK_SPARSE_LEVELS 4
+__global__ void k_tile_sparse(const float* __restrict__ tmax, const float* __restrict__ tmin, int tw, int th, float2* __restrict__ sp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tw * th) return;
+  const int kx = (int)blockIdx.y % HSK_SPARSE_LEVELS, ky = (int)blockIdx.y / HSK_SPARSE_LEVELS;
+  const int ty = t / tw, tx = t - ty * tw;
+  float mx = 0.0f, mn = 1e30f;
+  for (int a = ty; a < min(ty + (1 << ky), th); ++a)
+    for (int b = tx; b < min(tx + (1 << kx), tw); ++b) {
+      mx = fmaxf(mx, tmax[a * tw + b]);
+      mn = fminf(mn, tmin[a * tw + b]);
+    }
+  sp[(size_t)blockIdx.y * tw * th + t] = make_float2(mx, mn);
+}
+
 // clip [lo,hi] (in gz) with c + m*gz >= 0
 static __device__ __forceinline__ void clip_interval(float c, float m, float& lo, float& hi) {
   if (m > 0.0f) {
@@ -127,6 +151,15 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
   }
 }
 
+// what the coarse level needs (integrate.hip: "the coarse level"): the verdict bytes of the frame (one per wave-chunk), the
+// chunks' pending bytes (null: a count-only launch, which bumps nothing) and the thresholds of the box test
+struct CoarseArgs {
+  unsigned char* cflag;
+  unsigned char* cs;
+  const float2* sparse;  // k_tile_sparse's table of the frame's 16-px tiles
+  int zchunk;  // planes per chunk of THIS launch (vp.zchunk, or all stored planes of a thinner slab)
+  float free_thr, cull_thr;
+};
 // Per-frame pre-pass: for every lane column (4 x-adjacent voxels at one y) the range of stored planes that can
 // project into the padded image [-1.5, W+0.5] x [-1.5, H+0.5] in front of the camera.  The view frustum is
 // convex, so each column meets it in one interval; clipping the line cam(gz) = a + gz * c against the five
@@ -136,7 +169,8 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, const float* __restrict__ tmin,
                                 float2* __restrict__ dtab, int tw, int th, int dil_blocks, unsigned* __restrict__ qcount,
                                 const TrackState* __restrict__ st, VolParams vp, int W, int H, Intr in,
-                                int2* __restrict__ zint, TrackState* __restrict__ st_out, int2* __restrict__ wgz, RingOut early) {
+                                int2* __restrict__ zint, TrackState* __restrict__ st_out, int2* __restrict__ wgz, RingOut early,
+                                CoarseArgs ca) {
   // fin.slots != null: the frame's ICP has left its last solve to this launch (launch_icp_fused).  The first wave of
   // EVERY block reads the sharded sums of the last iteration and solves (deterministic: all blocks get the same pose),
   // the block then works with that pose; block 0 also publishes it -- what k_icp_final does in a launch of its own.
@@ -203,11 +237,13 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
   // that workgroup's z range: pass A's workgroups of the chunks outside it (half of its waves lie outside the frustum)
   // then leave on one scalar load instead of a vector load per lane and a wave-wide reduction.
   __shared__ int wg_lo[4], wg_hi[4];
+  __shared__ int4 wv_sh[4];
   const int ncol = vp.X / 4;
   const int gxn = (vp.X + 63) / 64, gyn = (vp.Y + 15) / 16;
   const bool fp_block = (int)blockIdx.x < gxn * gyn;
   const int fby = (int)blockIdx.x / gxn, fbx = (int)blockIdx.x - fby * gxn;
-  const int y = fby * 16 + (int)(threadIdx.x >> 4), lc = fbx * 16 + (int)(threadIdx.x & 15);
+  // (a wave = the footprint of a pass-A wave: 4 lane columns by 16 rows)
+  const int y = fby * 16 + (int)((threadIdx.x & 63) >> 2), lc = fbx * 16 + (int)(threadIdx.x >> 6) * 4 + (int)(threadIdx.x & 3);
   const bool col_ok = fp_block && y < vp.Y && lc < ncol;
   const int x0 = lc * 4;
   int zl = 0x7fffffff, zh = -0x7fffffff;
@@ -265,12 +301,102 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
     if ((threadIdx.x & 63) == 0) {
       wg_lo[threadIdx.x >> 6] = lo;
       wg_hi[threadIdx.x >> 6] = hi;
-      // this wave's footprint (16 lane columns x 4 rows): union of its columns' ranges, then their intersection
+      // this wave's footprint (4 lane columns x 16 rows): union of its columns' ranges, then their intersection
       ((int4*)(wgz + (((size_t)gxn * gyn + 1) & ~(size_t)1)))[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = make_int4(lo, hi, lo_all, hi_all);
+      wv_sh[threadIdx.x >> 6] = make_int4(lo, hi, lo_all, hi_all);
     }
     __syncthreads();
     if (threadIdx.x == 0)
       wgz[blockIdx.x] = make_int2(min(min(wg_lo[0], wg_lo[1]), min(wg_lo[2], wg_lo[3])), max(max(wg_hi[0], wg_hi[1]), max(wg_hi[2], wg_hi[3])));
+    // ---- the coarse level: one verdict per wave-chunk of this footprint (4 waves x the launch's chunks of planes).  The
+    // chunk's voxel centres fill a box; a box in front of the camera projects into the pixel box of its 8 corners (+-1 px
+    // for the rounding to a pixel), and its distances to the camera centre lie between the box's nearest and farthest
+    // point.  Against the 16-px tile table (raw: a tile with a pixel outside the image or without depth has minimum 0):
+    //   free   every voxel has a pixel inside the image, with depth, and sdf >= tau: the rule writes F = 1 into all of them
+    //   dead   no voxel can pass sdf >= -tau (or has a pixel with depth): the rule writes nothing
+    // Both are SUFFICIENT conditions of the exact per-voxel rule with the margins of pass A's second level -- a verdict only
+    // ever replaces work whose outcome it has proven.
+    if (ca.cflag != nullptr) {
+      const bool own = fin.slots != nullptr && !fin_pose.lost;
+      const bool lost = fin.slots != nullptr ? fin_pose.lost != 0 : st->lost != 0;
+      const float* __restrict__ Rm = own ? fin_pose.R : st->R;
+      const float* __restrict__ tm = own ? fin_pose.t : st->t;
+      const int zchunks = (vp.nzs + ca.zchunk - 1) / ca.zchunk;
+      const int tw16 = tw;
+      for (int item = threadIdx.x; item < 4 * zchunks; item += blockDim.x) {
+        const int w = item & 3, zc = item >> 2;
+        const int4 r = wv_sh[w];
+        const int zbeg = zc * ca.zchunk, zend = min(zbeg + ca.zchunk, vp.nzs);
+        unsigned verdict = HSK_CF_MIXED;
+        if ((zbeg > r.y) | (zend - 1 < r.x)) {
+          verdict = HSK_CF_SKIP;  // outside the padded frustum
+        } else {
+          const int xa = fbx * 64 + w * 16, ya = fby * 16;
+          const int xb = min(xa + 15, vp.X - 1), yb = min(ya + 15, vp.Y - 1);
+          const bool full = (xa + 15 < vp.X) & (ya + 15 < vp.Y) & (zbeg + vp.zchunk <= vp.nzs) & (ca.zchunk == vp.zchunk);
+          const float g0[3] = {((float)xa + 0.5f) * vp.cell[0] - tm[0], ((float)ya + 0.5f) * vp.cell[1] - tm[1],
+                               ((float)(vp.zs0 + zbeg) + 0.5f) * vp.cell[2] - tm[2]};
+          const float g1[3] = {((float)xb + 0.5f) * vp.cell[0] - tm[0], ((float)yb + 0.5f) * vp.cell[1] - tm[1],
+                               ((float)(vp.zs0 + zend - 1) + 0.5f) * vp.cell[2] - tm[2]};
+          float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f, zmn = 1e30f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float gx = (c & 1) ? g1[0] : g0[0], gy = (c & 2) ? g1[1] : g0[1], gz = (c & 4) ? g1[2] : g0[2];
+            const float cxm = (Rm[0] * gx + Rm[3] * gy) + Rm[6] * gz, cym = (Rm[1] * gx + Rm[4] * gy) + Rm[7] * gz;
+            const float czm = (Rm[2] * gx + Rm[5] * gy) + Rm[8] * gz;
+            const float rq = __builtin_amdgcn_rcpf(czm);
+            const float uq = (cxm * in.fx) * rq + in.cx, vq = (cym * in.fy) * rq + in.cy;
+            zmn = fminf(zmn, czm);
+            umin = fminf(umin, uq);
+            umax = fmaxf(umax, uq);
+            vmin = fminf(vmin, vq);
+            vmax = fmaxf(vmax, vq);
+          }
+          if (zmn > 0.05f) {
+            umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
+            float d_hi2 = 0.0f, d_lo2 = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const float p0 = g0[a] * g0[a], p1 = g1[a] * g1[a];
+              d_hi2 += fmaxf(p0, p1);
+              d_lo2 += (g0[a] <= 0.0f && g1[a] >= 0.0f) ? 0.0f : fminf(p0, p1);
+            }
+            const float d_hi = __builtin_amdgcn_sqrtf(d_hi2), d_lo = __builtin_amdgcn_sqrtf(d_lo2);
+            const bool in_img = (umin >= 0.0f) & (vmin >= 0.0f) & (umax <= (float)(W - 1)) & (vmax <= (float)(H - 1));
+            const bool off_img = (umax < 0.0f) | (vmax < 0.0f) | (umin > (float)(W - 1)) | (vmin > (float)(H - 1));
+            if (off_img) {
+              verdict = HSK_CF_SKIP;  // no voxel has a pixel
+            } else {
+              // (the box clamped to the image: a voxel whose pixel lies outside is not rewritten whatever the depth there)
+              const int tu0 = (int)fminf(fmaxf(umin, 0.0f), (float)(W - 1)) >> 4, tu1 = (int)fminf(fmaxf(umax, 0.0f), (float)(W - 1)) >> 4;
+              const int tv0 = (int)fminf(fmaxf(vmin, 0.0f), (float)(H - 1)) >> 4, tv1 = (int)fminf(fmaxf(vmax, 0.0f), (float)(H - 1)) >> 4;
+              const int nx = tu1 - tu0 + 1, ny = tv1 - tv0 + 1;
+              if ((nx <= (2 << (HSK_SPARSE_LEVELS - 1))) & (ny <= (2 << (HSK_SPARSE_LEVELS - 1)))) {
+                // (k_tile_sparse: the blocks of 2^kx x 2^ky tiles in the range's four corners cover it)
+                const int kx = min(31 - __clz(nx), HSK_SPARSE_LEVELS - 1), ky = min(31 - __clz(ny), HSK_SPARSE_LEVELS - 1);
+                const float2* __restrict__ lv = ca.sparse + (size_t)(ky * HSK_SPARSE_LEVELS + kx) * tw16 * th;
+                const int ub = tu1 - (1 << kx) + 1, vb = tv1 - (1 << ky) + 1;
+                const float2 q00 = lv[tv0 * tw16 + tu0], q01 = lv[tv0 * tw16 + ub], q10 = lv[vb * tw16 + tu0], q11 = lv[vb * tw16 + ub];
+                const float Dx = fmaxf(fmaxf(q00.x, q01.x), fmaxf(q10.x, q11.x)), Dn = fminf(fminf(q00.y, q01.y), fminf(q10.y, q11.y));
+                const bool dead = d_lo * 0.99999f - Dx > ca.cull_thr;
+                const bool in_all = (r.z <= zbeg) & (r.w >= zend - 1);
+                const bool fre = full & in_img & in_all & (d_hi * 1.00001f + ca.free_thr <= Dn);
+                verdict = dead ? HSK_CF_SKIP : (fre ? HSK_CF_FREE : HSK_CF_MIXED);
+              }
+            }
+          }
+        }
+        const size_t ci = (((size_t)zc * gyn + fby) * gxn + fbx) * 4 + w;
+        if (verdict == HSK_CF_FREE && ca.cs != nullptr && !lost) {
+          const unsigned c = ca.cs[ci];
+          if (c >= 1u && c < 255u) {  // one more pending observation of the whole chunk: the frame's work on it is done
+            ca.cs[ci] = (unsigned char)(c + 1u);
+            verdict = HSK_CF_SKIP;
+          }
+        }
+        ca.cflag[ci] = (unsigned char)verdict;
+      }
+    }
   }
 }
 
@@ -335,20 +461,48 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
 // What the calls return is bit for bit what it was without the summaries; they are a representation of the weights of
 // deep free space, kept by: pass A, hsk_reset (all 1), hsk_upload_tsdf (k_rebuild_uniform).
 // Layout: the groups of a pass-A chunk (vp.zchunk planes: 2 or 4 groups) sit side by side, so a pass-A lane fetches
-// (and rewrites) all of its summaries with ONE 16- or 32-bit access, and the bytes of a wave (16 lanes in x by 4 rows by
-// the chunk's groups) are contiguous.
+// (and rewrites) all of its summaries with ONE 16- or 32-bit access, and the bytes of a wave -- round 5: 4 lanes in x by 16
+// rows by the chunk's groups, a footprint of 16 x 16 voxels (94 mm square at 512^3) where it was 64 x 4 (375 x 23 mm): a
+// compact wave-chunk is far more often all free space or all occluded -- are contiguous.
+//
+// ---- the coarse level (round 5): one byte per WAVE-CHUNK (16 x 16 voxels x vp.zchunk planes: what one pass-A wave owns) ----
+// behind the lane-block bytes, index = lane-block byte index / (64 NS):
+//   0          nothing deferred; the chunk's lane-block bytes are current, and nothing is known about them
+//   1 + k      k free-space observations of the WHOLE chunk are pending on top of its lane-block bytes, k in 0 .. 254, and
+//              every lane-block byte of the chunk is "quiet": 2 .. 255 (all 16 voxels hold +1 with weight >= 1), so that
+//              one more free-space observation of the whole chunk is one more count here and nothing else.
+// k_column_zrange classifies every wave-chunk of the frame ONCE, conservatively, by its box (coarse_classify): all free space
+// in front of the surface (-> the byte is bumped there and then, when it is 1 .. 254), all occluded or outside the frustum
+// (-> nothing to do), or mixed.  Pass A's waves read that verdict with a scalar load and leave at once unless it is
+// "mixed" (or free with a byte that cannot take the bump): the classification of lane-blocks is O(surface + rim), not
+// O(volume).  A wave that does work its chunk first pushes the pending count down into its lanes' bytes
+// (hsk_sum_push), and at its end marks the chunk quiet (1) or not (0).  Readers: k_summaries<true> (flush), which pushes
+// down as well; hsk_reset (0: the blocks are in state 1, not quiet); hsk_upload_tsdf (k_summaries<false> rebuilds both levels).
 #define HSK_SUM_RAGGED 130u
 #define HSK_SUM_MAX 255u
 // (NS = groups, i.e. summary bytes, per lane and chunk: 2 or 4 -- vp.zchunk / 4; a power of two, so shifts and masks)
+static __host__ __device__ __forceinline__ size_t hsk_chunk_count(const VolParams& vp) {  // wave-chunks (4 per workgroup-chunk)
+  return (size_t)((vp.nzs + vp.zchunk - 1) / vp.zchunk) * ((vp.Y + 15) / 16) * ((vp.X + 63) / 64) * 4;
+}
+static __host__ __device__ __forceinline__ size_t hsk_lane_sum_bytes(const VolParams& vp) {  // lane-block bytes; the chunk bytes follow
+  return hsk_chunk_count(vp) * (size_t)(64 * (vp.zchunk >> 2));
+}
 template <int NS>
 static __host__ __device__ __forceinline__ size_t hsk_sum_index_ns(const VolParams& vp, int x0, int y, int zb) {
   static_assert(NS == 2 || NS == 4, "8 or 16 planes per chunk");
-  const size_t tiles_x = (size_t)(vp.X + 63) / 64, tiles_y = (size_t)(vp.Y + 3) / 4;
-  return (((((size_t)(zb >> (NS == 4 ? 4 : 3)) * tiles_y + (size_t)(y >> 2)) * tiles_x + (size_t)(x0 >> 6)) * 4 + (size_t)(y & 3)) * 16 +
-          (size_t)((x0 >> 2) & 15)) * (size_t)NS + (size_t)((zb >> 2) & (NS - 1));
+  const size_t tiles_x = (size_t)(vp.X + 63) / 64, tiles_y = (size_t)(vp.Y + 15) / 16;
+  const size_t wg = ((size_t)(zb >> (NS == 4 ? 4 : 3)) * tiles_y + (size_t)(y >> 4)) * tiles_x + (size_t)(x0 >> 6);
+  const size_t wave = (size_t)((x0 >> 4) & 3), lane = (size_t)(((y & 15) << 2) | ((x0 >> 2) & 3));
+  return ((wg * 4 + wave) * 64 + lane) * (size_t)NS + (size_t)((zb >> 2) & (NS - 1));
 }
 static __host__ __device__ __forceinline__ size_t hsk_sum_index(const VolParams& vp, int x0, int y, int zb) {
   return vp.zchunk == 16 ? hsk_sum_index_ns<4>(vp, x0, y, zb) : hsk_sum_index_ns<2>(vp, x0, y, zb);
+}
+// k pending free-space observations of a quiet block (byte s >= 2) pushed into its byte: a uniform block's weight
+// saturates at 128 (s = 129); a rim block's pending count simply grows -- and may leave the byte's range, which the callers
+// treat as "the words must be rewritten now" (>= HSK_SUM_MAX where a further observation is due, > HSK_SUM_MAX otherwise)
+static __host__ __device__ __forceinline__ unsigned hsk_sum_push(unsigned s, unsigned k) {
+  return s < HSK_SUM_RAGGED ? (s + k < (unsigned)HSK_MAX_WEIGHT + 1u ? s + k : (unsigned)HSK_MAX_WEIGHT + 1u) : s + k;
 }
 // Where the 16-B vector of voxels x0 .. x0 + 3 (x0 a multiple of 4) of row y, stored plane zb + u (zb a multiple of 4,
 // u in 0 .. 3) sits in the volume, in vectors: the four vectors of a lane-block are consecutive (hsk_dev.h: hsk_vox_index).
@@ -582,24 +736,27 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
 }
 
 #ifdef HSK_PA_TIMING
-// timing build (tools/pa_timing.sh): per wave of pass A, s_memrealtime stamps (100 MHz) at the phase boundaries, the
-// hardware slot it ran in and what it had to do
-__device__ unsigned long long g_pa_times[65536 * 8];
+// timing build (tools/pa_timing.sh): per working wave of pass A (slot = its wave-chunk), s_memrealtime stamps (100 MHz) at
+// the phase boundaries; slot 7 = free | uncertain << 32 lane-blocks of the chunk
+#define HSK_PA_SLOTS 65536u
+__device__ unsigned long long g_pa_times[HSK_PA_SLOTS * 8];
 extern "C" int hsk_debug_pa_times(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pa_times), (size_t)n * 8);
 }
-#define PA_STAMP(k) do { if (!COUNT_ONLY && lane == 0 && pa_wave < 65536u) g_pa_times[pa_wave * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#elif defined(HSK_PA_MARKS)
-#define PA_STAMP(k) asm volatile("s_nop 0 ; PA_MARK_" #k ::: "memory")  // static instruction census (tools/pa_census.sh)
+extern "C" int hsk_debug_pa_clear() {
+  static unsigned long long zeros[HSK_PA_SLOTS * 8];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pa_times), zeros, sizeof(zeros));
+}
+#define PA_STAMP(k) do { if (!COUNT_ONLY && lane == 0 && pa_slot < HSK_PA_SLOTS) g_pa_times[pa_slot * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
-#define PA_STAMP(k) do { } while (0)
+#define PA_STAMP(k) do { } while (0)  // (phase boundaries of pass A)
 #endif
 // (below, lane predicates are joined by & and |, without short-circuit evaluation: `a && b` on lane-varying conditions is
 // compiled into a lane-mask branch round b -- s_and_saveexec / s_cbranch_execz, scalar instructions, which pass A is short of)
 // Pass A of integrate (COUNT_ONLY: the same decisions without touching the volume -- V_upd for the roofline).
 template <bool COUNT_ONLY, int NS>
-__global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const int2* __restrict__ wgz,
-                                                   const int2* __restrict__ zint, int zchunk, unsigned gxa, unsigned gmagic,
+__global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) void k_integrate(const TrackState* __restrict__ st, const unsigned* __restrict__ cflag4,
+                                                   const int4* __restrict__ wvz, int zchunk, unsigned gxa, unsigned gmagic,
                                                    double* __restrict__ icp_slot0, unsigned char* __restrict__ uni,
                                                    const float2* __restrict__ dtab, int W, int H, int tw, int th, unsigned gya,
                                                    uint4* __restrict__ vol, const float* __restrict__ scaled, VolParams vp,
@@ -607,11 +764,16 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
                                                    unsigned* __restrict__ flags,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
-                                                   const float2* __restrict__ qtab, IntegrateConst k) {
-  // Half of the launch's workgroups lie outside the view frustum, and what they execute before they find that out is a
-  // tenth of the kernel's scalar instructions: the test comes FIRST and runs on what arrives with the wave -- the
-  // arguments preloaded into SGPRs (the x-block count and its reciprocal for the rotation: `% gridDim.x` was a hidden-
-  // argument load and twenty instructions of division) and ONE scalar load, the footprint's z range.
+                                                   const float2* __restrict__ qtab, IntegrateConst k, const int2* __restrict__ zint) {
+  // Most of the launch's waves have nothing to do -- their wave-chunk lies outside the view frustum, is wholly occluded, or
+  // is wholly free space already recorded in its chunk byte -- and what they execute before they find that out is pure
+  // overhead: the test comes FIRST and runs on what arrives with the wave -- the arguments preloaded into SGPRs (the
+  // x-block count and its reciprocal for the rotation: `% gridDim.x` was a hidden-argument load and twenty instructions of
+  // division) and ONE scalar load, the coarse level's verdicts of the workgroup's four wave-chunks (k_column_zrange).
+  // (Round 5 also built the launch as a persistent one over compacted work lists of the chunks that do need work, with
+  // static and with ticketed distribution: 23.6 / 31 us against 21.8 -- the loop keeps every argument live (52 scalar
+  // registers spilled into vector lanes), every wave starts behind two more dependent round trips, and the dispatcher
+  // balances better than either scheme: profiles/r05/integrate_notes.md.)
   const unsigned gdx = gxa, gdy = gya;  // the launch's grid (x blocks per row, rows of blocks)
   const unsigned bsum = blockIdx.x + blockIdx.y + blockIdx.z;
   // bsum % gdx: exact for bsum < 2^16 with gmagic = 2^32 / gdx + 1; a single x block (gmagic = 0: the reciprocal does not fit) is 0
@@ -625,19 +787,21 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       for (int i = threadIdx.y * 64 + threadIdx.x; i < ICP_SLOT_DOUBLES; i += 256)
         __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  {
-    // (zend = min(zbeg + zchunk, nzs) is not needed here: the footprint's range ends below nzs)
-    const unsigned long long w2 = *(const unsigned long long*)(wgz + (byr * gdx + bxr));  // (x = low word, y = high word)
-    const int wz_x = (int)(unsigned)w2, wz_y = (int)(unsigned)(w2 >> 32);
-    if ((zbeg > wz_y) | (zbeg + zchunk - 1 < wz_x)) return;
-  }
+  const unsigned lin = (blockIdx.z * gdy + byr) * gdx + bxr;
+  const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);  // the wave's quarter of the footprint
+  const unsigned verdict = (cflag4[lin] >> (8u * wq)) & 0xffu;
+  if (verdict == HSK_CF_SKIP) return;
   const int lane = threadIdx.x;
+  unsigned long long cnt = 0;
+  if (COUNT_ONLY && verdict == HSK_CF_FREE) {  // every voxel of the chunk is rewritten (F = 1)
+    if (lane == 0) atomicAdd(counter, (unsigned long long)(64 * NS * 16));
+    return;
+  }
   if (!COUNT_ONLY && st->lost) return;
 #ifdef HSK_PA_TIMING
-  const unsigned pa_wave = (((blockIdx.z * gdy + blockIdx.y) * gdx + blockIdx.x) * 4u + threadIdx.y);
-  if (!COUNT_ONLY && lane == 0 && pa_wave < 65536u) {
-    for (int q = 0; q < 8; ++q) g_pa_times[pa_wave * 8 + q] = 0ull;
-    g_pa_times[pa_wave * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  const unsigned pa_slot = lin * 4u + wq;
+  if (!COUNT_ONLY && lane == 0 && pa_slot < HSK_PA_SLOTS) {
+    for (int q = 0; q < 8; ++q) g_pa_times[pa_slot * 8 + q] = 0ull;
   }
 #endif
   PA_STAMP(0);
@@ -647,16 +811,14 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
   // turn, and a volume of 512 voxels has exactly eight blocks per row: unrotated, every workgroup of x block b ran on XCD b,
   // and the frustum covers the middle blocks of a row far more than the outer ones -- the XCDs' loads differed by as much
   // (profiles/r02/raycast_split_experiment.md met the same aliasing).
-  const int x0 = (int)(bxr * 16u + (unsigned)(lane & 15)) * 4;
-  const int y = (int)(byr * 4u + threadIdx.y) * 4 + (lane >> 4);
+  const int x0 = (int)(bxr * 16u + wq * 4u + (unsigned)(lane & 3)) * 4;
+  const int y = (int)(byr * 16u) + (lane >> 2);
   const bool active = (x0 < vp.X) & (y < vp.Y);
-  unsigned long long cnt = 0;
   const int zend = min(zbeg + zchunk, vp.nzs);
   // ... and of this wave's own footprint (16 lane columns x 4 rows): the wave-uniform loop bounds, without a wave-wide
   // reduction of the lanes' ranges (min over lanes of max(zl, zbeg) = max(min zl, zbeg)); a wave with nothing to do
   // leaves here, its lanes' ranges never loaded
-  const int4 wv = ((const int4*)(wgz + (((size_t)gdx * gdy + 1) & ~(size_t)1)))[(size_t)(byr * gdx + bxr) * 4 +
-                                                                                          (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y)];
+  const int4 wv = wvz[(size_t)(byr * gdx + bxr) * 4 + wq];
   const int wl = max(wv.x, zbeg), wh = min(wv.y, zend - 1);
   int zl = 0x7fffffff, zh = -0x7fffffff;  // this lane's stored-plane range inside the padded frustum
   if (wv.z <= zbeg && wv.w >= zend - 1) {
@@ -699,14 +861,16 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     // groups the chain is four trips long instead of eight, and pass A is bound by exactly that (its 65 k waves pass
     // through 6 resident slots per SIMD in about eleven rounds).
     static_assert(NS == 2 || NS == 4, "pass A stages the chunk's groups of 4 planes together; a lane's summaries of a chunk are one 16- or 32-bit word");
-    const int zb0 = wl & ~3;
+    // (slot sidx IS group sidx of the chunk -- round 5: the pending count of the coarse level is pushed into every group's
+    // byte, whether the wave's z range reaches the group or not)
+    const int zb0 = zbeg;
     int zbs[NS];
     bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS];
     float dc_s[NS];
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       zbs[sidx] = zb0 + 4 * sidx;
-      actv[sidx] = zbs[sidx] <= wh;  // wave-uniform
+      actv[sidx] = (zbs[sidx] + 3 >= wl) & (zbs[sidx] <= wh);  // wave-uniform
       free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
       dc_s[sidx] = 0.0f;
     }
@@ -732,13 +896,14 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
     }
     unsigned sum16 = 0u;  // all summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
-    unsigned char* const sum_at = uni + hsk_sum_index_ns<NS>(vp, x0, y, zbeg);
-    {
-      bool any_actv = false;
-#pragma unroll
-      for (int sidx = 0; sidx < NS; ++sidx) any_actv = any_actv || actv[sidx];
-      if (!COUNT_ONLY && uni != nullptr && active && any_actv) sum16 = NS == 2 ? (unsigned)*(const unsigned short*)sum_at : *(const unsigned*)sum_at;
+    unsigned char* const sum_at = uni + ((size_t)(lin * 4u + wq) * 64u + (unsigned)lane) * (unsigned)NS;  // (hsk_sum_index_ns<NS>(vp, x0, y, zbeg))
+    // ... and the chunk's byte of the coarse level (its workgroup's four as one scalar word): 1 + k = k observations pending
+    unsigned cbyte = 0u;
+    if (!COUNT_ONLY && uni != nullptr) {
+      if (active) sum16 = NS == 2 ? (unsigned)*(const unsigned short*)sum_at : *(const unsigned*)sum_at;
+      cbyte = (((const unsigned*)(uni + hsk_lane_sum_bytes(vp)))[lin] >> (8u * wq)) & 0xffu;
     }
+    const unsigned kpend = cbyte >= 2u ? cbyte - 1u : 0u;
     PA_STAMP(6);
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
@@ -748,10 +913,15 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       free44_s[sidx] = free44;
       other_s[sidx] = in_any_s[sidx] & !dead4 & !free44;
     }
+    // the lane's summaries with the chunk's pending observations pushed into them (kpend > 0 only over quiet bytes); a rim
+    // block's count may leave the byte's range: its words are rewritten below
     unsigned sum8[NS];
+    unsigned new16 = 0u;
 #pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) sum8[sidx] = actv[sidx] ? (sum16 >> (8 * ((zbs[sidx] - zbeg) >> 2))) & 0xffu : 0u;
-    unsigned new16 = sum16;
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      sum8[sidx] = hsk_sum_push((sum16 >> (8 * sidx)) & 0xffu, kpend);
+      new16 |= min(sum8[sidx], HSK_SUM_MAX) << (8 * sidx);  // (an out-of-range count is replaced by the block's new state below)
+    }
     PA_STAMP(2);
     // ---- stage 2: second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
     //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
@@ -816,10 +986,14 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     }
     PA_STAMP(3);
 #ifdef HSK_PA_TIMING
-    if (!COUNT_ONLY && pa_wave < 65536u) {
-      const unsigned nf = (unsigned)__popcll(__ballot(free44_s[0] && actv[0])) + (unsigned)__popcll(__ballot(free44_s[1] && actv[1]));
-      const unsigned no = (unsigned)__popcll(__ballot(other_s[0] && actv[0])) + (unsigned)__popcll(__ballot(other_s[1] && actv[1]));
-      if (lane == 0) g_pa_times[pa_wave * 8 + 7] = nf | ((unsigned long long)no << 32);
+    if (!COUNT_ONLY && pa_slot < HSK_PA_SLOTS) {
+      unsigned nf = 0, no = 0;
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        nf += (unsigned)__popcll(__ballot(free44_s[sidx] && actv[sidx]));
+        no += (unsigned)__popcll(__ballot(other_s[sidx] && actv[sidx]));
+      }
+      if (lane == 0) g_pa_times[pa_slot * 8 + 7] = nf | ((unsigned long long)no << 32);
     }
 #endif
     // ---- stage 4: wave-aggregated append of the uncertain lane-blocks: one of HSK_NQUEUES queues (a single counter
@@ -829,8 +1003,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     // per row and wave index (the capacity bound).  Both groups' tickets are requested before either is used.
     // (the tickets are REQUESTED here, before the free-space loads, and used after the stores: the counters' round trip
     // runs under the volume's -- one dependent round trip less in a wave's life)
-    const unsigned lin = (blockIdx.z * gdy + byr) * gdx + bxr;
-    const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + threadIdx.y * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
+    const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + wq * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
     // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_window)
     unsigned long long bo[NS];
     unsigned n_other = 0u, base_all = 0u;
@@ -865,7 +1038,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       for (int sidx = 0; sidx < NS; ++sidx) {
         const bool fr = actv[sidx] & free44_s[sidx], ot = actv[sidx] & other_s[sidx];
         const unsigned sm = sum8[sidx];
-        const int sbit = 8 * ((zbs[sidx] - zbeg) >> 2);  // where the group's summary sits in new16
+        const int sbit = 8 * sidx;  // where the group's summary sits in new16
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
         if (fr && sm == 1u) wstore = 1u;
         if (ot && sm >= 2u && sm < HSK_SUM_RAGGED) wstore = sm - 1u;
@@ -878,12 +1051,13 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
         // the byte: +1 for a free block in states 1 .. 128 (w + 1 <= 128) and 130 .. 254 (one more pending); 129 stays;
         // 0 for a block on its way to pass B (the word is stored once, after the read path below)
         {
-          const bool tick = fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm != HSK_SUM_MAX;
+          const bool tick = fr && sm != 0u && sm != (unsigned)HSK_MAX_WEIGHT + 1u && sm < HSK_SUM_MAX;
           if (tick || (ot && sm != 0u)) new16 = (new16 & ~(0xffu << sbit)) | ((tick ? sm + 1u : 0u) << sbit);
         }
         // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
-        //     pending observations on its way to pass B
-        rd[sidx] = (fr && (sm == 0u || sm == HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED);
+        //     pending observations on its way to pass B; a rim block the frame does not touch whose count, with the chunk's
+        //     pushed into it, no longer fits the byte
+        rd[sidx] = (fr && (sm == 0u || sm >= HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED) || sm > HSK_SUM_MAX;
       }
       // (one group at a time: this path is the exception now, and four vectors live instead of eight keep the kernel at
       // seven waves per SIMD)
@@ -915,8 +1089,8 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
               store_vec(VIDX(zbs[sidx], u), q4[u]);
             }
           }
-          if (fr) {
-            const int sbit = 8 * ((zbs[sidx] - zbeg) >> 2);
+          if (!(actv[sidx] && other_s[sidx])) {  // (a block on its way to pass B has lost its summary above)
+            const int sbit = 8 * sidx;
             new16 = (new16 & ~(0xffu << sbit)) | (hsk_sum_classify(q4) << sbit);
           }
         }
@@ -926,6 +1100,16 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
           *(unsigned short*)sum_at = (unsigned short)new16;
         else
           *(unsigned*)sum_at = new16;
+      }
+      // the chunk's byte: nothing pending any more; quiet (1) when the chunk is whole and every one of its blocks now holds
+      // +1 throughout with a weight (bytes 2 .. 255), so that a free-space observation of all of it is one count -- else 0
+      if (uni != nullptr) {
+        bool quiet = active;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) quiet = quiet & (((new16 >> (8 * sidx)) & 0xffu) >= 2u);
+        const bool whole = (zbeg + vp.zchunk <= vp.nzs) & (zchunk == vp.zchunk);
+        const unsigned cnew = (whole && __ballot(quiet) == ~0ull) ? 1u : 0u;
+        if (cnew != cbyte && lane == 0) (uni + hsk_lane_sum_bytes(vp))[lin * 4u + wq] = (unsigned char)cnew;
       }
     }
 #ifdef HSK_PA_TIMING
@@ -1081,14 +1265,30 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
   float2* fwin = qtab + (size_t)4 * fw * fh;
   hipLaunchKernelGGL(k_tile_window, dim3((fw * fh + 255) / 256, 9), dim3(256), 0, s, ftab, fw, fh, fwin);
   hipLaunchKernelGGL(k_tile_window, dim3((4 * fw * fh + 255) / 256, 9), dim3(256), 0, s, qtab, 2 * fw, 2 * fh, fwin + (size_t)9 * fw * fh);
+  // ... and behind those the sparse table of the 16-px tiles (the coarse level's range look-up)
+  float2* sparse = fwin + (size_t)45 * fw * fh;
+  hipLaunchKernelGGL(k_tile_sparse, dim3((tw * th + 255) / 256, HSK_SPARSE_LEVELS * HSK_SPARSE_LEVELS), dim3(256), 0, s, tiles, tiles + tw * th, tw, th, sparse);
+}
+// bytes of a frame's tile tables: 16-px raw (max, min) and dilated; 8-px and 4-px tables with nine window shapes each; the sparse table
+size_t tile_table_bytes(int W, int H) {
+  const size_t n16 = (size_t)((W + HSK_TILE - 1) / HSK_TILE) * ((H + HSK_TILE - 1) / HSK_TILE);
+  const size_t n8 = (size_t)((W + HSK_FTILE - 1) / HSK_FTILE) * ((H + HSK_FTILE - 1) / HSK_FTILE);
+  return n16 * 4 * sizeof(float) + n8 * 50 * sizeof(float2) + n16 * HSK_SPARSE_LEVELS * HSK_SPARSE_LEVELS * sizeof(float2);
 }
 
 // entries of the z-range tables: one int2 per lane column, then one per pass-A workgroup footprint (64 x 16 voxels), then
 // an int4 per wave footprint (64 x 4 voxels: four per workgroup)
 size_t integrate_zint_entries(const VolParams& vp) {
   const size_t fp = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16);
-  return (size_t)(vp.X / 4) * vp.Y + ((fp + 1) & ~(size_t)1) + 8 * fp;  // (the wave table is int4: kept 16-B aligned)
+  // (the wave table is int4: kept 16-B aligned; behind it the coarse level's verdict bytes, one per wave-chunk)
+  return (size_t)(vp.X / 4) * vp.Y + ((fp + 1) & ~(size_t)1) + 8 * fp + (hsk_chunk_count(vp) + 7) / 8;
 }
+// where the coarse level's verdict bytes of the last frame sit in launch_integrate's zint buffer, and how many there are
+size_t integrate_cflag_offset_bytes(const VolParams& vp) {
+  const size_t fp = (size_t)((vp.X + 63) / 64) * ((vp.Y + 15) / 16);
+  return ((size_t)(vp.X / 4) * vp.Y + ((fp + 1) & ~(size_t)1) + 8 * fp) * sizeof(int2);
+}
+size_t integrate_chunk_count(const VolParams& vp) { return hsk_chunk_count(vp); }
 size_t integrate_queue_counter_words() { return (size_t)HSK_NQUEUES * HSK_QCOUNT_STRIDE; }
 unsigned long long integrate_queue_entries(const unsigned* counter_words) {
   unsigned long long n = 0;
@@ -1120,39 +1320,43 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const IcpFinal none = {nullptr, nullptr, 0};
   const IcpFinal fin = (icp_final && !count_only) ? *icp_final : none;
   int2* wgz = zint + ncols;  // behind the column table: one entry per pass-A workgroup footprint (integrate_zint_entries)
+  const int4* wvz = (const int4*)(wgz + (((size_t)col_blocks + 1) & ~(size_t)1));  // ... one per wave footprint ...
+  unsigned char* cflag = (unsigned char*)(wvz + (size_t)col_blocks * 4);           // ... and the frame's verdict per wave-chunk
+  const IntegrateConst kc = integrate_const(vp, W, H, in);
+  const float2* sparse = (const float2*)(tmax + 4 * tw * th) + (size_t)50 * fw * fh;
+  const CoarseArgs ca = {cflag, (count_only || uni == nullptr) ? nullptr : uni + hsk_lane_sum_bytes(vp), sparse, zchunk, kc.free_thr2, kc.cull_thr2};
   const RingOut quiet_ring = {nullptr, nullptr, nullptr};
   const RingOut early_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, fin, tmax,
                      tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, dil_blocks, qcount, st, vp, W, H, in, zint,
-                     const_cast<TrackState*>(st), wgz, early_ring);
+                     const_cast<TrackState*>(st), wgz, early_ring, ca);
   dim3 block(64, 4, 1);
-  dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
+  const dim3 grid((vp.X + 63) / 64, (vp.Y + 15) / 16, zchunks);
   const float2* dil = (const float2*)(tmax + 2 * tw * th);
   // behind the counters: HSK_NQUEUES queues of qcap entries each; a block of pass A holds at most 4 waves x 64 lanes
   // x (zchunk / 4) blocks and every HSK_NQUEUES-th block shares a queue
   unsigned* qdata = queue + HSK_NQUEUES * HSK_QCOUNT_STRIDE;
   const unsigned nblk = grid.x * grid.y * (unsigned)zchunks;
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
-  const IntegrateConst kc = integrate_const(vp, W, H, in);
   // n % grid.x = n - mulhi(n, gmagic) * grid.x for n < 2^16; 0 for a single x block (the kernel takes 0 for the remainder)
   const unsigned gmagic = grid.x > 1u ? (unsigned)(0x100000000ull / grid.x) + 1u : 0u;
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     if (vp.zchunk == 16)
-      hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+      hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
     else
-      hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+      hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   } else {
     if (vp.zchunk == 16)
-      hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+      hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
     else
-      hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, wgz, zint, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc);
+      hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   }
@@ -1194,49 +1398,76 @@ void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, u
   hipLaunchKernelGGL(k_rebuild_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const short2*)vol, vp, flags);
 }
 
-// lane-block summaries of a volume that was uploaded rather than integrated (one thread per lane-block; a block that
-// reaches beyond the last stored plane has no summary), and the reverse: the volume's weights brought up to date
-size_t uniform_bytes(const VolParams& vp) {
-  return (size_t)((vp.nzs + vp.zchunk - 1) / vp.zchunk) * ((vp.Y + 3) / 4) * ((vp.X + 63) / 64) * (size_t)(64 * (vp.zchunk >> 2));
-}
-template <bool MATERIALIZE>
-__global__ void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
-  const int qx = vp.X / 4;
-  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * qx;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int xl = (int)(i % qx), y = (int)((i / qx) % vp.Y), zb = (int)(i / ((size_t)qx * vp.Y)) * 4;
-  const size_t ui = hsk_sum_index(vp, xl * 4, y, zb);
-  const int x0 = xl * 4;
+// Summaries of a volume that was uploaded rather than integrated (both levels), and the reverse: the volume's weights
+// brought up to date.  One WAVE per wave-chunk, lane = the pass-A lane that owns the blocks (a block that reaches beyond
+// the last stored plane has no summary): the chunk's byte is read by every lane before lane 0 rewrites it.
+size_t uniform_bytes(const VolParams& vp) { return hsk_lane_sum_bytes(vp) + ((hsk_chunk_count(vp) + 255) & ~(size_t)255); }
+size_t uniform_lane_bytes(const VolParams& vp) { return hsk_lane_sum_bytes(vp); }
+template <bool MATERIALIZE, int NS>
+__global__ __launch_bounds__(256) void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
+  const size_t cw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-chunk
+  if (cw >= hsk_chunk_count(vp)) return;
+  const int lane = threadIdx.x & 63, w = (int)(cw & 3);
+  const int tiles_x = (vp.X + 63) / 64, tiles_y = (vp.Y + 15) / 16;
+  const size_t wg = cw >> 2;
+  const int fbx = (int)(wg % tiles_x), fby = (int)((wg / tiles_x) % tiles_y), zc = (int)(wg / ((size_t)tiles_x * tiles_y));
+  const int x0 = (fbx * 16 + w * 4 + (lane & 3)) * 4, y = fby * 16 + (lane >> 2);
+  const bool active = x0 < vp.X && y < vp.Y;
+  unsigned char* const cs = uni + hsk_lane_sum_bytes(vp);
+  unsigned char* const sum_at = uni + (cw * 64 + (size_t)lane) * NS;
   if (!MATERIALIZE) {
-    unsigned code = 0u;
-    if (zb + 3 < vp.nzs) {
-      uint4 q[4];
-      for (int u = 0; u < 4; ++u) q[u] = vol[VIDX(zb, u)];
-      code = hsk_sum_classify(q);
+    bool quiet = active;
+#pragma unroll
+    for (int g = 0; g < NS; ++g) {
+      const int zb = zc * vp.zchunk + 4 * g;
+      unsigned code = 0u;
+      if (active && zb + 3 < vp.nzs) {
+        uint4 q[4];
+        for (int u = 0; u < 4; ++u) q[u] = vol[VIDX(zb, u)];
+        code = hsk_sum_classify(q);
+      }
+      sum_at[g] = (unsigned char)code;
+      quiet = quiet && code >= 2u;
     }
-    uni[ui] = (unsigned char)code;
+    const bool all_quiet = __ballot(quiet) == ~0ull;
+    if (lane == 0) cs[cw] = (zc * vp.zchunk + vp.zchunk <= vp.nzs && all_quiet) ? 1 : 0;
     return;
   }
-  const unsigned sm = uni[ui];
-  if (sm >= 2u && sm < HSK_SUM_RAGGED) {
-    const unsigned word = ((sm - 1u) << 16) | (unsigned)HSK_DIVISOR;
-    for (int u = 0; u < 4; ++u) vol[VIDX(zb, u)] = make_uint4(word, word, word, word);
-  } else if (sm > HSK_SUM_RAGGED) {
-    uint4 q[4];
-    for (int u = 0; u < 4; ++u) q[u] = vol[VIDX(zb, u)];
-    for (int u = 0; u < 4; ++u) {
-      hsk_vector_add_weight(q[u], sm - HSK_SUM_RAGGED);
-      vol[VIDX(zb, u)] = q[u];
+  const unsigned c = cs[cw];
+  const unsigned kpend = c >= 2u ? c - 1u : 0u;
+#pragma unroll
+  for (int g = 0; g < NS; ++g) {
+    const int zb = zc * vp.zchunk + 4 * g;
+    if (!active || zb >= vp.nzs) continue;
+    const unsigned s0 = sum_at[g], sm = hsk_sum_push(s0, kpend);
+    if (sm >= 2u && sm < HSK_SUM_RAGGED) {
+      const unsigned word = ((sm - 1u) << 16) | (unsigned)HSK_DIVISOR;
+      for (int u = 0; u < 4; ++u) vol[VIDX(zb, u)] = make_uint4(word, word, word, word);
+      if (sm != s0) sum_at[g] = (unsigned char)sm;
+    } else if (sm > HSK_SUM_RAGGED) {
+      uint4 q[4];
+      for (int u = 0; u < 4; ++u) q[u] = vol[VIDX(zb, u)];
+      for (int u = 0; u < 4; ++u) {
+        hsk_vector_add_weight(q[u], sm - HSK_SUM_RAGGED);
+        vol[VIDX(zb, u)] = q[u];
+      }
+      sum_at[g] = (unsigned char)hsk_sum_classify(q);
     }
-    uni[ui] = (unsigned char)hsk_sum_classify(q);
   }
+  // (the blocks stay quiet: a uniform block stays uniform, a rim block becomes 130 or 129)
+  if (kpend != 0u && lane == 0) cs[cw] = 1;
 }
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni) {
-  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
-  hipLaunchKernelGGL(k_summaries<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)const_cast<void*>(vol), vp, uni);
+  const unsigned nb = (unsigned)((hsk_chunk_count(vp) + 3) / 4);
+  if (vp.zchunk == 16)
+    hipLaunchKernelGGL((k_summaries<false, 4>), dim3(nb), dim3(256), 0, s, (uint4*)const_cast<void*>(vol), vp, uni);
+  else
+    hipLaunchKernelGGL((k_summaries<false, 2>), dim3(nb), dim3(256), 0, s, (uint4*)const_cast<void*>(vol), vp, uni);
 }
 void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned char* uni) {
-  const size_t n = (size_t)((vp.nzs + 3) / 4) * vp.Y * (vp.X / 4);
-  hipLaunchKernelGGL(k_summaries<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)vol, vp, uni);
+  const unsigned nb = (unsigned)((hsk_chunk_count(vp) + 3) / 4);
+  if (vp.zchunk == 16)
+    hipLaunchKernelGGL((k_summaries<true, 4>), dim3(nb), dim3(256), 0, s, (uint4*)vol, vp, uni);
+  else
+    hipLaunchKernelGGL((k_summaries<true, 2>), dim3(nb), dim3(256), 0, s, (uint4*)vol, vp, uni);
 }

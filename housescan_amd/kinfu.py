@@ -134,6 +134,13 @@ class KinfuTracker:
         self._ck(self.lib.hsk_count_updates(self.h, d.ctypes.data, d.shape[1], d.shape[0], _fp(p), C.byref(n)))
         return n.value
 
+    def integrate_coarse_counts(self):
+        """verdicts of the last integrate's coarse level over the wave-chunks: (mixed, settled as a whole, free but worked by
+        pass A, chunks currently quiet)"""
+        c = (C.c_uint64 * 4)()
+        self._ck(self.lib.hsk_integrate_coarse_counts(self.h, c))
+        return tuple(int(x) for x in c)
+
     def integrate_queue_entries(self):
         """lane-blocks the last integrate's classification pass handed to its per-voxel pass"""
         n = C.c_uint64()

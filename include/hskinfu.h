@@ -240,6 +240,11 @@ int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]);
 /* lane-blocks (4 x 1 x 4 voxels) the last integrate's classification pass could not settle and handed to its per-voxel
  * pass (a measure of the classification's slack: bench.py reports it beside V_upd); synchronises the context's stream */
 int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries);
+/* the coarse level of the last integrate (one verdict per wave-chunk of 16 x 16 voxels x the pass-A chunk of planes):
+ * counts[0] = chunks pass A had to classify lane-block by lane-block ("mixed"), [1] = chunks settled as a whole (outside the
+ * frustum, wholly occluded, or wholly free space with the observation recorded in the chunk's byte), [2] = wholly free
+ * chunks whose byte could not take it (pass A works them), [3] = chunks currently marked quiet; synchronises the stream */
+int hsk_integrate_coarse_counts(hsk_ctx* k, uint64_t counts[4]);
 int hsk_bilateral_tables(float ws[169], float wc[512]);
 /* Exhaustive self-test, on the GPU itself, of the exact-arithmetic shortcuts the kernels use for the specification's
  * correctly rounded 1/x, sqrt(x) and a/n (hardware approximation + one fused correction step; hsk_dev.h): every binary32
