@@ -874,60 +874,19 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
       dc_s[sidx] = 0.0f;
     }
-    // ---- stage 1: first level (16-px dilated tile table).  Both groups' look-ups are requested first, the lane's summaries
-    // behind them: loads return in the order they were issued, and requested ahead of the look-ups the summaries -- an
-    // 8 MiB table that misses where the 9.6 KB tile table hits -- made the first level wait for a byte that stage 3 uses.
-    float2 Dt_s[NS];
-    bool ok_s[NS], in_any_s[NS];
-#pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) {
-      const int zb = zbs[sidx];
-      in_any_s[sidx] = actv[sidx] & (zb + 3 >= zl) & (zb <= zh) & active;
-      in_all_s[sidx] = actv[sidx] & (zb >= zl) & (zb + 3 <= zh) & active;
-      const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - tz;  // centre of planes zb .. zb+3
-      const float czc = c.azc + i22 * gz;
-      const float rc = __builtin_amdgcn_rcpf(czc);
-      const float uc = (c.axfc + (i02 * gz) * in.fx) * rc + in.cx;
-      const float vc = (c.ayfc + (i12 * gz) * in.fy) * rc + in.cy;
-      const float r = k.rk4 * rc + 2.5f;
-      ok_s[sidx] = (czc > k.zmin4) & (fabsf(uc - k.hw) + r <= k.hw) & (fabsf(vc - k.hh) + r <= k.hh);
-      const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
-      Dt_s[sidx] = dtab[tv * tw + tu];
-      dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
-    }
-    unsigned sum16 = 0u;  // all summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
-    unsigned char* const sum_at = uni + ((size_t)(lin * 4u + wq) * 64u + (unsigned)lane) * (unsigned)NS;  // (hsk_sum_index_ns<NS>(vp, x0, y, zbeg))
-    // ... and the chunk's byte of the coarse level (its workgroup's four as one scalar word): 1 + k = k observations pending
-    unsigned cbyte = 0u;
-    if (!COUNT_ONLY && uni != nullptr) {
-      if (active) sum16 = NS == 2 ? (unsigned)*(const unsigned short*)sum_at : *(const unsigned*)sum_at;
-      cbyte = (((const unsigned*)(uni + hsk_lane_sum_bytes(vp)))[lin] >> (8u * wq)) & 0xffu;
-    }
-    const unsigned kpend = cbyte >= 2u ? cbyte - 1u : 0u;
-    PA_STAMP(6);
-#pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) {
-      const float dc = dc_s[sidx];
-      const bool dead4 = ok_s[sidx] & (dc * 0.99999f - Dt_s[sidx].x > k.cull_thr4);
-      const bool free44 = in_all_s[sidx] & ok_s[sidx] & (dc * 1.00001f + k.free_thr4 <= Dt_s[sidx].y);
-      free44_s[sidx] = free44;
-      other_s[sidx] = in_any_s[sidx] & !dead4 & !free44;
-    }
-    // the lane's summaries with the chunk's pending observations pushed into them (kpend > 0 only over quiet bytes); a rim
-    // block's count may leave the byte's range: its words are rewritten below
-    unsigned sum8[NS];
-    unsigned new16 = 0u;
-#pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) {
-      sum8[sidx] = hsk_sum_push((sum16 >> (8 * sidx)) & 0xffu, kpend);
-      new16 |= min(sum8[sidx], HSK_SUM_MAX) << (8 * sidx);  // (an out-of-range count is replaced by the block's new state below)
-    }
-    PA_STAMP(2);
-    // ---- stage 2: second level for the still undecided lanes: the 16 voxel centres span a parallelogram in camera
-    //      space, whose projection is a convex quadrilateral, so the pixel box of the four projected corners
-    //      (+-1 px for rounding) holds all 16 pixels; its exact min / max depth comes from the undilated 8-px
-    //      tile table (<= 3x3 tiles).  Every block decided here is one less entry for pass B.
-    // (the z-invariant terms of the lane's first and last voxel: only waves with an undecided lane come here)
+    // ---- stage 1 (round 5: the levels changed places).  With the coarse level above it, pass A only meets chunks that hold
+    // a surface, the frustum's rim or the camera's neighbourhood: the 16-px level, built to discard the bulk of free and
+    // occluded space cheaply, decided little there that the pixel-box level did not decide as well (its table is coarser
+    // and dilated, its distance bound looser: whenever the pixel-box level applies -- ok2 -- it decides at least as much),
+    // and every mixed wave went through both.  The pixel-box level now comes first, for every lane-block inside the lane's
+    // z range; the 16-px level is the fall-back for the blocks it cannot look up (a pixel box wider than 3 x 3 tiles of
+    // 8 px: blocks within half a metre of the camera, or one that leaves the image).
+    //      The 16 voxel centres span a parallelogram in camera space, whose projection is a convex quadrilateral, so the
+    //      pixel box of the four projected corners (+-1 px for rounding) holds all 16 pixels; its exact min / max depth
+    //      comes from the undilated 4-px or 8-px tile table (<= 3x3 tiles).  Every block decided is one less entry for pass B.
+    bool in_any_s[NS], ok2_s[NS];
+    float2 t9_s[NS];
+    float dlo_s[NS], dhi_s[NS];
     float cax[2], cay[2], caz[2], pn_lo, pn_hi;
     {
       const float gx0 = ((float)x0 + 0.5f) * vp.cell[0] - tx, gx3 = ((float)(x0 + 3) + 0.5f) * vp.cell[0] - tx;
@@ -938,10 +897,18 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       pn_hi = fmaxf(p0, p3);  // smallest / largest gx^2 + gy^2 over the lane's x range (not only at its 4 centres)
       pn_lo = (gx0 <= 0.0f && gx3 >= 0.0f) ? gy * gy : fminf(p0, p3);
     }
+    // (both groups' look-ups are requested before either is used, the lane's summaries behind them: loads return in the
+    // order they were issued, and the summaries -- an 8 MiB table that misses where the tile tables hit -- are not needed
+    // before stage 3)
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
-      if (!actv[sidx] || __ballot(other_s[sidx]) == 0ull) continue;
       const int zb = zbs[sidx];
+      in_any_s[sidx] = actv[sidx] & (zb + 3 >= zl) & (zb <= zh) & active;
+      in_all_s[sidx] = actv[sidx] & (zb >= zl) & (zb + 3 <= zh) & active;
+      ok2_s[sidx] = false;
+      t9_s[sidx] = make_float2(0.0f, 0.0f);
+      dlo_s[sidx] = dhi_s[sidx] = 0.0f;
+      if (!actv[sidx]) continue;  // wave-uniform
       const float gza = ((float)(vp.zs0 + zb) + 0.5f) * vp.cell[2] - tz;
       const float gzb = ((float)(vp.zs0 + zb + 3) + 0.5f) * vp.cell[2] - tz;
       float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f, zmn = 1e30f;
@@ -967,22 +934,75 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       const int sh = fine ? 2 : 3;
       const int tu0 = iu0 >> sh, tv0 = iv0 >> sh;
       const int nx = (iu1 >> sh) - tu0, ny = (iv1 >> sh) - tv0;  // tiles spanned, less one
-      const bool ok2 = in_img & (nx <= 2) & (ny <= 2);
+      ok2_s[sidx] = in_img & (nx <= 2) & (ny <= 2);
       const float2* __restrict__ tab = fine ? qtab : ftab;
       const int tbw = fine ? 2 * fw : fw, tbh = fine ? 2 * fh : fh;
       // (one look-up: table (nx, ny) holds the (max, min) of the nx x ny tiles from each tile on, k_tile_window)
       const int shape = min(max(ny, 0), 2) * 3 + min(max(nx, 0), 2);
-      const float2 t9 = tab[(size_t)shape * tbw * tbh + min(max(tv0, 0), tbh - 1) * tbw + min(max(tu0, 0), tbw - 1)];
-      const float Dx = t9.x, Dn = t9.y;
+      t9_s[sidx] = tab[(size_t)shape * tbw * tbh + min(max(tv0, 0), tbh - 1) * tbw + min(max(tu0, 0), tbw - 1)];
       // exact distance range of the block: its 16 voxel centres lie in the rectangle [gx0, gx3] x {gy} x [gza, gzb], over
       // which the distance to the camera centre is largest at a corner and smallest where each coordinate is nearest 0
       const float gz2_hi = fmaxf(gza * gza, gzb * gzb);
       const float gz2_lo = (gza <= 0.0f && gzb >= 0.0f) ? 0.0f : fminf(gza * gza, gzb * gzb);
-      const float d_hi = __builtin_amdgcn_sqrtf(pn_hi + gz2_hi), d_lo = __builtin_amdgcn_sqrtf(pn_lo + gz2_lo);
-      const bool dead2 = ok2 & (d_lo * 0.99999f - Dx > k.cull_thr2);
-      const bool free2 = in_all_s[sidx] & ok2 & (d_hi * 1.00001f + k.free_thr2 <= Dn);
-      free44_s[sidx] = free44_s[sidx] | (other_s[sidx] & free2);
-      other_s[sidx] = other_s[sidx] & !dead2 & !free2;
+      dhi_s[sidx] = __builtin_amdgcn_sqrtf(pn_hi + gz2_hi);
+      dlo_s[sidx] = __builtin_amdgcn_sqrtf(pn_lo + gz2_lo);
+    }
+    unsigned sum16 = 0u;  // all summaries of the lane's chunk (group g of the chunk in byte g): used in stage 3
+    unsigned char* const sum_at = uni + ((size_t)(lin * 4u + wq) * 64u + (unsigned)lane) * (unsigned)NS;  // (hsk_sum_index_ns<NS>(vp, x0, y, zbeg))
+    // ... and the chunk's byte of the coarse level (its workgroup's four as one scalar word): 1 + k = k observations pending
+    unsigned cbyte = 0u;
+    if (!COUNT_ONLY && uni != nullptr) {
+      if (active) sum16 = NS == 2 ? (unsigned)*(const unsigned short*)sum_at : *(const unsigned*)sum_at;
+      cbyte = (((const unsigned*)(uni + hsk_lane_sum_bytes(vp)))[lin] >> (8u * wq)) & 0xffu;
+    }
+    const unsigned kpend = cbyte >= 2u ? cbyte - 1u : 0u;
+    PA_STAMP(6);
+    bool need1 = false;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      const bool dead2 = ok2_s[sidx] & (dlo_s[sidx] * 0.99999f - t9_s[sidx].x > k.cull_thr2);
+      const bool free2 = in_all_s[sidx] & ok2_s[sidx] & (dhi_s[sidx] * 1.00001f + k.free_thr2 <= t9_s[sidx].y);
+      free44_s[sidx] = free2;
+      other_s[sidx] = in_any_s[sidx] & !dead2 & !free2;
+      need1 = need1 | (in_any_s[sidx] & !ok2_s[sidx]);
+    }
+    // the lane's summaries with the chunk's pending observations pushed into them (kpend > 0 only over quiet bytes); a rim
+    // block's count may leave the byte's range: its words are rewritten below
+    unsigned sum8[NS];
+    unsigned new16 = 0u;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      sum8[sidx] = hsk_sum_push((sum16 >> (8 * sidx)) & 0xffu, kpend);
+      new16 |= min(sum8[sidx], HSK_SUM_MAX) << (8 * sidx);  // (an out-of-range count is replaced by the block's new state below)
+    }
+    PA_STAMP(2);
+    // ---- stage 2: the 16-px level (dilated tile table against the block's centre +- radius) for the blocks the pixel-box
+    // level could not look up -- only in waves that hold such a block
+    if (__ballot(need1) != 0ull) {
+      float2 Dt_s[NS];
+      bool ok_s[NS];
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        const int zb = zbs[sidx];
+        const float gz = ((float)(vp.zs0 + zb) + 2.0f) * vp.cell[2] - tz;  // centre of planes zb .. zb+3
+        const float czc = c.azc + i22 * gz;
+        const float rc = __builtin_amdgcn_rcpf(czc);
+        const float uc = (c.axfc + (i02 * gz) * in.fx) * rc + in.cx;
+        const float vc = (c.ayfc + (i12 * gz) * in.fy) * rc + in.cy;
+        const float r = k.rk4 * rc + 2.5f;
+        ok_s[sidx] = (czc > k.zmin4) & (fabsf(uc - k.hw) + r <= k.hw) & (fabsf(vc - k.hh) + r <= k.hh);
+        const int tu = min(max((int)uc >> 4, 0), tw - 1), tv = min(max((int)vc >> 4, 0), th - 1);
+        Dt_s[sidx] = dtab[tv * tw + tu];
+        dc_s[sidx] = __builtin_amdgcn_sqrtf(gz * gz + c.pnc);
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        const float dc = dc_s[sidx];
+        const bool dead4 = ok_s[sidx] & (dc * 0.99999f - Dt_s[sidx].x > k.cull_thr4);
+        const bool free44 = in_all_s[sidx] & ok_s[sidx] & (dc * 1.00001f + k.free_thr4 <= Dt_s[sidx].y);
+        free44_s[sidx] = free44_s[sidx] | (other_s[sidx] & free44);
+        other_s[sidx] = other_s[sidx] & !dead4 & !free44;
+      }
     }
     PA_STAMP(3);
 #ifdef HSK_PA_TIMING
