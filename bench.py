@@ -162,6 +162,57 @@ def pmc_counters(volume, total, passes, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def kernel_durations(volume, total, window_first, timeout_s=240):
+    """mean duration (us) of every kernel over the launches of the timed window: a child run of tools/replay_frames.py under
+    rocprofv3 --kernel-trace (the per-dispatch trace, so that the window can be cut out); {name prefix: us} or (None, reason)"""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="hsk_kt_")
+    try:
+        out = os.path.join(tmp, "kt")
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "replay_frames.py"),
+               str(volume), str(total)]
+        try:
+            subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        except (subprocess.SubprocessError, OSError) as e:
+            return None, f"rocprofv3 --kernel-trace failed: {type(e).__name__}"
+        files = glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True)
+        if not files:
+            return None, "rocprofv3 --kernel-trace wrote no trace"
+        per = {}
+        for r in csv.DictReader(open(files[0])):
+            per.setdefault(r["Kernel_Name"].split("(")[0], []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3)
+        return {k: float(np.mean(v[window_first:total])) for k, v in per.items() if len(v) >= total and v[window_first:total]}, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def issue_util_block(volume, total, window_first):
+    """how busy pass A and pass B keep the two issue pipes -- SQ_INSTS_VALU x 2 cycles (a wave64 instruction on a
+    SIMD-32: MI355X_MICROARCH.md) over 1024 SIMDs x the kernel's cycles, SQ_INSTS_SALU over 256 scalar units x cycles (2.4 GHz);
+    counters and durations from child runs over the frames of the timed window"""
+    per, why = pmc_counters(volume, total, ["SQ_INSTS_VALU SQ_INSTS_SALU"])
+    if per is None:
+        return {"note": why}
+    dur, why = kernel_durations(volume, total, window_first)
+    if dur is None:
+        return {"note": why}
+    out = {"note": "SQ_INSTS_VALU x 2 / (1024 SIMDs x cycles), SQ_INSTS_SALU / (256 x cycles), cycles = mean kernel duration x 2.4 GHz; "
+                   "chip-wide averages over the launch: the CUs inside the frustum are busier than that"}
+    for label, prefix in (("pass_a", "void k_integrate<false"), ("pass_b", "void k_integrate_detail2<false"), ("k_column_zrange", "k_column_zrange")):
+        pn = [k for k in per if k.startswith(prefix)]
+        dn = [k for k in dur if k.startswith(prefix)]
+        if not pn or not dn:
+            continue
+        valu = float(np.mean(per[pn[0]].get("SQ_INSTS_VALU", [0])[window_first:total]))
+        salu = float(np.mean(per[pn[0]].get("SQ_INSTS_SALU", [0])[window_first:total]))
+        cyc = dur[dn[0]] * 2400.0
+        out[label] = {"us": round(dur[dn[0]], 2), "insts_valu": int(valu), "insts_salu": int(salu),
+                      "valu": round(valu * 2.0 / (1024.0 * cyc), 3), "salu": round(salu / (256.0 * cyc), 3)}
+    return out
+
+
 INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false", "void k_integrate_detail2<false")   # (name prefixes: pass A is k_integrate<false, 2 | 4>)
 
 
@@ -207,38 +258,46 @@ def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
 # ---------------------------------------------------------------------------------------------------------------------
 def readout_block(trk, n, with_download=True):
     """After the timed frames: the deferred free-space weights written back into the volume (k_summaries<true>, what
-    every read-out does first), the TSDF zero-crossing cloud (hsk_extract_cloud: count pass, row scan, write pass, D2H)
-    and the whole volume (hsk_download_tsdf: D2H into pageable host memory) -- host wall clock around each call."""
+    every read-out does first), the TSDF zero-crossing cloud (hsk_extract_cloud), the two meshes and the whole volume
+    (hsk_download_tsdf into pageable host memory) -- host wall clock around each call of the Python binding, i.e. around the
+    caller's protocol: a size query, then the fill.  Every product is taken twice: the first call of a context also pays for
+    what the library allocates on first use (the pinned staging pair, the row tables, the product buffer: `first_call_ms`);
+    the second follows a DIFFERENT product, so its count pass runs again (the cache only serves query + fill of one product)."""
     trk.synchronize()
     t0 = time.perf_counter()
     trk.flush_weights()
     trk.synchronize()
     t1 = time.perf_counter()
-    cloud, total = trk.extract_cloud()
-    t2 = time.perf_counter()
-    out = {"flush_weights_ms": round((t1 - t0) * 1e3, 3), "extract_cloud_ms": round((t2 - t1) * 1e3, 3), "cloud_points": int(total),
-           "note": "host clock; flush = the free-space weights held in the lane-block summaries written back into the volume (once: the "
+    out = {"flush_weights_ms": round((t1 - t0) * 1e3, 3),
+           "note": "host clock; flush = the free-space weights held in the summaries written back into the volume (once: the "
                    "read-outs after it find them current); the timed frames never pay it"}
-    del cloud
-    # the mesh the .ply export is written from (hsk_extract_mesh: count pass, row scan, write pass, D2H of 36 B per triangle)
-    t2 = time.perf_counter()
-    tris, n_tri = trk.extract_mesh()
-    t2b = time.perf_counter()
-    out["extract_mesh_ms"] = round((t2b - t2) * 1e3, 3)
-    out["mesh_triangles"] = int(n_tri)
-    del tris
-    t2 = time.perf_counter()
-    tris, n_tri = trk.extract_mesh(cubes=True)   # hsk_extract_mesh_cubes: marching cubes, the form upstream's .ply has
-    t2b = time.perf_counter()
-    out["extract_mesh_cubes_ms"] = round((t2b - t2) * 1e3, 3)
-    out["mesh_cubes_triangles"] = int(n_tri)
-    del tris
+    first = {}
+
+    def timed(name, fn):
+        ta = time.perf_counter()
+        res, cnt = fn()
+        tb = time.perf_counter()
+        del res
+        return round((tb - ta) * 1e3, 3), int(cnt)
+
+    for rnd in (0, 1):
+        for name, key, fn in (("extract_cloud_ms", "cloud_points", trk.extract_cloud), ("extract_mesh_ms", "mesh_triangles", trk.extract_mesh),
+                              ("extract_mesh_cubes_ms", "mesh_cubes_triangles", lambda: trk.extract_mesh(cubes=True))):
+            ms, cnt = timed(name, fn)
+            if rnd == 0:
+                first[name] = ms
+            else:
+                out[name], out[key] = ms, cnt
+    out["first_call_ms"] = first
     if with_download:
+        t2 = time.perf_counter()
+        vol = trk.download_tsdf()   # (a fresh host array: the page faults of its 512 MiB / 4 GiB are inside)
         t3 = time.perf_counter()
-        vol = trk.download_tsdf()
+        trk.download_tsdf(out=vol)  # (the same array again: the copy alone)
         t4 = time.perf_counter()
         out["download_tsdf_ms"] = round((t4 - t3) * 1e3, 1)
         out["download_GBps_pageable_host"] = round(vol.nbytes / (t4 - t3) / 1e9, 2)
+        out["download_tsdf_fresh_array_ms"] = round((t3 - t2) * 1e3, 1)
         del vol
     return out
 
@@ -267,6 +326,7 @@ def concurrent_rooms(hsk, n, dev_frames, local_rank, counts=(2, 4)):
                 t.submit_frame_dev(dev_frames[k].data_ptr())
                 lost[i] += not t.wait_frame()[1]
             lost[i] += not t.wait_frame()[1]
+            t.synchronize()   # (the last wait returns with the pose: that frame's integrate and raycast are part of the work timed)
 
         threads = [threading.Thread(target=run, args=(i,)) for i in range(M)]
         for th in threads:
@@ -372,6 +432,7 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
     rep = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=0)
     rep.set_profiling(True)
     rep_poses = {}
+    all_poses = []
     sample = list(range(1 + Wm, total, max(1, K // 10)))
     p = None
     entries = []
@@ -380,6 +441,7 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
         if i == 1 + Wm:
             rep.stage_ms(reset=True)  # warm-up frames are not part of the timed region
         p, _ = rep.process_frame_dev(dev_frames[i].data_ptr())
+        all_poses.append(p.copy())
         if i >= 1 + Wm:
             m1, n1 = rep.stage_ms(reset=True)
             if n1 == 1:
@@ -390,6 +452,7 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
     per_frame = np.array(per_frame) if per_frame else np.zeros((1, 4))
     ms, nf = [float(v) for v in per_frame.sum(axis=0)], len(per_frame)
     replay_with_events.per_frame_us = per_frame * 1e3
+    replay_with_events.poses = all_poses
     rep.set_profiling(False)
     if final_pose is not None:
         assert np.array_equal(p, final_pose), "the replay must reproduce the timed run's final pose bit for bit"
@@ -418,9 +481,11 @@ def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic, "hbm_GBps": None if traffic is None else round(traffic / t_int / 1e9, 1),
         "hbm_frac": None if traffic is None else round(traffic / t_int / 1e9 / HBM_PEAK_GBS, 4),
-        "frac_note": "achieved / frac: ALGORITHMIC bytes (SURVEY.md 8(d): 8 B x V_upd + 2 B x W x H) over the stage's time -- an effective rate: the "
-                     "lane-block summaries record deep-free-space weight updates in one byte per 16 voxels instead of moving the voxels, so the "
-                     "bytes that really cross the memory side are `traffic`, and hbm_GBps / hbm_frac = traffic over the same time",
+        "frac_note": ("EFFECTIVE, > 1 BECAUSE DEFERRED: " if achieved / HBM_PEAK_GBS > 1.0 else "") +
+                     "achieved / frac: ALGORITHMIC bytes (SURVEY.md 8(d): 8 B x V_upd + 2 B x W x H) over the stage's time -- an effective rate: the "
+                     "summaries record deep-free-space weight updates in one byte per 16 voxels (or per 4096: the coarse level) instead of moving "
+                     "the voxels, so the bytes that really cross the memory side are `traffic`, and hbm_GBps / hbm_frac = traffic over the same "
+                     "time; the volume a read-out sees is bit-equal to the oracle's after the flush (profiles/r05/long_parity_*.txt of this build id)",
         "algorithmic_bytes_per_launch": int(alg_bytes), "v_upd_mean": int(v_mean),
         "pass_b_queue_entries_mean": None if getattr(replay_with_events, "queue_entries", None) is None else int(replay_with_events.queue_entries),
         "avg_launch_us": round(t_int * 1e6, 2), "frames": int(nf),
@@ -438,6 +503,36 @@ def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
     if traffic_info is not None:
         block["traffic_detail"] = traffic_info
     return block
+
+
+def noise_block(args, hsk, torch, n, local_rank, clean_fps):
+    """SURVEY.md 8(d)'s noise run on the measured path: the same timed region on the stream with sensor noise
+    (sigma = 1.2 mm z^2, 2 % dropout: what a real takeDepthSnapshot frame looks like where the render is exact)"""
+    K2, W2 = min(args.steps, 60), min(args.warmup, 10)
+    tot = 1 + W2 + K2
+    gts, frames = hsk.synth_noisy_frames(tot)
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+    dev = [dev_all[i] for i in range(tot)]
+    torch.cuda.synchronize()
+    trk, pose, lost, el, _ = timed_single(hsk, torch, n, K2, W2, args.ahead, dev, local_rank)
+    trk.close()
+    rep, ms, nf, _, v_mean, _ = replay_with_events(hsk, n, K2, W2, frames, dev, local_rank, pose)
+    rep.close()
+    poses = replay_with_events.poses
+    terr = np.array([np.linalg.norm(p[:3, 3] - g[:3, 3]) * 1000.0 for p, g in zip(poses, gts)])
+    aerr = np.array([angle_deg(p[:3, :3], g[:3, :3]) for p, g in zip(poses, gts)])
+    blk = roofline_block(n, ms, nf, v_mean, None, None)
+    fps = K2 / el
+    out = {"stream": "scripted synthetic stream + sigma = 1.2 mm x (z / 1 m)^2 per pixel (seed 1234) + 2 % dropout (seed 5678)",
+           "frames_per_s": round(fps, 2), "steps": K2, "warmup": W2, "lost_frames": int(lost),
+           "vs_clean_render": None if not clean_fps else round(fps / clean_fps, 3),
+           "stage_us": {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1), "integrate": round(ms[2] / nf * 1e3, 1),
+                        "raycast": round(ms[3] / nf * 1e3, 1)},
+           "integrate": {k: blk[k] for k in ("achieved", "frac", "v_upd_mean", "pass_b_queue_entries_mean", "avg_launch_us")},
+           "trajectory": {"ate_rmse_mm": round(float(np.sqrt(np.mean(terr ** 2))), 3), "ate_max_mm": round(float(terr.max()), 3),
+                          "max_angle_deg": round(float(aerr.max()), 4), "frames": len(poses), "against": "the scripted ground truth"},
+           "parity": "tests/test_gpu_parity.py::test_noisy_stream_512_vs_oracle (40 frames, bit-equal) and tools/long_parity.py N FRAMES --noise"}
+    return out
 
 
 def run_single(args, hsk, torch, local_rank):
@@ -472,6 +567,8 @@ def run_single(args, hsk, torch, local_rank):
     out["roofline"] = roofline_block(n, ms, nf, v_mean, traffic, tinfo if isinstance(tinfo, dict) else None)
     if traffic is None:
         out["roofline"]["traffic_note"] = str(tinfo)
+    if not args.no_traffic:
+        out["roofline"]["issue_util"] = issue_util_block(n, total, 1 + Wm)
     pf = replay_with_events.per_frame_us
     out["stage_us"] = {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1), "integrate": round(ms[2] / nf * 1e3, 1),
                        "raycast": round(ms[3] / nf * 1e3, 1),
@@ -506,6 +603,7 @@ def run_single(args, hsk, torch, local_rank):
             trk.wait_frame()
             stamps.append(time.perf_counter())
         trk.wait_frame()
+        trk.synchronize()   # (hsk_wait_frame returns when the POSE is final: the last frame's integrate and raycast may still be running)
         t2 = time.perf_counter()
         per_h = np.diff(np.array([t1] + stamps + [t2]))
         out["pcie_inclusive_pipelined_fps"] = round(len(hf) / (t2 - t1), 2)
@@ -513,7 +611,13 @@ def run_single(args, hsk, torch, local_rank):
                                       "frame), %d frames; worst single frame %.2f ms" % (len(hf), float(per_h.max()) * 1e3))
     if not args.no_readout:
         out["readout_ms"] = readout_block(trk, n)
+        # the deferred weights' worst case: a host that reads a product after EVERY frame pays the flush every frame
+        fl = out["readout_ms"]["flush_weights_ms"] * 1e3
+        out["roofline"]["integrate_plus_flush_every_frame_us"] = round(out["stage_us"]["integrate"] + fl, 1)
+        out["roofline"]["frac_with_flush_every_frame"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / ((out["stage_us"]["integrate"] + fl) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     trk.close()
+    if not args.no_noise:
+        out["noise_%d" % n] = noise_block(args, hsk, torch, n, local_rank, out["value"])
     if not args.no_rooms and n <= 512:
         out["concurrent_rooms_one_gpu"] = concurrent_rooms(hsk, n, dev_frames, local_rank)
     # ---- SURVEY.md 8(d) cfg2 / BASELINE configs[1]: the 300-frame scripted stream at 256^3, from a recorded file ----
@@ -546,6 +650,10 @@ def run_single(args, hsk, torch, local_rank):
                                  "integrate": round(ms2[2] / nf2 * 1e3, 1), "raycast": round(ms2[3] / nf2 * 1e3, 1)}})
         if ro2 is not None:
             blk["readout_ms"] = ro2
+            blk["integrate_plus_flush_every_frame_us"] = round(blk["stage_us"]["integrate"] + ro2["flush_weights_ms"] * 1e3, 1)
+            blk["frac_with_flush_every_frame"] = round(blk["algorithmic_bytes_per_launch"] / ((blk["stage_us"]["integrate"] + ro2["flush_weights_ms"] * 1e3) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if not args.no_traffic:
+            blk["issue_util"] = issue_util_block(1024, tot2, 1 + W2)
         out["roofline_1024"] = blk
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, hsk)
@@ -586,10 +694,16 @@ def slab_halo_planes(n, size_m=3.0, trunc=0.03):
     return int(np.ceil(2.0 * 0.8 * tau / cell)) + 3
 
 
-def predicted_us(n, G):
-    """the frame time of G z-slabs priced from round 3's single-GPU stage times and xGMI link rates
+# single-GPU stage times (ICP, integrate, raycast; us) the multi-GPU prediction is priced from: this round's, and round 3's
+# (what DESIGN.md section 6's table was first written with: kept beside it as predicted_us_r03)
+STAGE_US_R05 = {512: (112.0, 58.0, 57.0), 1024: (113.0, 205.0, 73.0)}
+STAGE_US_R03 = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}
+
+
+def predicted_us(n, G, stage_us=None):
+    """the frame time of G z-slabs priced from the CURRENT single-GPU stage times and xGMI link rates
     (arithmetic, never measured) -- carried in the line so that the first multi-GPU run adjudicates it"""
-    base = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}.get(n)
+    base = (stage_us or STAGE_US_R05).get(n)
     if base is None or G < 2:
         return None
     icp, integ, ray = base
@@ -601,7 +715,8 @@ def predicted_us(n, G):
     return {"icp": icp, "integrate": round(integ_g, 1), "raycast": round(ray_g, 1), "slab_work_us": round(icp + integ_g + ray_g, 1),
             "exchange_us": exch, "adopt_us": adopt, "frame_us": round(frame, 1), "frames_per_s": round(1e6 / frame, 1),
             "single_gpu_frame_us": icp + integ + ray,
-            "source": "DESIGN.md section 6 (direct exchange; replicated ICP; from round 3's single-GPU stage times and ~100 GB/s per xGMI link)"}
+            "source": "DESIGN.md section 6 (direct exchange; replicated ICP; from %s single-GPU stage times and ~100 GB/s per xGMI link)"
+                      % ("round 3's" if stage_us is STAGE_US_R03 else "round 5's")}
 
 
 def plane_crcs(vol):
@@ -824,8 +939,21 @@ class Launcher:
         self.torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
         if self.torchrun:
             self.my_ranks = [int(os.environ["RANK"])]
-            self.dir = os.path.join(tempfile.gettempdir(), "hskbench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
-            os.makedirs(self.dir, exist_ok=True)
+            # one scratch directory per RUN: the launcher's pid of torch.distributed.run, its port and its run id -- and the
+            # director empties it before it publishes anything, so that nothing a crashed earlier run left under the same
+            # name (step files, rendezvous files, a single-context reference) can be replayed; followers wait for the nonce
+            self.dir = os.path.join(tempfile.gettempdir(), "hskbench_%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                                                                                 "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "") if c.isalnum())[:24]))
+            if int(os.environ["RANK"]) == 0:
+                shutil.rmtree(self.dir, ignore_errors=True)
+                os.makedirs(self.dir, exist_ok=True)
+                with open(os.path.join(self.dir, "nonce.tmp"), "w") as f:
+                    f.write(str(os.getpid()))
+                os.replace(os.path.join(self.dir, "nonce.tmp"), os.path.join(self.dir, "nonce"))
+            else:
+                t_end = time.time() + 600.0
+                while not os.path.exists(os.path.join(self.dir, "nonce")) and time.time() < t_end:
+                    time.sleep(0.05)
         else:
             self.my_ranks = list(range(self.world))
             self.dir = tempfile.mkdtemp(prefix="hskbench_")
@@ -898,6 +1026,8 @@ class Launcher:
             limit = self.IMPORT_STALL_S if any(ph in ("not started", "start") for ph in phases) else self.STALL_S
             if now - newest > limit:
                 self.kill(procs)
+                for _, _, log in procs:
+                    log.close()
                 return False, "stalled for %.0f s in phase %s: workers killed" % (limit, "/".join(sorted(set(phases))))
             time.sleep(0.05)
         for _, _, log in procs:
@@ -969,7 +1099,9 @@ class Launcher:
         if a.mode == "slab":
             for f in a.forms:
                 forms[f] = self.run_step(f, n)
-        good = {f: r for f, r in forms.items() if r and r.get("matches_single_gpu", single is None) and not r["lost_frames"]}
+        # (a form counts only when it was CHECKED against the single context and matched: without the reference -- the
+        # `single` step failed -- nothing is "good", and the line falls back to the weak-scaling head below)
+        good = {f: r for f, r in forms.items() if r and r.get("matches_single_gpu") is True and not r["lost_frames"]}
         best = max(good, key=lambda f: good[f]["value"]) if good else None
         pairs = None
         if a.mode == "pairs" or (a.mode == "slab" and G >= 4 and G % 2 == 0 and not a.no_rooms):
@@ -985,13 +1117,13 @@ class Launcher:
             r2 = f2 = None
             for f in order:
                 r2, f2 = self.run_step(f, 1024, steps=K2, warmup=W2), f
-                if r2 and r2.get("matches_single_gpu", s2 is None):
+                if r2 and r2.get("matches_single_gpu") is True:
                     break
             big = {"workload": "configs[3]: ONE 1024^3 TSDF as %d z-slabs, the same synthetic stream, %d timed frames" % (G, K2),
                    "single_gpu_same_frames": None if s2 is None else {k: s2[k] for k in ("value", "unit", "ms_per_step", "lost_frames")},
                    "form": f2, "slabs": None if r2 is None else {k: r2[k] for k in r2 if k not in ("build_id", "form", "world", "volume")},
                    "speedup_vs_single_gpu": None if not (r2 and s2) else round(r2["value"] / s2["value"], 3),
-                   "predicted_us": predicted_us(1024, G)}
+                   "predicted_us": predicted_us(1024, G), "predicted_us_r03": predicted_us(1024, G, STAGE_US_R03)}
         self.publish({"form": "done"})
         # ---- the line ----
         K, Wm = a.steps, a.warmup
@@ -1032,7 +1164,7 @@ class Launcher:
             "forms": {f: (dict(strip(r), what=FORM_TEXT[f]) if r else {"failed": self.failed.get("%s@%d" % (f, n), "failed")}) for f, r in forms.items()},
             "single_gpu_same_frames": None if single is None else {k: single[k] for k in ("value", "unit", "ms_per_step", "lost_frames", "final_pose_f32_hex")},
             "speedup_vs_single_gpu": None if not (single and slab_head) else round(head["value"] / single["value"], 3),
-            "predicted_us": predicted_us(n, G),
+            "predicted_us": predicted_us(n, G), "predicted_us_r03": predicted_us(n, G, STAGE_US_R03),
         }
         if head.get("stage_us"):
             out["stage_us"] = head["stage_us"]
@@ -1172,6 +1304,7 @@ def main():
                     help="time the replay of a recorded depth stream through hsk_track_stream instead of the synthetic in-HBM frames "
                          "(a missing FILE is first recorded from the 300-frame synthetic stream)")
     ap.add_argument("--no-rooms", action="store_true", help="skip the concurrent-room blocks (N = 1: 2 and 4 rooms at once on the one GPU; N > 1, --mode slab: one room per GPU, a room per GPU pair)")
+    ap.add_argument("--no-noise", action="store_true", help="skip the noise run (the timed region again on the stream with sensor noise: noise_<volume>)")
     ap.add_argument("--quick", action="store_true", help="all of the above")
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
@@ -1200,7 +1333,7 @@ def main():
     args = ap.parse_args()
     if args.quick:
         args.no_cpu_baseline = args.no_traffic = args.no_1024 = args.no_host_frames = args.no_rooms = True
-        args.no_readout = args.no_trajectory = True
+        args.no_readout = args.no_trajectory = args.no_noise = True
     if args.forms:
         args.forms = [f.strip() for f in args.forms.split(",") if f.strip()]
         bad = [f for f in args.forms if f not in SLAB_FORMS]

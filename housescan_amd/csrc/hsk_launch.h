@@ -36,7 +36,8 @@ void launch_resolve_push(hipStream_t s, const int* keys_local, const int* keys_m
                          const PushDests& dst, int P);
 void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,
                     unsigned long long* row_offset, unsigned long long* total, float* xyz, unsigned long long cap,
-                    int pass);
+                    int pass, const unsigned* flags);
+size_t hsk_scan_scratch_entries(int nrows);  // entries of a row_offset buffer for nrows rows (the offsets, then the scan's block sums)
 
 // image
 void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
@@ -68,6 +69,6 @@ void hsk_build_tet_table(TetTable* tt);
 int hsk_build_cube_table(CubeTable* ct);  // marching cubes; returns the most triangles of a case (HSK_MC_MAXT)
 int hsk_mesh_z_end(const VolParams& vp);
 void launch_extract_mesh(hipStream_t s, const void* vol, const VolParams& vp, const TetTable& tt, unsigned* row_count,
-                         unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass);
+                         unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass, const unsigned* flags);
 void launch_extract_mesh_mc(hipStream_t s, const void* vol, const VolParams& vp, const CubeTable* ct_dev, unsigned* row_count,
-                            unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass);
+                            unsigned long long* row_offset, unsigned long long* total, float* tri, unsigned long long cap, int pass, const unsigned* flags);

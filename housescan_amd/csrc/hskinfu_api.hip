@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/hskinfu.h"
 #include "hsk_dev.h"
@@ -71,6 +73,18 @@ struct hsk_ctx {
   unsigned long long* d_counter = nullptr;
   unsigned* d_rowcnt = nullptr;
   unsigned long long* d_rowoff = nullptr;
+  // read-out (round 5): what the volume looked like when a product was last counted (a size query followed by the fill
+  // finds the rows' counts and offsets in place), a grow-only device buffer for the product, and two pinned staging
+  // buffers through which products and the volume reach the caller's pageable memory (lazily allocated)
+  uint64_t vol_epoch = 1;       // counted up by everything that changes the volume
+  int ro_kind = 0;              // 1 cloud, 2 tetrahedra mesh, 3 cubes mesh: whose counts d_rowcnt / d_rowoff hold
+  uint64_t ro_epoch = 0;
+  unsigned long long ro_total = 0;
+  void* d_out = nullptr;
+  size_t out_bytes = 0;
+  void* h_pin[2] = {nullptr, nullptr};
+  size_t pin_bytes = 0;
+  hipEvent_t ev_pin[2] = {};
   int frame = 0;
   std::string err;
   // asynchronous submission ring (hsk_submit_frame_dev / hsk_wait_frame)
@@ -239,6 +253,11 @@ static void free_all(hsk_ctx* k) {
   F(k->d_counter);
   F(k->d_rowcnt);
   F(k->d_rowoff);
+  F(k->d_out);
+  for (auto& p : k->h_pin)
+    if (p) (void)hipHostFree(p);
+  for (auto& e : k->ev_pin)
+    if (e) (void)hipEventDestroy(e);
   if (k->h_st) (void)hipHostFree(k->h_st);
   if (k->h_stage) (void)hipHostFree(k->h_stage);
   if (k->h_ring) (void)hipHostFree(k->h_ring);
@@ -285,6 +304,7 @@ static int do_reset(hsk_ctx* k) {
   memcpy(k->h_st->Rp, k->init_R, sizeof(k->init_R));
   memcpy(k->h_st->tp, k->init_t, sizeof(k->init_t));
   k->frame = 0;
+  k->vol_epoch += 1;
   k->pending_reset = false;
   return upload_state(k);
 }
@@ -510,6 +530,7 @@ static void enqueue_icp(hsk_ctx* k, IcpFinal* fin = nullptr) {
 // are consumed (ring_mark)
 static void enqueue_integrate(hsk_ctx* k, const IcpFinal* fin = nullptr, bool report_early = false) {
   k->weights_pending = true;
+  k->vol_epoch += 1;
   const RingOut ring = {k->d_ring_view, k->d_fifo_view, k->d_ring_seq};
   launch_integrate(k->stream, k->d_vol, k->B().d_scaled, k->d_st, k->vp, k->lv[0].W, k->lv[0].H, k->lv[0].in, false,
                    k->d_counter, k->d_flags, k->B().d_tmax, k->d_zint, k->d_queue, (fin && fin->slots) ? fin : nullptr,
@@ -616,6 +637,7 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
     }
     HIPCHK(k, hipGraphLaunch(k->gexec, s));
     k->weights_pending = true;  // (the replayed graph integrates without passing through enqueue_integrate)
+    k->vol_epoch += 1;
   } else {
     enqueue_tracked_frame(k, false);
   }
@@ -1096,7 +1118,67 @@ extern "C" int hsk_icp_solve(const double in27[27], float x6[6], int* ok) {
   return HSK_OK;
 }
 
-#define HSK_COPY_PLANES 32  // planes converted per batch by hsk_download_tsdf / hsk_upload_tsdf (128 MiB of staging at 1024^3)
+// ---- between device memory and the caller's PAGEABLE host memory (round 5) ------------------------------------------------
+// A copy into pageable memory goes through the runtime's own staging at 16-17 GB/s, and hsk_download_tsdf moved 512 MiB
+// that way (31 ms; 253 ms at 1024^3), allocating and freeing its device staging inside every call.  Two pinned buffers
+// that live with the context: the device fills one (a conversion kernel writing straight into the mapped buffer, or a DMA
+// copy) while host threads move the other's content to where the caller wants it.
+#define HSK_PIN_BYTES ((size_t)32 << 20)
+static int ensure_pinned(hsk_ctx* k) {
+  if (k->h_pin[0]) return HSK_OK;
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(k, hipHostMalloc(&k->h_pin[i], HSK_PIN_BYTES, hipHostMallocDefault));
+    HIPCHK(k, hipEventCreateWithFlags(&k->ev_pin[i], hipEventDisableTiming));
+  }
+  k->pin_bytes = HSK_PIN_BYTES;
+  return HSK_OK;
+}
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+  size_t nt = bytes >> 22;  // a thread per 4 MiB, at most 8 (a core moves 10-20 GB/s)
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  if (nt > 8) nt = 8;
+  if (nt > hw) nt = hw;
+  if (nt <= 1) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < nt; ++t) {
+    const size_t off = t * per;
+    if (off >= bytes) break;
+    const size_t len = bytes - off < per ? bytes - off : per;
+    th.emplace_back([=]() { memcpy((char*)dst + off, (const char*)src + off, len); });
+  }
+  memcpy(dst, src, per < bytes ? per : bytes);
+  for (auto& t : th) t.join();
+}
+// `bytes` of device memory at src into the caller's dst, in pieces through the pinned pair: the DMA of piece i + 1 runs
+// under the host's copy of piece i
+static int copy_out(hsk_ctx* k, void* dst, const void* src_dev, size_t bytes) {
+  int r = ensure_pinned(k);
+  if (r != HSK_OK) return r;
+  size_t prev_off = 0, prev_len = 0;
+  int i = 0;
+  for (size_t off = 0; off < bytes; off += k->pin_bytes, ++i) {
+    const size_t len = bytes - off < k->pin_bytes ? bytes - off : k->pin_bytes;
+    HIPCHK(k, hipMemcpyAsync(k->h_pin[i & 1], (const char*)src_dev + off, len, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipEventRecord(k->ev_pin[i & 1], k->stream));
+    if (prev_len) {
+      HIPCHK(k, hipEventSynchronize(k->ev_pin[(i & 1) ^ 1]));
+      parallel_memcpy((char*)dst + prev_off, k->h_pin[(i & 1) ^ 1], prev_len);
+    }
+    prev_off = off;
+    prev_len = len;
+  }
+  if (prev_len) {
+    HIPCHK(k, hipEventSynchronize(k->ev_pin[(i - 1) & 1]));
+    parallel_memcpy((char*)dst + prev_off, k->h_pin[(i - 1) & 1], prev_len);
+  }
+  return HSK_OK;
+}
+
 extern "C" int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz) {
   if (!k) return HSK_ERR_ARG;
   if (z0) *z0 = k->vp.zs0;
@@ -1108,21 +1190,32 @@ extern "C" int hsk_download_tsdf(hsk_ctx* k, int16_t* out) {
   if (!k || !out) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   flush_weights(k);  // the weights of deep free space live in the summaries until read
-  // the caller's array is row-major (x fastest, then y, then plane); the volume is stored in 64-B blocks: converted on the
-  // device, a batch of planes at a time, through a staging buffer that lives for this call
+  // the caller's array is row-major (x fastest, then y, then plane); the volume is stored in 64-B blocks: the conversion
+  // kernel writes a batch of planes straight into one of the pinned buffers while the host moves the other's out
+  int r = ensure_pinned(k);
+  if (r != HSK_OK) return r;
   const size_t plane_bytes = (size_t)k->vp.X * k->vp.Y * 4;
-  const int batch = k->vp.nzs < HSK_COPY_PLANES ? k->vp.nzs : HSK_COPY_PLANES;
-  void* stage = nullptr;
-  HIPCHK(k, hipMalloc(&stage, plane_bytes * (size_t)batch));
-  hipError_t e = hipSuccess;
-  for (int zz0 = 0; zz0 < k->vp.nzs && e == hipSuccess; zz0 += batch) {
+  if (plane_bytes > k->pin_bytes) return fail(k, HSK_ERR_ARG, "hsk_download_tsdf: a plane of this volume exceeds the staging buffer");
+  const int batch = (int)(k->pin_bytes / plane_bytes) < k->vp.nzs ? (int)(k->pin_bytes / plane_bytes) : k->vp.nzs;
+  int prev_z = 0, prev_n = 0, i = 0;
+  for (int zz0 = 0; zz0 < k->vp.nzs; zz0 += batch, ++i) {
     const int nz = k->vp.nzs - zz0 < batch ? k->vp.nzs - zz0 : batch;
-    launch_vol_to_linear(k->stream, k->d_vol, k->vp, zz0, nz, stage);
-    e = hipMemcpyAsync((char*)out + (size_t)zz0 * plane_bytes, stage, plane_bytes * (size_t)nz, hipMemcpyDeviceToHost, k->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+    void* pin_dev = nullptr;
+    HIPCHK(k, hipHostGetDevicePointer(&pin_dev, k->h_pin[i & 1], 0));
+    launch_vol_to_linear(k->stream, k->d_vol, k->vp, zz0, nz, pin_dev);
+    HIPCHK(k, hipEventRecord(k->ev_pin[i & 1], k->stream));
+    if (prev_n) {
+      HIPCHK(k, hipEventSynchronize(k->ev_pin[(i & 1) ^ 1]));
+      parallel_memcpy((char*)out + (size_t)prev_z * plane_bytes, k->h_pin[(i & 1) ^ 1], (size_t)prev_n * plane_bytes);
+    }
+    prev_z = zz0;
+    prev_n = nz;
   }
-  (void)hipFree(stage);
-  HIPCHK(k, e);
+  if (prev_n) {
+    HIPCHK(k, hipEventSynchronize(k->ev_pin[(i - 1) & 1]));
+    parallel_memcpy((char*)out + (size_t)prev_z * plane_bytes, k->h_pin[(i - 1) & 1], (size_t)prev_n * plane_bytes);
+  }
+  HIPCHK(k, hipGetLastError());
   return HSK_OK;
 }
 extern "C" int hsk_flush_weights(hsk_ctx* k) {
@@ -1136,22 +1229,24 @@ extern "C" int hsk_upload_tsdf(hsk_ctx* k, const int16_t* in) {
   if (!k || !in) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
   {
+    int r = ensure_pinned(k);
+    if (r != HSK_OK) return r;
     const size_t plane_bytes = (size_t)k->vp.X * k->vp.Y * 4;
-    const int batch = k->vp.nzs < HSK_COPY_PLANES ? k->vp.nzs : HSK_COPY_PLANES;
-    void* stage = nullptr;
-    HIPCHK(k, hipMalloc(&stage, plane_bytes * (size_t)batch));
-    hipError_t e = hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream);  // (the padding planes of the last block row)
-    for (int zz0 = 0; zz0 < k->vp.nzs && e == hipSuccess; zz0 += batch) {
+    if (plane_bytes > k->pin_bytes) return fail(k, HSK_ERR_ARG, "hsk_upload_tsdf: a plane of this volume exceeds the staging buffer");
+    const int batch = (int)(k->pin_bytes / plane_bytes) < k->vp.nzs ? (int)(k->pin_bytes / plane_bytes) : k->vp.nzs;
+    HIPCHK(k, hipMemsetAsync(k->d_vol, 0, k->vol_bytes, k->stream));  // (the padding planes of the last block row)
+    int i = 0;
+    for (int zz0 = 0; zz0 < k->vp.nzs; zz0 += batch, ++i) {
       const int nz = k->vp.nzs - zz0 < batch ? k->vp.nzs - zz0 : batch;
-      e = hipMemcpyAsync(stage, (const char*)in + (size_t)zz0 * plane_bytes, plane_bytes * (size_t)nz, hipMemcpyHostToDevice, k->stream);
-      if (e == hipSuccess) {
-        launch_vol_from_linear(k->stream, k->d_vol, k->vp, zz0, nz, stage);
-        e = hipStreamSynchronize(k->stream);
-      }
+      if (i >= 2) HIPCHK(k, hipEventSynchronize(k->ev_pin[i & 1]));  // the kernel that read this buffer two batches ago
+      parallel_memcpy(k->h_pin[i & 1], (const char*)in + (size_t)zz0 * plane_bytes, (size_t)nz * plane_bytes);
+      void* pin_dev = nullptr;
+      HIPCHK(k, hipHostGetDevicePointer(&pin_dev, k->h_pin[i & 1], 0));
+      launch_vol_from_linear(k->stream, k->d_vol, k->vp, zz0, nz, pin_dev);
+      HIPCHK(k, hipEventRecord(k->ev_pin[i & 1], k->stream));
     }
-    (void)hipFree(stage);
-    HIPCHK(k, e);
   }
+  k->vol_epoch += 1;
   HIPCHK(k, hipMemsetAsync(k->d_flags, 0, k->flags_bytes, k->stream));
   launch_rebuild_flags(k->stream, k->d_vol, k->vp, k->d_flags);
   launch_rebuild_uniform(k->stream, k->d_vol, k->vp, k->d_uni);
@@ -1200,59 +1295,63 @@ extern "C" int hsk_download_scaled_depth(hsk_ctx* k, float* out) {
   return HSK_OK;
 }
 
+// A product of the volume (cloud, mesh): counted row by row, the rows' offsets scanned, then written in voxel order.  The
+// callers' protocol is a size query (null buffer) followed by the fill: the second call finds the counts and offsets of
+// the first in place when nothing has touched the volume in between (ro_kind / ro_epoch) -- the count sweep ran twice
+// per product before.  The product is written into a device buffer that only ever grows and reaches the caller through
+// the pinned pair (copy_out).
+template <class Count, class Fill>
+static int extract_product(hsk_ctx* k, int kind, size_t elem_bytes, float* out, size_t cap, size_t* n_out, Count count, Fill fill) {
+  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // (>= the mesh rows: one pair of buffers for every product)
+  if (!k->d_rowcnt) {
+    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
+    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, hsk_scan_scratch_entries(nrows) * 8));
+  }
+  flush_weights(k);
+  if (!(k->ro_kind == kind && k->ro_epoch == k->vol_epoch)) {
+    k->ro_kind = 0;
+    count();
+    unsigned long long total = 0;
+    HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    k->ro_kind = kind;
+    k->ro_epoch = k->vol_epoch;
+    k->ro_total = total;
+  }
+  *n_out = (size_t)k->ro_total;
+  if (!out || cap == 0 || k->ro_total == 0) return HSK_OK;
+  const size_t nw = k->ro_total < cap ? (size_t)k->ro_total : cap;
+  if (k->out_bytes < nw * elem_bytes) {
+    if (k->d_out) (void)hipFree(k->d_out);
+    k->d_out = nullptr;
+    k->out_bytes = 0;
+    const size_t want = nw * elem_bytes + (nw * elem_bytes >> 2);  // (a quarter more: a scan grows from call to call)
+    HIPCHK(k, hipMalloc(&k->d_out, want));
+    k->out_bytes = want;
+  }
+  fill((float*)k->d_out, nw);
+  return copy_out(k, out, k->d_out, nw * elem_bytes);
+}
+
 extern "C" int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_points) {
   if (!k || !n_points) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);
-  if (!k->d_rowcnt) {
-    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
-    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
-  }
-  flush_weights(k);
-  launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
-  unsigned long long total = 0;
-  HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
-  HIPCHK(k, hipStreamSynchronize(k->stream));
-  *n_points = (size_t)total;
-  if (!xyz || cap_points == 0 || total == 0) return HSK_OK;
-  const size_t nw = total < cap_points ? (size_t)total : cap_points;
-  float* d_xyz = nullptr;
-  HIPCHK(k, hipMalloc((void**)&d_xyz, nw * 12));
-  launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, d_xyz, nw, 1);
-  hipError_t e = hipMemcpyAsync(xyz, d_xyz, nw * 12, hipMemcpyDeviceToHost, k->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
-  (void)hipFree(d_xyz);
-  HIPCHK(k, e);
-  return HSK_OK;
+  return extract_product(
+      k, 1, 12, xyz, cap_points, n_points,
+      [&]() { launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0, k->d_flags); },
+      [&](float* d, size_t nw) { launch_extract(k->stream, k->d_vol, k->vp, k->d_rowcnt, k->d_rowoff, k->d_counter, d, nw, 1, k->d_flags); });
 }
 
 // Triangle soup (9 floats per triangle) of the TSDF zero level set, marching tetrahedra, voxel order.
 extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles) {
   if (!k || !n_triangles) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // >= the mesh rows; shared with hsk_extract_cloud
-  if (!k->d_rowcnt) {
-    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
-    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
-  }
   TetTable tt;
   hsk_build_tet_table(&tt);
-  flush_weights(k);
-  launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
-  unsigned long long total = 0;
-  HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
-  HIPCHK(k, hipStreamSynchronize(k->stream));
-  *n_triangles = (size_t)total;
-  if (!tri_xyz || cap_triangles == 0 || total == 0) return HSK_OK;
-  const size_t nw = total < cap_triangles ? (size_t)total : cap_triangles;
-  float* d_tri = nullptr;
-  HIPCHK(k, hipMalloc((void**)&d_tri, nw * 36));
-  launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, d_tri, nw, 1);
-  hipError_t e = hipMemcpyAsync(tri_xyz, d_tri, nw * 36, hipMemcpyDeviceToHost, k->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
-  (void)hipFree(d_tri);
-  HIPCHK(k, e);
-  return HSK_OK;
+  return extract_product(
+      k, 2, 36, tri_xyz, cap_triangles, n_triangles,
+      [&]() { launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0, k->d_flags); },
+      [&](float* d, size_t nw) { launch_extract_mesh(k->stream, k->d_vol, k->vp, tt, k->d_rowcnt, k->d_rowoff, k->d_counter, d, nw, 1, k->d_flags); });
 }
 
 // The same level set by MARCHING CUBES (the form upstream's .ply export has, README.md:16-17): about half the triangles
@@ -1260,33 +1359,16 @@ extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles
 extern "C" int hsk_extract_mesh_cubes(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles) {
   if (!k || !n_triangles) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // >= the mesh rows; shared with hsk_extract_cloud
-  if (!k->d_rowcnt) {
-    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
-    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, (size_t)nrows * 8));
-  }
   if (!k->d_cube_tab) {
     CubeTable ct;
     if (hsk_build_cube_table(&ct) != HSK_MC_MAXT) return fail(k, HSK_ERR_STATE, "marching-cubes table: a case with more triangles than the table holds");
     HIPCHK(k, hipMalloc((void**)&k->d_cube_tab, sizeof(CubeTable)));
     HIPCHK(k, hipMemcpy(k->d_cube_tab, &ct, sizeof(CubeTable), hipMemcpyHostToDevice));
   }
-  flush_weights(k);
-  launch_extract_mesh_mc(k->stream, k->d_vol, k->vp, k->d_cube_tab, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0);
-  unsigned long long total = 0;
-  HIPCHK(k, hipMemcpyAsync(&total, k->d_counter, 8, hipMemcpyDeviceToHost, k->stream));
-  HIPCHK(k, hipStreamSynchronize(k->stream));
-  *n_triangles = (size_t)total;
-  if (!tri_xyz || cap_triangles == 0 || total == 0) return HSK_OK;
-  const size_t nw = total < cap_triangles ? (size_t)total : cap_triangles;
-  float* d_tri = nullptr;
-  HIPCHK(k, hipMalloc((void**)&d_tri, nw * 36));
-  launch_extract_mesh_mc(k->stream, k->d_vol, k->vp, k->d_cube_tab, k->d_rowcnt, k->d_rowoff, k->d_counter, d_tri, nw, 1);
-  hipError_t e = hipMemcpyAsync(tri_xyz, d_tri, nw * 36, hipMemcpyDeviceToHost, k->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
-  (void)hipFree(d_tri);
-  HIPCHK(k, e);
-  return HSK_OK;
+  return extract_product(
+      k, 3, 36, tri_xyz, cap_triangles, n_triangles,
+      [&]() { launch_extract_mesh_mc(k->stream, k->d_vol, k->vp, k->d_cube_tab, k->d_rowcnt, k->d_rowoff, k->d_counter, nullptr, 0, 0, k->d_flags); },
+      [&](float* d, size_t nw) { launch_extract_mesh_mc(k->stream, k->d_vol, k->vp, k->d_cube_tab, k->d_rowcnt, k->d_rowoff, k->d_counter, d, nw, 1, k->d_flags); });
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1451,6 +1533,7 @@ extern "C" int hsk_mgpu_frame_front(hsk_ctx* k, const void* depth_dev, int w, in
   }
   HIPCHK(k, hipGraphLaunch(k->sgexec[set], k->stream));
   k->weights_pending = true;
+  k->vol_epoch += 1;
   return HSK_OK;
 }
 

@@ -174,8 +174,11 @@ class KinfuTracker:
         self._ck(self.lib.hsk_icp_solve(s.ctypes.data_as(C.POINTER(C.c_double)), _fp(x), C.byref(ok)))
         return x, bool(ok.value)
 
-    def download_tsdf(self):
-        out = np.empty((self.stored_nz, self.cfg.vol_y, self.cfg.vol_x, 2), np.int16)
+    def download_tsdf(self, out=None):
+        """the stored planes as a row-major [nz, Y, X, 2] int16 array (into `out` when given: no fresh pages to fault in)"""
+        if out is None:
+            out = np.empty((self.stored_nz, self.cfg.vol_y, self.cfg.vol_x, 2), np.int16)
+        assert out.dtype == np.int16 and out.flags.c_contiguous and out.size == self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2
         self._ck(self.lib.hsk_download_tsdf(self.h, out.ctypes.data))
         return out
 
@@ -384,6 +387,25 @@ def synth_depth(pose, w=640, h=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
     if rc != 0:
         raise KinfuError(f"hsk_synth_render failed ({rc})")
     return d
+
+
+def synth_noisy_frames(count, first=0, sigma_mm=1.2, dropout=0.02, seeds=(1234, 5678)):
+    """SURVEY.md 8(d)'s noise run: the scripted stream with sensor noise -- sigma = 1.2 mm x (z / 1 m)^2 on every pixel
+    (generator seed 1234) and 2 % of the pixels dropped to 0 (seed 5678), what a real takeDepthSnapshot frame looks like
+    (/root/reference/housescan/HoniHelper.hs:20-36) where the render is exact.  Frames `first .. first + count - 1`; the
+    generators are drawn from frame 0 on, so frame k is the same whatever `first` is.  -> (ground-truth poses, uint16 frames)"""
+    rn, rd = np.random.default_rng(seeds[0]), np.random.default_rng(seeds[1])
+    poses, frames = [], []
+    for k in range(first + count):
+        gt = synth_pose(k)
+        d = synth_depth(gt).astype(np.float64)
+        z = d / 1000.0
+        d = d + rn.normal(size=d.shape) * sigma_mm * z * z
+        d[rd.random(d.shape) < dropout] = 0
+        if k >= first:
+            poses.append(gt)
+            frames.append(np.clip(np.rint(d), 0, 65535).astype(np.uint16))
+    return poses, frames
 
 
 def synth_room_extents(variant):

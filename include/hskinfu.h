@@ -87,7 +87,14 @@ int hsk_process_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h, float
  * therefore stay valid until hsk_wait_frame has returned that frame.  Its CONTENTS may still be in the making on a
  * stream the context has adopted through hsk_set_stream (an upload or a conversion kernel enqueued there): the second
  * stream is ordered behind everything enqueued on the adopted stream at the time of the call.  Work on any other
- * stream (and any work when the context runs on its own stream) must have completed before the call. */
+ * stream (and any work when the context runs on its own stream) must have completed before the call.
+ * WHAT "WAITED" MEANS: hsk_wait_frame returns as soon as the frame's POSE and verdict are final -- when its ICP has ended.
+ * The frame's integrate and raycast may still be running on hsk_stream() at that point.  Every call of this library is
+ * ordered behind them on that stream, so callers that only use the library see nothing of it; a caller that takes
+ * "waited" for "the GPU is idle" or "the volume is current" -- to stop a clock, or to touch the volume or the model maps
+ * from another stream -- must call hsk_synchronize() first.  A frame that does not report within HSK_FRAME_TIMEOUT_S
+ * seconds (environment, default 20) makes hsk_wait_frame -- and the synchronous hsk_process_frame[_dev], which go through
+ * it -- return HSK_ERR_TIMEOUT. */
 #define HSK_MAX_IN_FLIGHT 3
 int hsk_submit_frame_dev(hsk_ctx* k, const void* depth_dev, int w, int h);
 int hsk_submit_frame(hsk_ctx* k, const uint16_t* depth, int w, int h); /* host frame; copied before the call returns */

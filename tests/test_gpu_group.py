@@ -255,14 +255,13 @@ print("done")
 """
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_direct_exchange_between_processes_sharing_the_gpu(hsk, synth_frames, tmp_path, world):
+@pytest.mark.parametrize("world,n", [(2, 64), (3, 64), (8, 256)])   # (8 ranks: the size of the node the scaling run will use)
+def test_direct_exchange_between_processes_sharing_the_gpu(hsk, synth_frames, tmp_path, world, n):
     """the RANK form of the group across OS processes (one slab each; here they share device 0, which RCCL refuses --
     "Duplicate GPU detected" -- and the direct form does not): hipIpc-mapped peer buffers, the POSIX shared-memory flag page,
     stream waits on flags another process raises.  Every rank must report the single context's poses; the ranks' owned
     planes together are the single context's volume."""
     import sys
-    n = 64
     idfile = str(tmp_path / "comm_id")
     open(idfile, "wb").write(os.urandom(128))
     script = DIRECT_RANK_SCRIPT.format(root=ROOT)
@@ -271,7 +270,7 @@ def test_direct_exchange_between_processes_sharing_the_gpu(hsk, synth_frames, tm
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=240))
+            outs.append(p.communicate(timeout=420))
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
