@@ -20,6 +20,7 @@ size_t integrate_chunk_count(const VolParams& vp);         // ... one per wave-c
 size_t integrate_zint_entries(const VolParams& vp);  // column z ranges + workgroup z ranges (launch_integrate's zint)
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tmax);
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles);
+void launch_tile_tables(hipStream_t s, int W, int H, float* tiles);  // the window forms + the sparse table, from the raw tables
 size_t tile_table_bytes(int W, int H);  // allocation of `tiles` (launch_tile_max + launch_tile_fine fill it)
 void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, unsigned* flags);
 // stored planes [zz0, zz0 + nz) of the volume (64-B blocks, hsk_dev.h: hsk_vox_index) to / from a row-major device array
@@ -46,6 +47,8 @@ void launch_scale_depth(hipStream_t s, const uint16_t* src, int W, int H, Intr i
 void launch_pyrdown(hipStream_t s, const uint16_t* src, int W, int H, uint16_t* dst);
 void launch_vmap_nmap_pyramid(hipStream_t s, uint16_t* const* depth, const ImgLevel* lv, float* const* vmap,
                               float* const* nmap);
+// pyrDown x 2 and the vertex / normal maps of all three levels in one launch (depth[0] is read, depth[1], depth[2] written)
+void launch_pyramid_maps(hipStream_t s, uint16_t* const* depth, const ImgLevel* lv, float* const* vmap, float* const* nmap);
 void launch_transform_maps(hipStream_t s, const float* vs, const float* ns, int P, const TrackState* st, float* vd,
                            float* nd);
 void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W, int H, float* v1, float* n1, float* v2,

@@ -508,12 +508,13 @@ extern "C" int hsk_synchronize(hsk_ctx* k) {
 // ------------------------------------------------------------------------------------------------------
 // frame building blocks (enqueue only; no host synchronisation)
 // ------------------------------------------------------------------------------------------------------
+// three launches (round 5; they were nine): the bilateral filter with scaleDepth and the raw tile tables of all three
+// granularities; the derived tile tables; pyrDown x 2 with the vertex / normal maps of the three levels
 static void enqueue_preprocess(hsk_ctx* k, hipStream_t s) {
   launch_bilateral_scale(s, k->B().d_raw, k->lv[0].W, k->lv[0].H, k->lv[0].in, k->h_ws, k->d_wc, k->B().d_dep[0], k->B().d_scaled,
                          k->B().d_tmax);
-  launch_tile_fine(s, k->B().d_scaled, k->lv[0].W, k->lv[0].H, k->B().d_tmax);
-  for (int l = 1; l < HSK_NLEVELS; ++l) launch_pyrdown(s, k->B().d_dep[l - 1], k->lv[l - 1].W, k->lv[l - 1].H, k->B().d_dep[l]);
-  launch_vmap_nmap_pyramid(s, k->B().d_dep, k->lv, k->B().d_vcur, k->B().d_ncur);
+  launch_tile_tables(s, k->lv[0].W, k->lv[0].H, k->B().d_tmax);
+  launch_pyramid_maps(s, k->B().d_dep, k->lv, k->B().d_vcur, k->B().d_ncur);
 }
 
 // fin: leave the frame's last solve to the integrate that the caller enqueues next with the same descriptor (its first

@@ -103,20 +103,6 @@ __global__ void k_tile_fine(const float* __restrict__ scaled, int W, int H, floa
 // where it made nine -- pass A and pass B are bound by the CU's vector-memory front end
 // (profiles/r02/integrate_analysis.md section 7) -- and over exactly the tiles the box touches, not always 3 x 3.
 // Entry (tx, ty) of shape (nx, ny) = over a < ny, b < nx of tab[min(ty + a, last)][min(tx + b, last)].
-__global__ void k_tile_window(const float2* __restrict__ tab, int tbw, int tbh, float2* __restrict__ win) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= tbw * tbh) return;
-  const int nx = (int)blockIdx.y % 3 + 1, ny = (int)blockIdx.y / 3 + 1;
-  const int ty = t / tbw, tx = t - ty * tbw;
-  float mx = 0.0f, mn = 1e30f;
-  for (int a = 0; a < ny; ++a)
-    for (int b = 0; b < nx; ++b) {
-      const float2 v = tab[min(ty + a, tbh - 1) * tbw + min(tx + b, tbw - 1)];
-      mx = fmaxf(mx, v.x);
-      mn = fminf(mn, v.y);
-    }
-  win[(size_t)blockIdx.y * tbw * tbh + t] = make_float2(mx, mn);
-}
 
 // The coarse level (k_column_zrange) asks for the (max, min) of the depth over the 16-px tiles a wave-chunk's pixel box
 // touches -- up to 16 x 16 of them for a chunk next to the camera.  A sparse table answers any such range with FOUR
@@ -125,18 +111,44 @@ __global__ void k_tile_window(const float2* __restrict__ tab, int tbw, int tbh, 
 // above nx, ny that sit in its corners.  Walked tile by tile the look-up was a chain of up to 144 dependent round trips in a
 // kernel of one wave per SIMD: 12 us of the frame's critical path.
 #define HSK_SPARSE_LEVELS 4
-__global__ void k_tile_sparse(const float* __restrict__ tmax, const float* __restrict__ tmin, int tw, int th, float2* __restrict__ sp) {
+
+// The derived tables of a frame in ONE launch (round 5; they were three): blockIdx.y 0 .. 8 the nine window shapes of the
+// 8-px table, 9 .. 17 those of the 4-px table, 18 .. 33 the sixteen levels of the 16-px sparse table.  All of them read only
+// the raw tables that k_bilateral_scale (or k_tile_max + k_tile_fine on the stage paths) has written.
+__global__ void k_tile_tables(const float* __restrict__ tmax, const float* __restrict__ tmin, int tw, int th, const float2* __restrict__ ftab,
+                              const float2* __restrict__ qtab, int fw, int fh, float2* __restrict__ fwin, float2* __restrict__ sparse) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= tw * th) return;
-  const int kx = (int)blockIdx.y % HSK_SPARSE_LEVELS, ky = (int)blockIdx.y / HSK_SPARSE_LEVELS;
-  const int ty = t / tw, tx = t - ty * tw;
-  float mx = 0.0f, mn = 1e30f;
-  for (int a = ty; a < min(ty + (1 << ky), th); ++a)
-    for (int b = tx; b < min(tx + (1 << kx), tw); ++b) {
-      mx = fmaxf(mx, tmax[a * tw + b]);
-      mn = fminf(mn, tmin[a * tw + b]);
-    }
-  sp[(size_t)blockIdx.y * tw * th + t] = make_float2(mx, mn);
+  const int job = blockIdx.y;
+  if (job < 18) {
+    const bool fine = job >= 9;
+    const float2* __restrict__ tab = fine ? qtab : ftab;
+    const int tbw = fine ? 2 * fw : fw, tbh = fine ? 2 * fh : fh;
+    if (t >= tbw * tbh) return;
+    const int shape = fine ? job - 9 : job;
+    const int nx = shape % 3 + 1, ny = shape / 3 + 1;
+    const int ty = t / tbw, tx = t - ty * tbw;
+    float mx = 0.0f, mn = 1e30f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        const float2 v = tab[min(ty + a, tbh - 1) * tbw + min(tx + b, tbw - 1)];
+        mx = fmaxf(mx, v.x);
+        mn = fminf(mn, v.y);
+      }
+    float2* __restrict__ win = fine ? fwin + (size_t)9 * fw * fh : fwin;
+    win[(size_t)shape * tbw * tbh + t] = make_float2(mx, mn);
+  } else {
+    if (t >= tw * th) return;
+    const int lv = job - 18;
+    const int kx = lv % HSK_SPARSE_LEVELS, ky = lv / HSK_SPARSE_LEVELS;
+    const int ty = t / tw, tx = t - ty * tw;
+    float mx = 0.0f, mn = 1e30f;
+    for (int a = ty; a < min(ty + (1 << ky), th); ++a)
+      for (int b = tx; b < min(tx + (1 << kx), tw); ++b) {
+        mx = fmaxf(mx, tmax[a * tw + b]);
+        mn = fminf(mn, tmin[a * tw + b]);
+      }
+    sparse[(size_t)lv * tw * th + t] = make_float2(mx, mn);
+  }
 }
 
 // clip [lo,hi] (in gz) with c + m*gz >= 0
@@ -156,7 +168,7 @@ static __device__ __forceinline__ void clip_interval(float c, float m, float& lo
 struct CoarseArgs {
   unsigned char* cflag;
   unsigned char* cs;
-  const float2* sparse;  // k_tile_sparse's table of the frame's 16-px tiles
+  const float2* sparse;  // the sparse table (k_tile_tables) of the frame's 16-px tiles
   int zchunk;  // planes per chunk of THIS launch (vp.zchunk, or all stored planes of a thinner slab)
   float free_thr, cull_thr;
 };
@@ -372,7 +384,7 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
               const int tv0 = (int)fminf(fmaxf(vmin, 0.0f), (float)(H - 1)) >> 4, tv1 = (int)fminf(fmaxf(vmax, 0.0f), (float)(H - 1)) >> 4;
               const int nx = tu1 - tu0 + 1, ny = tv1 - tv0 + 1;
               if ((nx <= (2 << (HSK_SPARSE_LEVELS - 1))) & (ny <= (2 << (HSK_SPARSE_LEVELS - 1)))) {
-                // (k_tile_sparse: the blocks of 2^kx x 2^ky tiles in the range's four corners cover it)
+                // (k_tile_tables: the blocks of 2^kx x 2^ky tiles in the range's four corners cover it)
                 const int kx = min(31 - __clz(nx), HSK_SPARSE_LEVELS - 1), ky = min(31 - __clz(ny), HSK_SPARSE_LEVELS - 1);
                 const float2* __restrict__ lv = ca.sparse + (size_t)(ky * HSK_SPARSE_LEVELS + kx) * tw16 * th;
                 const int ub = tu1 - (1 << kx) + 1, vb = tv1 - (1 << ky) + 1;
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       ok2_s[sidx] = in_img & (nx <= 2) & (ny <= 2);
       const float2* __restrict__ tab = fine ? qtab : ftab;
       const int tbw = fine ? 2 * fw : fw, tbh = fine ? 2 * fh : fh;
-      // (one look-up: table (nx, ny) holds the (max, min) of the nx x ny tiles from each tile on, k_tile_window)
+      // (one look-up: table (nx, ny) holds the (max, min) of the nx x ny tiles from each tile on, k_tile_tables)
       const int shape = min(max(ny, 0), 2) * 3 + min(max(nx, 0), 2);
       t9_s[sidx] = tab[(size_t)shape * tbw * tbh + min(max(tv0, 0), tbh - 1) * tbw + min(max(tu0, 0), tbw - 1)];
       // exact distance range of the block: its 16 voxel centres lie in the rectangle [gx0, gx3] x {gy} x [gza, gzb], over
@@ -1024,7 +1036,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     // (the tickets are REQUESTED here, before the free-space loads, and used after the stores: the counters' round trip
     // runs under the volume's -- one dependent round trip less in a wave's life)
     const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + wq * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
-    // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_window)
+    // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_tables)
     unsigned long long bo[NS];
     unsigned n_other = 0u, base_all = 0u;
 #pragma unroll
@@ -1274,20 +1286,26 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
   }
 }
 
-// fine (8-px) tile table: depends only on the depth frame, so it belongs to the preprocessing
+// the derived tables behind the raw ones (what pass A and the coarse level read): the window forms of the 8-px and 4-px
+// tables (nine shapes each), then the sparse table of the 16-px tiles -- one launch
+void launch_tile_tables(hipStream_t s, int W, int H, float* tiles) {
+  const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
+  const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
+  float2* ftab = (float2*)(tiles + 4 * tw * th);
+  float2* qtab = ftab + (size_t)fw * fh;
+  float2* fwin = qtab + (size_t)4 * fw * fh;
+  float2* sparse = fwin + (size_t)45 * fw * fh;
+  hipLaunchKernelGGL(k_tile_tables, dim3((4 * fw * fh + 255) / 256, 18 + HSK_SPARSE_LEVELS * HSK_SPARSE_LEVELS), dim3(256), 0, s, tiles, tiles + tw * th, tw,
+                     th, (const float2*)ftab, (const float2*)qtab, fw, fh, fwin, sparse);
+}
+// stage paths (the scaled depth alone, no bilateral launch): the raw 8-px and 4-px tables, then the derived ones
 void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* tiles) {
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int fw = (W + HSK_FTILE - 1) / HSK_FTILE, fh = (H + HSK_FTILE - 1) / HSK_FTILE;
   float2* ftab = (float2*)(tiles + 4 * tw * th);
   float2* qtab = ftab + (size_t)fw * fh;
   hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, ftab, fw, fh, qtab);
-  // behind them their window forms (what pass A reads): nine shapes of the 8-px table, then nine of the 4-px one
-  float2* fwin = qtab + (size_t)4 * fw * fh;
-  hipLaunchKernelGGL(k_tile_window, dim3((fw * fh + 255) / 256, 9), dim3(256), 0, s, ftab, fw, fh, fwin);
-  hipLaunchKernelGGL(k_tile_window, dim3((4 * fw * fh + 255) / 256, 9), dim3(256), 0, s, qtab, 2 * fw, 2 * fh, fwin + (size_t)9 * fw * fh);
-  // ... and behind those the sparse table of the 16-px tiles (the coarse level's range look-up)
-  float2* sparse = fwin + (size_t)45 * fw * fh;
-  hipLaunchKernelGGL(k_tile_sparse, dim3((tw * th + 255) / 256, HSK_SPARSE_LEVELS * HSK_SPARSE_LEVELS), dim3(256), 0, s, tiles, tiles + tw * th, tw, th, sparse);
+  launch_tile_tables(s, W, H, tiles);
 }
 // bytes of a frame's tile tables: 16-px raw (max, min) and dilated; 8-px and 4-px tables with nine window shapes each; the sparse table
 size_t tile_table_bytes(int W, int H) {

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
                                                          BilateralWs ws,
                                                          const float* __restrict__ wc_tab,
                                                          unsigned short* __restrict__ dst, float* __restrict__ scaled,
-                                                         float* __restrict__ tmax, float* __restrict__ tmin) {
+                                                         float* __restrict__ tmax, float* __restrict__ tmin, float2* __restrict__ ftab,
+                                                         float2* __restrict__ qtab, int fw, int fh) {
   // The tile holds 4 x depth: the tap's |difference| then IS the byte offset of its range weight (one v_sad_u32, one
   // v_min_u32, no shift), and sum1 comes out scaled by exactly 4: a power of two passes through the rounding of every
   // normal product and sum, and in the subnormal range (weights down to exp(-145) are in the table) an integer depth times
@@ -41,6 +42,8 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
   // a lane-mask branch.
   __shared__ unsigned tile[BIL_S][BIL_S + 1];
   __shared__ float shx[4], shn[4];
+  __shared__ float sct[BIL_T][BIL_T + 1];  // the block's scaled depths (0 outside the image): the finer tile tables come from here
+  __shared__ float2 q4[4][4];
   __shared__ float wc[513];  // wc[512] = 0: every difference of 512 and more
   const int tid = threadIdx.y * BIL_T + threadIdx.x;
   const int bx = blockIdx.x * BIL_T, by = blockIdx.y * BIL_T;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
     sc = ((float)value * lambda) / 1000.0f;
     scaled[y * W + x] = sc;
   }
+  sct[threadIdx.y][threadIdx.x] = sc;
   {
     float mx = sc, mn = sc;
 #pragma unroll
@@ -82,6 +86,32 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
       const int tw = gridDim.x;
       tmax[blockIdx.y * tw + blockIdx.x] = fmaxf(fmaxf(shx[0], shx[1]), fmaxf(shx[2], shx[3]));
       tmin[blockIdx.y * tw + blockIdx.x] = fminf(fminf(shn[0], shn[1]), fminf(shn[2], shn[3]));
+    }
+    // ... and the undilated 4-px and 8-px tables of pass A's pixel-box level (round 5: a launch of their own before, one
+    // THREAD per 8-px tile walking 64 floats at a stride of 8 -- 15 us; here the tile is already in the block): the block's
+    // sixteen 4-px tiles by sixteen threads, its four 8-px tiles from those (same values, same order-free max / min)
+    if (tid < 16) {
+      const int qx = tid & 3, qy = tid >> 2;
+      float mx = 0.0f, mn = 1e30f;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+          const float v = sct[qy * 4 + dy][qx * 4 + dx];
+          mx = fmaxf(mx, v);
+          mn = fminf(mn, v);
+        }
+      q4[qy][qx] = make_float2(mx, mn);
+      const int gx = blockIdx.x * 4 + qx, gy = blockIdx.y * 4 + qy;
+      if (gx < 2 * fw && gy < 2 * fh) qtab[(size_t)gy * (2 * fw) + gx] = make_float2(mx, mn);
+    }
+    __syncthreads();
+    if (tid < 4) {
+      const int ex = tid & 1, ey = tid >> 1;
+      const float2 a = q4[2 * ey][2 * ex], b = q4[2 * ey][2 * ex + 1], c = q4[2 * ey + 1][2 * ex], d = q4[2 * ey + 1][2 * ex + 1];
+      const int gx = blockIdx.x * 2 + ex, gy = blockIdx.y * 2 + ey;
+      if (gx < fw && gy < fh)
+        ftab[(size_t)gy * fw + gx] = make_float2(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fminf(fminf(a.y, b.y), fminf(c.y, d.y)));
     }
   }
   if (!inside) return;
@@ -113,14 +143,18 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
   dst[y * W + x] = (unsigned short)res;
 }
 
-// tiles: raw tile maxima then minima (tw*th floats each), as launch_tile_max lays them out
+// tiles: raw tile maxima then minima (tw*th floats each), as launch_tile_max lays them out; behind them (and the dilated
+// table) the raw 8-px and 4-px tables, as launch_tile_fine lays them out
 void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, Intr in, const float* ws, const float* wc,
                             uint16_t* dst, float* scaled, float* tiles) {
   dim3 block(BIL_T, BIL_T), grid((W + BIL_T - 1) / BIL_T, (H + BIL_T - 1) / BIL_T);
   BilateralWs wsv;
   for (int i = 0; i < 169; ++i) wsv.w[i] = ws[i];  // ws: HOST pointer to the 13x13 table
+  const int fw = (W + 7) / 8, fh = (H + 7) / 8;
+  float2* ftab = (float2*)(tiles + 4 * grid.x * grid.y);
+  float2* qtab = ftab + (size_t)fw * fh;
   hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, wsv, wc, dst, scaled, tiles,
-                     tiles + grid.x * grid.y);
+                     tiles + grid.x * grid.y, ftab, qtab, fw, fh);
 }
 
 // scaleDepth alone (stage-level integrate entry point)
@@ -244,6 +278,148 @@ void launch_vmap_nmap_pyramid(hipStream_t s, uint16_t* const* depth, const ImgLe
   }
   a.first_block[HSK_NLEVELS] = nb;
   hipLaunchKernelGGL(k_vmap_nmap, dim3(nb), dim3(64, 4), 0, s, a);
+}
+
+// pyrDown x 2 and the vertex / normal maps of all three levels in ONE launch (round 5; they were three: two pyrDown
+// launches of 7 us each and the maps).  A block owns a T x T tile of level 0 = T/2 squared of level 1 = T/4 squared of level 2
+// and keeps what they need in LDS: level 2 with its +1 neighbours for the normals is T/4 + 1 squared, whose 5 x 5 windows
+// reach T/2 + 5 squared of level 1, whose windows reach T + 13 squared of level 0 (the overlap between blocks is re-read
+// from L2, the overlapping pyrDown pixels are computed again: integer arithmetic on the same inputs).  The arithmetic is
+// k_pyrdown's and k_vmap_nmap's, on the same values: bit for bit the same images and maps.  T = 16: 1200 blocks for a
+// 640 x 480 frame (with T = 32, 300 blocks of four dependent phases each, the launch took 15.8 us).
+#ifndef PM_T0
+#define PM_T0 16
+#endif
+#define PM_T1 (PM_T0 / 2)
+#define PM_T2 (PM_T0 / 4)
+#define PM_S0 (PM_T0 + 13)
+#define PM_S1 (PM_T1 + 5)
+#define PM_S2 (PM_T2 + 1)
+static __device__ __forceinline__ bool pm_vertex(int dmm, int u, int v, float cx, float cy, float fx_inv, float fy_inv, float& X, float& Y, float& Z) {
+  const float z = (float)dmm / 1000.0f;
+  if (z != 0.0f) {
+    X = (z * ((float)u - cx)) * fx_inv;
+    Y = (z * ((float)v - cy)) * fy_inv;
+    Z = z;
+    return true;
+  }
+  X = Y = Z = HSK_NANF;
+  return false;
+}
+// dst(x, y) of pyrDown from a level held in LDS: src[(sy - oy) * pitch + (sx - ox)] = source pixel (sx, sy); W, H = source size
+static __device__ __forceinline__ int pm_pyrdown(const unsigned short* src, int pitch, int ox, int oy, int W, int H, int x, int y) {
+  const int center = src[(2 * y - oy) * pitch + (2 * x - ox)];
+  const int y0 = max(2 * y - 2, 0), y1 = min(2 * y + 2, H - 2);  // (upper clip exclusive of the last row / column, as the bilateral's)
+  const int x0 = max(2 * x - 2, 0), x1 = min(2 * x + 2, W - 2);
+  int sum = 0, count = 0;
+  for (int cy = y0; cy <= y1; ++cy)
+    for (int cx = x0; cx <= x1; ++cx) {
+      const int val = src[(cy - oy) * pitch + (cx - ox)];
+      const int d = abs(val - center);
+      if (d < 90) {
+        sum += val;
+        ++count;
+      }
+    }
+  return sum / count;
+}
+static __device__ __forceinline__ void pm_maps(const unsigned short* lv, int pitch, int ox, int oy, int W, int H, const Intr& in, int u, int v,
+                                               float* __restrict__ vmap, float* __restrict__ nmap) {
+  const size_t P = (size_t)W * H, i = (size_t)v * W + u;
+  const float fx_inv = 1.0f / in.fx, fy_inv = 1.0f / in.fy;
+  float x0, y0, z0;
+  const bool ok0 = pm_vertex(lv[(v - oy) * pitch + (u - ox)], u, v, in.cx, in.cy, fx_inv, fy_inv, x0, y0, z0);
+  vmap[i] = x0;
+  vmap[P + i] = y0;
+  vmap[2 * P + i] = z0;
+  float n0 = HSK_NANF, n1 = HSK_NANF, n2 = HSK_NANF;
+  if (ok0 && u < W - 1 && v < H - 1) {
+    float x1, y1, z1, x2, y2, z2;
+    const bool ok1 = pm_vertex(lv[(v - oy) * pitch + (u + 1 - ox)], u + 1, v, in.cx, in.cy, fx_inv, fy_inv, x1, y1, z1);
+    const bool ok2 = pm_vertex(lv[(v + 1 - oy) * pitch + (u - ox)], u, v + 1, in.cx, in.cy, fx_inv, fy_inv, x2, y2, z2);
+    if (ok1 && ok2) {
+      const float ax = x1 - x0, ay = y1 - y0, az = z1 - z0;
+      const float bx = x2 - x0, by = y2 - y0, bz = z2 - z0;
+      const float r0 = ay * bz - az * by;
+      const float r1 = az * bx - ax * bz;
+      const float r2 = ax * by - ay * bx;
+      const float inv = 1.0f / sqrtf(hsk_dot3(r0, r1, r2, r0, r1, r2));
+      n0 = r0 * inv;
+      n1 = r1 * inv;
+      n2 = r2 * inv;
+    }
+  }
+  nmap[i] = n0;
+  nmap[P + i] = n1;
+  nmap[2 * P + i] = n2;
+}
+__global__ __launch_bounds__(256) void k_pyramid_maps(PyramidArgs a, unsigned short* __restrict__ d1, unsigned short* __restrict__ d2) {
+  __shared__ unsigned short l0[PM_S0 * PM_S0], l1[PM_S1 * PM_S1], l2[PM_S2 * PM_S2];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const int W0 = a.W[0], H0 = a.H[0], W1 = a.W[1], H1 = a.H[1], W2 = a.W[2], H2 = a.H[2];
+  const int bx = blockIdx.x, by = blockIdx.y;
+  // level 0: pixels [T bx - 6, T bx + T + 6] squared (0 outside the image: never used by a pixel inside)
+  const int ox0 = PM_T0 * bx - 6, oy0 = PM_T0 * by - 6;
+  for (int i = tid; i < PM_S0 * PM_S0; i += 256) {
+    const int ly = i / PM_S0, lx = i - ly * PM_S0;
+    const int gx = ox0 + lx, gy = oy0 + ly;
+    l0[i] = (gx >= 0 && gy >= 0 && gx < W0 && gy < H0) ? a.depth[0][(size_t)gy * W0 + gx] : (unsigned short)0;
+  }
+  __syncthreads();
+  // level 1: [T/2 bx - 2, T/2 bx + T/2 + 2] squared
+  const int ox1 = PM_T1 * bx - 2, oy1 = PM_T1 * by - 2;
+  for (int i = tid; i < PM_S1 * PM_S1; i += 256) {
+    const int ly = i / PM_S1, lx = i - ly * PM_S1;
+    const int x = ox1 + lx, y = oy1 + ly;
+    int v = 0;
+    if (x >= 0 && y >= 0 && x < W1 && y < H1) {
+      v = pm_pyrdown(l0, PM_S0, ox0, oy0, W0, H0, x, y);
+      if (lx >= 2 && lx < 2 + PM_T1 && ly >= 2 && ly < 2 + PM_T1) d1[(size_t)y * W1 + x] = (unsigned short)v;  // (the block's own tile)
+    }
+    l1[i] = (unsigned short)v;
+  }
+  __syncthreads();
+  // level 2: [T/4 bx, T/4 bx + T/4] squared
+  const int ox2 = PM_T2 * bx, oy2 = PM_T2 * by;
+  if (tid < PM_S2 * PM_S2) {
+    const int ly = tid / PM_S2, lx = tid - ly * PM_S2;
+    const int x = ox2 + lx, y = oy2 + ly;
+    int v = 0;
+    if (x < W2 && y < H2) {
+      v = pm_pyrdown(l1, PM_S1, ox1, oy1, W1, H1, x, y);
+      if (lx < PM_T2 && ly < PM_T2) d2[(size_t)y * W2 + x] = (unsigned short)v;
+    }
+    l2[tid] = (unsigned short)v;
+  }
+  __syncthreads();
+  // the maps: T x T pixels of level 0, a quarter as many of level 1, a sixteenth of level 2
+  for (int i = tid; i < PM_T0 * PM_T0; i += 256) {
+    const int u = PM_T0 * bx + (i % PM_T0), v = PM_T0 * by + (i / PM_T0);
+    if (u < W0 && v < H0) pm_maps(l0, PM_S0, ox0, oy0, W0, H0, a.in[0], u, v, a.vmap[0], a.nmap[0]);
+  }
+  for (int i = tid; i < PM_T1 * PM_T1; i += 256) {
+    const int u = PM_T1 * bx + (i % PM_T1), v = PM_T1 * by + (i / PM_T1);
+    if (u < W1 && v < H1) pm_maps(l1, PM_S1, ox1, oy1, W1, H1, a.in[1], u, v, a.vmap[1], a.nmap[1]);
+  }
+  if (tid < PM_T2 * PM_T2) {
+    const int u = PM_T2 * bx + (tid % PM_T2), v = PM_T2 * by + (tid / PM_T2);
+    if (u < W2 && v < H2) pm_maps(l2, PM_S2, ox2, oy2, W2, H2, a.in[2], u, v, a.vmap[2], a.nmap[2]);
+  }
+}
+void launch_pyramid_maps(hipStream_t s, uint16_t* const* depth, const ImgLevel* lv, float* const* vmap, float* const* nmap) {
+  static_assert(HSK_NLEVELS == 3, "k_pyramid_maps holds three levels");
+  PyramidArgs a;
+  for (int l = 0; l < HSK_NLEVELS; ++l) {
+    a.depth[l] = depth[l];
+    a.vmap[l] = vmap[l];
+    a.nmap[l] = nmap[l];
+    a.W[l] = lv[l].W;
+    a.H[l] = lv[l].H;
+    a.in[l] = lv[l].in;
+    a.first_block[l] = 0;
+  }
+  a.first_block[HSK_NLEVELS] = 0;
+  hipLaunchKernelGGL(k_pyramid_maps, dim3((lv[0].W + PM_T0 - 1) / PM_T0, (lv[0].H + PM_T0 - 1) / PM_T0), dim3(64, 4), 0, s, a, depth[1], depth[2]);
 }
 
 // tranformMaps (A.2, first frame): v_g = R v + t, n_g = R n, pose taken from the device state
