@@ -205,6 +205,19 @@ static __device__ __forceinline__ float hsk_dot3(float ax, float ay, float az, f
   return (ax * bx + ay * by) + az * bz;
 }
 
+// ---- the tile tables of a frame (one allocation per image-buffer set: launch_tile_max / launch_bilateral_scale fill the raw
+// tables, launch_tile_tables the derived ones); offsets in floats.  n16 / n8: tiles of 16 / 8 pixels.
+//   [0, n16) raw 16-px max, [n16, 2 n16) raw 16-px min (0 when a pixel of the tile has no depth), [2 n16, 4 n16) the dilated table
+//   then, as float2: the 8-px table (n8), the 4-px table (4 n8), their nine window shapes each (45 n8), the sparse 16-px table
+//   (16 n16) -- in the 8-px / 4-px tables and their windows .y is the minimum over the pixels WITH depth, negated when a
+//   pixel of the tile (window) has none
+//   then the validity mask (round 5): one bit per pixel, 1 = no depth (or outside the image), rows of hsk_mask_pitch32 words
+__host__ __device__ static inline size_t hsk_tiles_n16(int W, int H) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
+__host__ __device__ static inline size_t hsk_tiles_n8(int W, int H) { return (size_t)((W + 7) / 8) * ((H + 7) / 8); }
+__host__ __device__ static inline int hsk_mask_pitch32(int W) { return (W + 31) / 32 + 1; }  // (+1: a box's two words are always there)
+__host__ __device__ static inline size_t hsk_tiles_mask_offset(int W, int H) { return 4 * hsk_tiles_n16(W, H) + 2 * 50 * hsk_tiles_n8(W, H) + 2 * 16 * hsk_tiles_n16(W, H); }
+__host__ __device__ static inline size_t hsk_tiles_floats(int W, int H) { return hsk_tiles_mask_offset(W, H) + (size_t)hsk_mask_pitch32(W) * (size_t)(((H + 15) / 16) * 16); }
+
 // launchers implemented in the kernel translation units
 struct ImgLevel {
   int W, H;

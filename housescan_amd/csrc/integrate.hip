@@ -37,12 +37,23 @@
 #endif
 
 __global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float* __restrict__ tmax,
-                           float* __restrict__ tmin, int tw) {
+                           float* __restrict__ tmin, int tw, unsigned short* __restrict__ vmask16) {
   __shared__ float shx[4], shn[4];
   const int tx = blockIdx.x, ty = blockIdx.y;
   const int x = tx * HSK_TILE + (threadIdx.x & 15), y = ty * HSK_TILE + (threadIdx.x >> 4);
   const bool in = x < W && y < H;
   const float v = in ? scaled[y * W + x] : 0.0f;
+  {  // the validity mask, as k_bilateral_scale writes it (1 = no depth or outside the image)
+    const unsigned long long inv = __ballot(v == 0.0f);
+    if ((threadIdx.x & 63) == 0) {
+      const int pitch16 = 2 * hsk_mask_pitch32(W);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = ty * HSK_TILE + (int)(threadIdx.x >> 6) * 4 + r;
+        if (yy < H) vmask16[(size_t)yy * pitch16 + tx] = (unsigned short)(inv >> (16 * r));
+      }
+    }
+  }
   float mx = v, mn = v;  // a pixel outside the image or without depth makes the tile minimum 0 ("not all valid")
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -64,7 +75,7 @@ __global__ void k_tile_max(const float* __restrict__ scaled, int W, int H, float
 void launch_tile_max(hipStream_t s, const float* scaled, int W, int H, float* tiles) {
   const int tw = (W + HSK_TILE - 1) / HSK_TILE, th = (H + HSK_TILE - 1) / HSK_TILE;
   const int n = tw * th;
-  hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tiles, tiles + n, tw);
+  hipLaunchKernelGGL(k_tile_max, dim3(tw, th), dim3(256), 0, s, scaled, W, H, tiles, tiles + n, tw, (unsigned short*)(tiles + hsk_tiles_mask_offset(W, H)));
 }
 
 // Fine tile tables for the second classification level: per 8x8-pixel tile and per 4x4-pixel tile the (max,
@@ -77,24 +88,29 @@ __global__ void k_tile_fine(const float* __restrict__ scaled, int W, int H, floa
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= fw * fh) return;
   const int ty = t / fw, tx = t - ty * fw;
+  // (.y: the minimum over the pixels WITH depth, negated when a pixel of the tile has none -- hsk_dev.h, the tile tables)
   float mx = 0.0f, mn = 1e30f;
+  bool hole = false;
 #pragma unroll
   for (int qy = 0; qy < 2; ++qy)
 #pragma unroll
     for (int qx = 0; qx < 2; ++qx) {
       float qmx = 0.0f, qmn = 1e30f;
+      bool qhole = false;
       for (int dy = 0; dy < 4; ++dy)
         for (int dx = 0; dx < 4; ++dx) {
           const int x = tx * HSK_FTILE + qx * 4 + dx, y = ty * HSK_FTILE + qy * 4 + dy;
           const float v = (x < W && y < H) ? scaled[(size_t)y * W + x] : 0.0f;  // outside the image: never "all valid"
           qmx = fmaxf(qmx, v);
-          qmn = fminf(qmn, v);
+          qmn = v != 0.0f ? fminf(qmn, v) : qmn;
+          qhole = qhole | (v == 0.0f);
         }
-      qtab[(size_t)(2 * ty + qy) * (2 * fw) + (2 * tx + qx)] = make_float2(qmx, qmn);
+      qtab[(size_t)(2 * ty + qy) * (2 * fw) + (2 * tx + qx)] = make_float2(qmx, qhole ? -qmn : qmn);
       mx = fmaxf(mx, qmx);
       mn = fminf(mn, qmn);
+      hole = hole | qhole;
     }
-  ftab[t] = make_float2(mx, mn);
+  ftab[t] = make_float2(mx, hole ? -mn : mn);
 }
 
 // The second level needs the (max, min) of the depth over the tiles its pixel box touches: nx x ny tiles, nx, ny <= 3,
@@ -128,14 +144,16 @@ __global__ void k_tile_tables(const float* __restrict__ tmax, const float* __res
     const int nx = shape % 3 + 1, ny = shape / 3 + 1;
     const int ty = t / tbw, tx = t - ty * tbw;
     float mx = 0.0f, mn = 1e30f;
+    bool hole = false;
     for (int a = 0; a < ny; ++a)
       for (int b = 0; b < nx; ++b) {
         const float2 v = tab[min(ty + a, tbh - 1) * tbw + min(tx + b, tbw - 1)];
         mx = fmaxf(mx, v.x);
-        mn = fminf(mn, v.y);
+        mn = fminf(mn, fabsf(v.y));
+        hole = hole | (v.y < 0.0f);
       }
     float2* __restrict__ win = fine ? fwin + (size_t)9 * fw * fh : fwin;
-    win[(size_t)shape * tbw * tbh + t] = make_float2(mx, mn);
+    win[(size_t)shape * tbw * tbh + t] = make_float2(mx, hole ? -mn : mn);
   } else {
     if (t >= tw * th) return;
     const int lv = job - 18;
@@ -776,7 +794,8 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
                                                    unsigned* __restrict__ flags,
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
-                                                   const float2* __restrict__ qtab, IntegrateConst k, const int2* __restrict__ zint) {
+                                                   const float2* __restrict__ qtab, IntegrateConst k, const int2* __restrict__ zint,
+                                                   const unsigned* __restrict__ vmask, int mpitch) {
   // Most of the launch's waves have nothing to do -- their wave-chunk lies outside the view frustum, is wholly occluded, or
   // is wholly free space already recorded in its chunk byte -- and what they execute before they find that out is pure
   // overhead: the test comes FIRST and runs on what arrives with the wave -- the arguments preloaded into SGPRs (the
@@ -897,6 +916,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     //      pixel box of the four projected corners (+-1 px for rounding) holds all 16 pixels; its exact min / max depth
     //      comes from the undilated 4-px or 8-px tile table (<= 3x3 tiles).  Every block decided is one less entry for pass B.
     bool in_any_s[NS], ok2_s[NS];
+    unsigned box_s[NS];
     float2 t9_s[NS];
     float dlo_s[NS], dhi_s[NS];
     float cax[2], cay[2], caz[2], pn_lo, pn_hi;
@@ -918,6 +938,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       in_any_s[sidx] = actv[sidx] & (zb + 3 >= zl) & (zb <= zh) & active;
       in_all_s[sidx] = actv[sidx] & (zb >= zl) & (zb + 3 <= zh) & active;
       ok2_s[sidx] = false;
+      box_s[sidx] = 0u;
       t9_s[sidx] = make_float2(0.0f, 0.0f);
       dlo_s[sidx] = dhi_s[sidx] = 0.0f;
       if (!actv[sidx]) continue;  // wave-uniform
@@ -938,10 +959,20 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
         vmin = fminf(vmin, vq);
         vmax = fmaxf(vmax, vq);
       }
-      umin -= 1.0f; vmin -= 1.0f; umax += 1.0f; vmax += 1.0f;
+      // The PIXELS of the 16 voxels: a voxel's pixel is the nearest integer to its projection, the projections lie between
+      // the corners', and these corner values differ from what the exact rule computes by rounding errors of 1e-4 px at
+      // most -- so the pixels lie in [rint(umin - 1/64), rint(umax + 1/64)].  (Round 5: the box was floor(umin - 1) ..
+      // floor(umax + 1), two pixels more in either direction, which for the typical block -- 4 voxels across, ONE row -- is
+      // a box of 11 x 4 pixels where 9 x 2 hold them all: more tiles under it, fewer decisions, and with holes in the depth
+      // image three times the chance of meeting one.)
+      const float ue = 0.015625f;
+      const bool front = zmn > 0.05f;
+      const int iu0 = (int)rintf(fminf(fmaxf(front ? umin - ue : -8.0f, -8.0f), 65536.0f)), iu1 = (int)rintf(fminf(fmaxf(front ? umax + ue : -8.0f, -8.0f), 65536.0f));
+      const int iv0 = (int)rintf(fminf(fmaxf(front ? vmin - ue : -8.0f, -8.0f), 65536.0f)), iv1 = (int)rintf(fminf(fmaxf(front ? vmax + ue : -8.0f, -8.0f), 65536.0f));
       // the 4-px table when the box spans at most 3 x 3 of its tiles, else the 8-px one (at most 3 x 3 again, else undecided)
-      const bool in_img = (zmn > 0.05f) & (umin >= 0.0f) & (vmin >= 0.0f) & (umax <= (float)(W - 1)) & (vmax <= (float)(H - 1));
-      const int iu0 = (int)umin, iv0 = (int)vmin, iu1 = (int)umax, iv1 = (int)vmax;
+      const bool in_img = front & (iu0 >= 0) & (iv0 >= 0) & (iu1 <= W - 1) & (iv1 <= H - 1);
+      // (the box, for the validity mask below: 10 + 9 bits of its corner, 5 + 2 of its extent; wider or taller: no look-up)
+      box_s[sidx] = ((iu1 - iu0 < 32) & (iv1 - iv0 < 4) & in_img & (W <= 1024) & (H <= 512)) ? ((unsigned)iu0 | ((unsigned)iv0 << 10) | ((unsigned)(iu1 - iu0) << 19) | ((unsigned)(iv1 - iv0) << 24) | (1u << 26)) : 0u;
       const bool fine = ((iu1 >> 2) <= (iu0 >> 2) + 2) & ((iv1 >> 2) <= (iv0 >> 2) + 2);
       const int sh = fine ? 2 : 3;
       const int tu0 = iu0 >> sh, tv0 = iv0 >> sh;
@@ -973,7 +1004,31 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       const bool dead2 = ok2_s[sidx] & (dlo_s[sidx] * 0.99999f - t9_s[sidx].x > k.cull_thr2);
-      const bool free2 = in_all_s[sidx] & ok2_s[sidx] & (dhi_s[sidx] * 1.00001f + k.free_thr2 <= t9_s[sidx].y);
+      // free space: every pixel of the box WITH depth lies far enough behind the block (.y: the minimum over those,
+      // negated when a pixel under the tiles has none) -- and every pixel of the box has depth: by the tiles when they say
+      // so, else by the validity mask over the box itself.  A depth image with holes (a real sensor's: 2 % of the pixels
+      // in SURVEY.md 8(d)'s noise run) left no tile window whole, and every block of free space went to pass B.
+      const bool free2v = in_all_s[sidx] & ok2_s[sidx] & (dhi_s[sidx] * 1.00001f + k.free_thr2 <= fabsf(t9_s[sidx].y));
+      bool whole = t9_s[sidx].y > 0.0f;
+      const bool ask = free2v & !whole & (box_s[sidx] != 0u);
+      if (__ballot(ask) != 0ull) {
+        unsigned bad = 1u;
+        if (ask) {
+          const unsigned bx = box_s[sidx];
+          const int iu0 = (int)(bx & 1023u), iv0 = (int)((bx >> 10) & 511u), wd = (int)((bx >> 19) & 31u), ht = (int)((bx >> 24) & 3u);
+          const unsigned* __restrict__ row = vmask + (size_t)iv0 * mpitch + (iu0 >> 5);
+          const unsigned long long sel = ((wd == 31 ? 0ull : (1ull << (wd + 1))) - 1ull) << (iu0 & 31);
+          unsigned long long any = 0ull;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const unsigned* __restrict__ rp = row + (size_t)min(h, ht) * mpitch;
+            any |= ((unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32)) & sel;
+          }
+          bad = any != 0ull ? 1u : 0u;
+        }
+        whole = whole | (ask & (bad == 0u));
+      }
+      const bool free2 = free2v & whole;
       free44_s[sidx] = free2;
       other_s[sidx] = in_any_s[sidx] & !dead2 & !free2;
       need1 = need1 | (in_any_s[sidx] & !ok2_s[sidx]);
@@ -1307,12 +1362,8 @@ void launch_tile_fine(hipStream_t s, const float* scaled, int W, int H, float* t
   hipLaunchKernelGGL(k_tile_fine, dim3((fw * fh + 255) / 256), dim3(256), 0, s, scaled, W, H, ftab, fw, fh, qtab);
   launch_tile_tables(s, W, H, tiles);
 }
-// bytes of a frame's tile tables: 16-px raw (max, min) and dilated; 8-px and 4-px tables with nine window shapes each; the sparse table
-size_t tile_table_bytes(int W, int H) {
-  const size_t n16 = (size_t)((W + HSK_TILE - 1) / HSK_TILE) * ((H + HSK_TILE - 1) / HSK_TILE);
-  const size_t n8 = (size_t)((W + HSK_FTILE - 1) / HSK_FTILE) * ((H + HSK_FTILE - 1) / HSK_FTILE);
-  return n16 * 4 * sizeof(float) + n8 * 50 * sizeof(float2) + n16 * HSK_SPARSE_LEVELS * HSK_SPARSE_LEVELS * sizeof(float2);
-}
+// bytes of a frame's tile tables (layout: hsk_dev.h)
+size_t tile_table_bytes(int W, int H) { return hsk_tiles_floats(W, H) * sizeof(float); }
 
 // entries of the z-range tables: one int2 per lane column, then one per pass-A workgroup footprint (64 x 16 voxels), then
 // an int4 per wave footprint (64 x 4 voxels: four per workgroup)
@@ -1362,6 +1413,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   unsigned char* cflag = (unsigned char*)(wvz + (size_t)col_blocks * 4);           // ... and the frame's verdict per wave-chunk
   const IntegrateConst kc = integrate_const(vp, W, H, in);
   const float2* sparse = (const float2*)(tmax + 4 * tw * th) + (size_t)50 * fw * fh;
+  const unsigned* vmask = (const unsigned*)(tmax + hsk_tiles_mask_offset(W, H));  // validity of every pixel (k_bilateral_scale / k_tile_max)
   const CoarseArgs ca = {cflag, (count_only || uni == nullptr) ? nullptr : uni + hsk_lane_sum_bytes(vp), sparse, zchunk, kc.free_thr2, kc.cull_thr2};
   const RingOut quiet_ring = {nullptr, nullptr, nullptr};
   const RingOut early_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;
@@ -1382,19 +1434,19 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   if (count_only) {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     else
       hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   } else {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     else
       hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint);
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags);
   }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
                                                          const float* __restrict__ wc_tab,
                                                          unsigned short* __restrict__ dst, float* __restrict__ scaled,
                                                          float* __restrict__ tmax, float* __restrict__ tmin, float2* __restrict__ ftab,
-                                                         float2* __restrict__ qtab, int fw, int fh) {
+                                                         float2* __restrict__ qtab, int fw, int fh, unsigned short* __restrict__ vmask16) {
   // The tile holds 4 x depth: the tap's |difference| then IS the byte offset of its range weight (one v_sad_u32, one
   // v_min_u32, no shift), and sum1 comes out scaled by exactly 4: a power of two passes through the rounding of every
   // normal product and sum, and in the subnormal range (weights down to exp(-145) are in the table) an integer depth times
@@ -71,6 +71,19 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
   }
   sct[threadIdx.y][threadIdx.x] = sc;
   {
+    // the validity mask (one bit per pixel, 1 = no depth or outside the image): the wave's four rows of 16 pixels are the
+    // four halfwords of its ballot
+    const unsigned long long inv = __ballot(sc == 0.0f);
+    if ((tid & 63) == 0) {
+      const int pitch16 = 2 * hsk_mask_pitch32(W);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = by + (tid >> 6) * 4 + r;
+        if (yy < H) vmask16[(size_t)yy * pitch16 + blockIdx.x] = (unsigned short)(inv >> (16 * r));
+      }
+    }
+  }
+  {
     float mx = sc, mn = sc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -90,28 +103,33 @@ __global__ __launch_bounds__(256) void k_bilateral_scale(const unsigned short* _
     // ... and the undilated 4-px and 8-px tables of pass A's pixel-box level (round 5: a launch of their own before, one
     // THREAD per 8-px tile walking 64 floats at a stride of 8 -- 15 us; here the tile is already in the block): the block's
     // sixteen 4-px tiles by sixteen threads, its four 8-px tiles from those (same values, same order-free max / min)
+    // (.y: the minimum over the pixels WITH depth, negated when a pixel of the tile has none -- hsk_dev.h, the tile tables)
     if (tid < 16) {
       const int qx = tid & 3, qy = tid >> 2;
       float mx = 0.0f, mn = 1e30f;
+      bool hole = false;
 #pragma unroll
       for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
           const float v = sct[qy * 4 + dy][qx * 4 + dx];
           mx = fmaxf(mx, v);
-          mn = fminf(mn, v);
+          mn = v != 0.0f ? fminf(mn, v) : mn;
+          hole = hole | (v == 0.0f);
         }
-      q4[qy][qx] = make_float2(mx, mn);
+      const float2 e = make_float2(mx, hole ? -mn : mn);
+      q4[qy][qx] = e;
       const int gx = blockIdx.x * 4 + qx, gy = blockIdx.y * 4 + qy;
-      if (gx < 2 * fw && gy < 2 * fh) qtab[(size_t)gy * (2 * fw) + gx] = make_float2(mx, mn);
+      if (gx < 2 * fw && gy < 2 * fh) qtab[(size_t)gy * (2 * fw) + gx] = e;
     }
     __syncthreads();
     if (tid < 4) {
       const int ex = tid & 1, ey = tid >> 1;
       const float2 a = q4[2 * ey][2 * ex], b = q4[2 * ey][2 * ex + 1], c = q4[2 * ey + 1][2 * ex], d = q4[2 * ey + 1][2 * ex + 1];
       const int gx = blockIdx.x * 2 + ex, gy = blockIdx.y * 2 + ey;
-      if (gx < fw && gy < fh)
-        ftab[(size_t)gy * fw + gx] = make_float2(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fminf(fminf(a.y, b.y), fminf(c.y, d.y)));
+      const float mn = fminf(fminf(fabsf(a.y), fabsf(b.y)), fminf(fabsf(c.y), fabsf(d.y)));
+      const bool hole = (a.y < 0.0f) | (b.y < 0.0f) | (c.y < 0.0f) | (d.y < 0.0f);
+      if (gx < fw && gy < fh) ftab[(size_t)gy * fw + gx] = make_float2(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), hole ? -mn : mn);
     }
   }
   if (!inside) return;
@@ -154,7 +172,7 @@ void launch_bilateral_scale(hipStream_t s, const uint16_t* src, int W, int H, In
   float2* ftab = (float2*)(tiles + 4 * grid.x * grid.y);
   float2* qtab = ftab + (size_t)fw * fh;
   hipLaunchKernelGGL(k_bilateral_scale, grid, block, 0, s, src, W, H, in, wsv, wc, dst, scaled, tiles,
-                     tiles + grid.x * grid.y, ftab, qtab, fw, fh);
+                     tiles + grid.x * grid.y, ftab, qtab, fw, fh, (unsigned short*)(tiles + hsk_tiles_mask_offset(W, H)));
 }
 
 // scaleDepth alone (stage-level integrate entry point)
