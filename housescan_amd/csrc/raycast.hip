@@ -155,6 +155,10 @@ extern "C" int hsk_debug_rc_times(unsigned long long* out, int n) {
 #ifndef RC_GROUP
 #define RC_GROUP 4     // march steps located and gathered together (k_raycast)
 #endif
+// A wave's pixel tile is TW x (64 / TW), a template parameter of the kernel (round 5; profiles/r05/raycast_notes.md): 8 x 8,
+// or 16 x 4 for volumes far beyond the Infinity Cache -- x-adjacent rays gather x-adjacent voxels, four of which share a
+// 64-B block: 1024^3 71.6 -> 66.3 us, 512^3 56.8 -> 57.1 (kept at 8 x 8); 4 x 16: 60.8 / 84.6 us.
+#define RC_TH (64 / RC_TW)
 #define RC_STAGE_MAX 4  // 16-B loads per thread: 4 KiB / (64 x 16 B); larger bitfields take the loop below
 // minimum over the 64 lanes of a wave whose lanes are ALL active, as a wave-uniform value: four DPP steps inside each row of
 // 16 lanes, two row broadcasts, one v_readlane (six ds_bpermute round trips through the LDS crossbar before)
@@ -200,7 +204,7 @@ static __device__ __forceinline__ const char* rc_kernarg() {
   return ka;
 }
 // SLAB: this context stores / owns only part of the z range (multi-GPU).
-template <bool SLAB>
+template <bool SLAB, int RC_TW>
 __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
   const short2* __restrict__ vol = a.vol;
   const TrackState* __restrict__ st = a.st;
@@ -235,15 +239,15 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
   const int lane = threadIdx.x & 63;
 #endif
   const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+  const int tiles_x = (W + RC_TW - 1) / RC_TW, tiles_y = (H + RC_TH - 1) / RC_TH;
   // Tile rows are dispatched from the top and bottom edges of the image inwards (0, last, 1, last - 1, ...): the rays of
   // the border rows meet floor and ceiling at grazing angles and march longest, and a wave dispatched last onto a SIMD
   // that already holds its share of waves finishes last -- with the rows in image order the launch ended with exactly
   // those tiles (tools/rc_timing.sh).  Scheduling only.  Measured 512^3 / 1024^3: 90.6 / 117.9 -> 86.8 / 110.8 us.
   const int ty_lin = tile / tiles_x;
   const int ty = (ty_lin & 1) ? (tiles_y - 1 - (ty_lin >> 1)) : (ty_lin >> 1);
-  const int x = (tile % tiles_x) * 8 + (lane & 7);
-  const int y = ty * 8 + (lane >> 3);
+  const int x = (tile % tiles_x) * RC_TW + (lane % RC_TW);
+  const int y = ty * RC_TH + (lane / RC_TW);
   if (!SLAB && ring.slots && blockIdx.x == 0 && threadIdx.x == 0) {
     // the tracker state is final once the ICP has ended (nothing after it writes it): report it to the host now, also
     // for a lost or dropped frame, which returns just below
@@ -615,8 +619,8 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
     // taps arrive by lane shuffles instead of a second launch reading the maps back.
     float m[6] = {vx, vy, vz, nx, ny, nz};
     float l1[6], l2[6];
-    pyramid_step(m, 1, 8, l1);
-    pyramid_step(l1, 2, 16, l2);
+    pyramid_step(m, 1, RC_TW, l1);
+    pyramid_step(l1, 2, 2 * RC_TW, l2);
     const int w1 = W >> 1, w2 = W >> 2;
     const size_t P1 = (size_t)w1 * (H >> 1), P2 = (size_t)w2 * (H >> 2);
     if (((x | y) & 1) == 0) {
@@ -634,7 +638,9 @@ __global__ __launch_bounds__(RC_BLOCK, RC_WPE) void k_raycast(RcArgs a) {
 
 void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const VolParams& vp, int W, int H, Intr in,
                     float* vmap, float* nmap, int* keys, const unsigned* flags, const MapPyramid* pyramid, const RingOut* ring) {
-  const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
+  // (the wide tile wants whole tiles: the fused pyramid's shuffles assume them)
+  const int tw_px = (vp.stream_nt && (W % 16) == 0 && (H % 4) == 0) ? 16 : 8;
+  const int tiles = ((W + tw_px - 1) / tw_px) * ((H + 64 / tw_px - 1) / (64 / tw_px));
   dim3 block(RC_BLOCK);
   dim3 grid((tiles + RC_BLOCK / 64 - 1) / (RC_BLOCK / 64));
   const int words = hsk_flag_words(vp);
@@ -657,10 +663,15 @@ void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const 
   a.tail.pyr = (!slab && pyramid) ? *pyramid : none;
   a.tail.W = W;
   a.tail.H = H;
-  if (slab)
-    hipLaunchKernelGGL(k_raycast<true>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
+  const size_t lds = (size_t)(words + HSK_SUPER_WORDS) * 4;
+  if (slab && tw_px == 16)
+    hipLaunchKernelGGL((k_raycast<true, 16>), grid, block, lds, s, a);
+  else if (slab)
+    hipLaunchKernelGGL((k_raycast<true, 8>), grid, block, lds, s, a);
+  else if (tw_px == 16)
+    hipLaunchKernelGGL((k_raycast<false, 16>), grid, block, lds, s, a);
   else
-    hipLaunchKernelGGL(k_raycast<false>, grid, block, (size_t)(words + HSK_SUPER_WORDS) * 4, s, a);
+    hipLaunchKernelGGL((k_raycast<false, 8>), grid, block, lds, s, a);
 }
 // the fused pyramid needs complete 8x8 tiles and a single-device volume
 bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H) {
