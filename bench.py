@@ -269,8 +269,8 @@ def readout_block(trk, n, with_download=True):
     trk.synchronize()
     t1 = time.perf_counter()
     out = {"flush_weights_ms": round((t1 - t0) * 1e3, 3),
-           "note": "host clock; flush = the free-space weights held in the summaries written back into the volume (once: the "
-                   "read-outs after it find them current); the timed frames never pay it"}
+           "note": "host clock; flush = the free-space weights held in the summaries written back into the volume: only hsk_download_tsdf "
+                   "needs it (the products ask whether a weight is zero, which no deferred weight is); the timed frames never pay it"}
     first = {}
 
     def timed(name, fn):
@@ -611,7 +611,8 @@ def run_single(args, hsk, torch, local_rank):
                                       "frame), %d frames; worst single frame %.2f ms" % (len(hf), float(per_h.max()) * 1e3))
     if not args.no_readout:
         out["readout_ms"] = readout_block(trk, n)
-        # the deferred weights' worst case: a host that reads a product after EVERY frame pays the flush every frame
+        # the deferred weights' worst case: a host that DOWNLOADS THE VOLUME after every frame pays the flush every frame (the
+        # products -- cloud, meshes -- no longer flush: they only ask whether a weight is zero, which no deferred weight is)
         fl = out["readout_ms"]["flush_weights_ms"] * 1e3
         out["roofline"]["integrate_plus_flush_every_frame_us"] = round(out["stage_us"]["integrate"] + fl, 1)
         out["roofline"]["frac_with_flush_every_frame"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / ((out["stage_us"]["integrate"] + fl) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)

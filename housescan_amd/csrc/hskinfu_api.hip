@@ -1308,7 +1308,11 @@ static int extract_product(hsk_ctx* k, int kind, size_t elem_bytes, float* out, 
     HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
     HIPCHK(k, hipMalloc((void**)&k->d_rowoff, hsk_scan_scratch_entries(nrows) * 8));
   }
-  flush_weights(k);
+  // (NO flush of the deferred weights here, round 5: the products ask of a weight only whether it is zero, and a weight the
+  // summaries hold ahead of the volume's copy is never that -- a block leaves "never observed" with a store of (+1, 1),
+  // and every deferred state has all 16 weights >= 1 in the volume itself; the TSDF values are always current.  Only
+  // hsk_download_tsdf, which hands the weights out, brings them up to date.  A host that shows a cloud after every
+  // frame pays for the cloud, not for rewriting the frustum's free space.)
   if (!(k->ro_kind == kind && k->ro_epoch == k->vol_epoch)) {
     k->ro_kind = 0;
     count();

@@ -187,6 +187,7 @@ struct CoarseArgs {
   unsigned char* cflag;
   unsigned char* cs;
   const float2* sparse;  // the sparse table (k_tile_tables) of the frame's 16-px tiles
+  unsigned dirty_off;    // the chunks' dirty bytes sit this far behind their pending bytes
   int zchunk;  // planes per chunk of THIS launch (vp.zchunk, or all stored planes of a thinner slab)
   float free_thr, cull_thr;
 };
@@ -421,6 +422,7 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
           const unsigned c = ca.cs[ci];
           if (c >= 1u && c < 255u) {  // one more pending observation of the whole chunk: the frame's work on it is done
             ca.cs[ci] = (unsigned char)(c + 1u);
+            ca.cs[ca.dirty_off + ci] = 1;
             verdict = HSK_CF_SKIP;
           }
         }
@@ -517,6 +519,10 @@ static __host__ __device__ __forceinline__ size_t hsk_chunk_count(const VolParam
 static __host__ __device__ __forceinline__ size_t hsk_lane_sum_bytes(const VolParams& vp) {  // lane-block bytes; the chunk bytes follow
   return hsk_chunk_count(vp) * (size_t)(64 * (vp.zchunk >> 2));
 }
+// ... and behind the chunk bytes one DIRTY byte per wave-chunk: 1 = a weight of the chunk may be ahead of the volume's copy
+// (a byte was ticked, or an observation is pending in the chunk byte) since the last flush -- the flush (k_summaries<true>)
+// rewrites only such chunks: a host that reads a product after every frame pays for the frame's free space, not for the volume
+static __host__ __device__ __forceinline__ size_t hsk_chunk_bytes_padded(const VolParams& vp) { return (hsk_chunk_count(vp) + 255) & ~(size_t)255; }
 template <int NS>
 static __host__ __device__ __forceinline__ size_t hsk_sum_index_ns(const VolParams& vp, int x0, int y, int zb) {
   static_assert(NS == 2 || NS == 4, "8 or 16 planes per chunk");
@@ -1197,6 +1203,8 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
         const bool whole = (zbeg + vp.zchunk <= vp.nzs) & (zchunk == vp.zchunk);
         const unsigned cnew = (whole && __ballot(quiet) == ~0ull) ? 1u : 0u;
         if (cnew != cbyte && lane == 0) (uni + hsk_lane_sum_bytes(vp))[lin * 4u + wq] = (unsigned char)cnew;
+        // (a summary of the chunk moved: some weight may now be ahead of the volume's copy -- the flush's business)
+        if (__ballot(new16 != sum16) != 0ull && lane == 0) (uni + hsk_lane_sum_bytes(vp) + hsk_chunk_bytes_padded(vp))[lin * 4u + wq] = 1;
       }
     }
 #ifdef HSK_PA_TIMING
@@ -1270,7 +1278,8 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
                                                                         int H, uint4* __restrict__ vol,
                                                                         const float* __restrict__ scaled, Intr in, VolParams vp,
                                                                         unsigned long long* __restrict__ counter,
-                                                                        unsigned* __restrict__ flags) {
+                                                                        unsigned* __restrict__ flags, unsigned long long qmag_x,
+                                                                        unsigned long long qmag_y) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
 #ifdef HSK_PB_TIMING
@@ -1325,8 +1334,12 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
     const unsigned id = id_next;
     id_next = entry_at(e0 + stride + lane);
     const unsigned lb = id & 0x0fffffffu;
-    const int x0 = (int)(lb % (unsigned)qx) * 4, y = (int)((lb / (unsigned)qx) % (unsigned)vp.Y);
-    const int zb = (int)(lb / ((unsigned)qx * (unsigned)vp.Y)) * 4;
+    // lb = ((zb / 4) * Y + y) * qx + x0 / 4, taken apart by multiplications (qmag = floor(2^40 / d) + 1: exact for every
+    // lb below 2^40 / d, i.e. for every volume the 28-bit ids admit; three integer divisions were ~75 instructions a trip)
+    const unsigned row = (unsigned)(((unsigned long long)lb * qmag_x) >> 40);
+    const unsigned zq = (unsigned)(((unsigned long long)row * qmag_y) >> 40);
+    const int x0 = (int)(lb - row * (unsigned)qx) * 4, y = (int)(row - zq * (unsigned)vp.Y);
+    const int zb = (int)zq * 4;
     cnt += detail_entry<COUNT_ONLY, DETAIL2_U>(id >> 28, x0, y, zb, vol, scaled, P, vp, W, H, in, flags);
 #ifdef HSK_PB_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1414,7 +1427,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const IntegrateConst kc = integrate_const(vp, W, H, in);
   const float2* sparse = (const float2*)(tmax + 4 * tw * th) + (size_t)50 * fw * fh;
   const unsigned* vmask = (const unsigned*)(tmax + hsk_tiles_mask_offset(W, H));  // validity of every pixel (k_bilateral_scale / k_tile_max)
-  const CoarseArgs ca = {cflag, (count_only || uni == nullptr) ? nullptr : uni + hsk_lane_sum_bytes(vp), sparse, zchunk, kc.free_thr2, kc.cull_thr2};
+  const CoarseArgs ca = {cflag, (count_only || uni == nullptr) ? nullptr : uni + hsk_lane_sum_bytes(vp), sparse, (unsigned)hsk_chunk_bytes_padded(vp), zchunk, kc.free_thr2, kc.cull_thr2};
   const RingOut quiet_ring = {nullptr, nullptr, nullptr};
   const RingOut early_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, fin, tmax,
@@ -1430,6 +1443,8 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned qcap = ((nblk + HSK_NQUEUES - 1) / HSK_NQUEUES) * 256u * (unsigned)((zchunk + 3) / 4);
   // n % grid.x = n - mulhi(n, gmagic) * grid.x for n < 2^16; 0 for a single x block (the kernel takes 0 for the remainder)
   const unsigned gmagic = grid.x > 1u ? (unsigned)(0x100000000ull / grid.x) + 1u : 0u;
+  // (pass B takes a queued lane-block id apart by multiplications: floor(2^40 / d) + 1 for d = X / 4 and d = Y)
+  const unsigned long long qmag_x = (1ull << 40) / (unsigned long long)(vp.X / 4) + 1ull, qmag_y = (1ull << 40) / (unsigned long long)vp.Y + 1ull;
   const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     if (vp.zchunk == 16)
@@ -1439,7 +1454,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
       hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
                          W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
-                       counter, flags);
+                       counter, flags, qmag_x, qmag_y);
   } else {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
@@ -1448,7 +1463,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
       hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
                          (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
-                       counter, flags);
+                       counter, flags, qmag_x, qmag_y);
   }
 }
 
@@ -1491,7 +1506,7 @@ void launch_rebuild_flags(hipStream_t s, const void* vol, const VolParams& vp, u
 // Summaries of a volume that was uploaded rather than integrated (both levels), and the reverse: the volume's weights
 // brought up to date.  One WAVE per wave-chunk, lane = the pass-A lane that owns the blocks (a block that reaches beyond
 // the last stored plane has no summary): the chunk's byte is read by every lane before lane 0 rewrites it.
-size_t uniform_bytes(const VolParams& vp) { return hsk_lane_sum_bytes(vp) + ((hsk_chunk_count(vp) + 255) & ~(size_t)255); }
+size_t uniform_bytes(const VolParams& vp) { return hsk_lane_sum_bytes(vp) + 2 * hsk_chunk_bytes_padded(vp); }
 size_t uniform_lane_bytes(const VolParams& vp) { return hsk_lane_sum_bytes(vp); }
 template <bool MATERIALIZE, int NS>
 __global__ __launch_bounds__(256) void k_summaries(uint4* __restrict__ vol, VolParams vp, unsigned char* __restrict__ uni) {
@@ -1504,7 +1519,9 @@ __global__ __launch_bounds__(256) void k_summaries(uint4* __restrict__ vol, VolP
   const int x0 = (fbx * 16 + w * 4 + (lane & 3)) * 4, y = fby * 16 + (lane >> 2);
   const bool active = x0 < vp.X && y < vp.Y;
   unsigned char* const cs = uni + hsk_lane_sum_bytes(vp);
+  unsigned char* const dirty = cs + hsk_chunk_bytes_padded(vp);
   unsigned char* const sum_at = uni + (cw * 64 + (size_t)lane) * NS;
+  if (MATERIALIZE && dirty[cw] == 0) return;  // nothing of this chunk is ahead of the volume (wave-uniform)
   if (!MATERIALIZE) {
     bool quiet = active;
 #pragma unroll
@@ -1520,7 +1537,10 @@ __global__ __launch_bounds__(256) void k_summaries(uint4* __restrict__ vol, VolP
       quiet = quiet && code >= 2u;
     }
     const bool all_quiet = __ballot(quiet) == ~0ull;
-    if (lane == 0) cs[cw] = (zc * vp.zchunk + vp.zchunk <= vp.nzs && all_quiet) ? 1 : 0;
+    if (lane == 0) {
+      cs[cw] = (zc * vp.zchunk + vp.zchunk <= vp.nzs && all_quiet) ? 1 : 0;
+      dirty[cw] = 0;  // (the summaries were just read off the volume)
+    }
     return;
   }
   const unsigned c = cs[cw];
@@ -1545,7 +1565,10 @@ __global__ __launch_bounds__(256) void k_summaries(uint4* __restrict__ vol, VolP
     }
   }
   // (the blocks stay quiet: a uniform block stays uniform, a rim block becomes 130 or 129)
-  if (kpend != 0u && lane == 0) cs[cw] = 1;
+  if (lane == 0) {
+    if (kpend != 0u) cs[cw] = 1;
+    dirty[cw] = 0;
+  }
 }
 void launch_rebuild_uniform(hipStream_t s, const void* vol, const VolParams& vp, unsigned char* uni) {
   const unsigned nb = (unsigned)((hsk_chunk_count(vp) + 3) / 4);

@@ -241,6 +241,33 @@ def test_gpu_marching_cubes_matches_oracle_bit_for_bit(oracle, hsk, synth_frames
 
 
 @pytest.mark.gpu
+def test_products_do_not_wait_for_the_deferred_weights(oracle, hsk, synth_frames):
+    """round 5: hsk_extract_cloud / hsk_extract_mesh[_cubes] no longer write the deferred free-space weights back first (a
+    product asks of a weight only whether it is zero, which no deferred weight is).  Taken BEFORE anything has flushed --
+    twelve tracked frames, then the products, then the download that does flush -- they must be the oracle's products of
+    that volume, and the same again afterwards."""
+    n = 128
+    trk = hsk.KinfuTracker(n=n)
+    for k in range(12):
+        trk.process_frame(synth_frames(k)[1])
+    cloud, n_cloud = trk.extract_cloud()
+    mesh, n_mesh = trk.extract_mesh()
+    cubes, n_cubes = trk.extract_mesh(cubes=True)
+    vol = trk.download_tsdf()   # (flushes)
+    assert int((vol[..., 1] > 1).sum()) > 100000   # weights were indeed running ahead of single observations
+    cfg = oracle.default_config(n)
+    o_cloud, o_n = oracle.extract_cloud(cfg, vol)
+    assert n_cloud == o_n > 1000 and np.array_equal(cloud.view(np.uint32), o_cloud.view(np.uint32))
+    o_mesh, o_nm = oracle.extract_mesh(cfg, vol)
+    assert n_mesh == o_nm and np.array_equal(mesh.view(np.uint32), o_mesh.view(np.uint32))
+    o_cubes, o_nc = oracle.extract_mesh(cfg, vol, cubes=True)
+    assert n_cubes == o_nc and np.array_equal(cubes.view(np.uint32), o_cubes.view(np.uint32))
+    again, n_again = trk.extract_cloud()
+    assert n_again == n_cloud and np.array_equal(again.view(np.uint32), cloud.view(np.uint32))
+    trk.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mesh_of_a_scan_is_consistently_oriented_and_lies_on_the_scene(hsk, tmp_path):
     """configs[2]-style scan at 256^3: the mesh has no inconsistently wound edge, its vertices sit on the
     synthetic scene's surfaces, and the .ply written from it welds to ~half as many vertices as triangles"""

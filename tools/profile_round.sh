@@ -24,6 +24,14 @@ for job in "256 300" "512 300" "1024 100"; do
   (cd $ROOT && timeout 1200 python3 tools/long_parity.py $1 $2 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_$1.txt)
   cat $OUT/long_parity_$1.txt
 done
+# ... on the noise run (sigma = 1.2 mm z^2, 2 % dropout), where the hole-aware paths of integrate do their work
+(cd $ROOT && timeout 1200 python3 tools/long_parity.py 512 300 --noise 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_noise_512.txt)
+cat $OUT/long_parity_noise_512.txt
+# the read-out kernels (not in the bench's timed region): kernel stats + host times at both sizes
+for v in 512 1024; do
+  (cd $ROOT && timeout 900 tools/readout_profile.sh $v > $OUT/readout_$v.txt 2>&1)
+  cp $ROOT/gpurun_out/readout_$v/kernel_stats.csv $OUT/readout_kernel_stats_$v.csv 2>/dev/null
+done
 # ... and of the z-slab group on this one device: 2 and 8 slabs with the direct exchange, 4 with the staged composites,
 # 2 with the row-sharded ICP (N slabs = one volume, bit for bit, at length)
 for job in "512 300 2 direct" "512 300 8 direct" "512 100 4 composite" "512 100 2 icp_allreduce" "1024 60 4 direct" "1024 60 8 direct"; do
