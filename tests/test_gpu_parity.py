@@ -10,6 +10,11 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The fuzz tests hold two assertions about what the suite's OWN seeds happen to produce (so many updates, so many lost
+# frames): they show that the seeds exercise what they are meant to, and say nothing about parity.  tools/fuzz_campaign.py,
+# which runs the same tests over hundreds of other seeds, switches them off -- so that every parity comparison behind them
+# still runs for every seed (a seed that tripped the expectation used to leave its volume and its pipelined run unchecked).
+SEED_EXPECTATIONS = True
 
 
 def bits(a):
@@ -141,7 +146,8 @@ def test_integrate_and_raycast_fuzz(hsk, oracle, seed):
         trk.integrate(depth, pose)
         assert_same_bits(trk.download_tsdf(), vol, f"tsdf, seed {seed} frame {k}")
         total += n_upd
-    assert total > 30000
+    if SEED_EXPECTATIONS:
+        assert total > 30000
     for k in range(3):
         pose = (_lookat_pose if k else _random_pose)(rng, size / 2, size * 0.5)
         vm, nm, keys = trk.raycast(pose, want_keys=True)
@@ -581,7 +587,8 @@ def test_tracker_fuzz_vs_oracle(hsk, oracle, synth_frames, seed):
         assert_same_bits(ph, po, f"seed {seed} pose frame {i}")
         want.append((po, oko))
     # (seeds 0 and 3 track through their garbage frames; the others lose 2-4 frames)
-    assert seed in (0, 3) or sum(not ok for _, ok in want[1:]) >= 2
+    if SEED_EXPECTATIONS:
+        assert seed in (0, 3) or sum(not ok for _, ok in want[1:]) >= 2
     assert_same_bits(trk.download_tsdf(), ot.volume(), "tsdf (tracker fuzz)")
     for level in range(3):
         assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"model vmap {level} (tracker fuzz)")

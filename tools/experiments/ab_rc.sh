@@ -1,5 +1,5 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
+source "$(dirname "$0")/../restore_default.sh"
 cd ${GRAFT_REPO_ROOT:-.}
 for v in "$@"; do
   touch housescan_amd/csrc/*.hip

@@ -1,5 +1,5 @@
 #!/bin/bash
-source tools/restore_default.sh
+source "$(dirname "$0")/../restore_default.sh"
 cd ${GRAFT_REPO_ROOT:-.}
 i=0
 for fl in "" "-mllvm -amdgpu-sched-strategy=max-ilp" "-mllvm -amdgpu-sched-strategy=max-memory-clause"; do

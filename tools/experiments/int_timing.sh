@@ -1,5 +1,5 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
+source "$(dirname "$0")/../restore_default.sh"
 # usage: tools/int_timing.sh [volume] ["extra -D flags"] -- per-wave life of integrate pass B (timing build)
 cd ${GRAFT_REPO_ROOT:-.}
 touch housescan_amd/csrc/integrate.hip housescan_amd/csrc/raycast.hip housescan_amd/csrc/extract.hip

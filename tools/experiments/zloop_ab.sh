@@ -1,5 +1,5 @@
 #!/bin/bash
-source tools/restore_default.sh
+source "$(dirname "$0")/../restore_default.sh"
 cd ${GRAFT_REPO_ROOT:-.}
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical"
 cp housescan_amd/libhskinfu.so /tmp/lib_default.so

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """The suite's two fuzz tests (tests/test_gpu_parity.py: random depth images from arbitrary poses into cubic / non-cubic / ragged
 volumes with the raycast of the result; streams that mix good frames with garbage, empty frames and jumps through the tracker,
-synchronous and pipelined) over MANY more seeds than the suite holds.  A seed counts as a parity failure when an assertion
-about bits, verdicts or counts fails; the tests' seed-specific expectations (so many updates, so many lost frames) are reported
-apart.   usage: tools/fuzz_campaign.py FIRST_SEED COUNT"""
+synchronous and pipelined) over MANY more seeds than the suite holds.  The tests' two seed-specific expectations (so many updates, so many lost frames: about the suite's own seeds) are switched off,
+so every comparison of bits, verdicts and counts runs for every seed, and whatever fails is a parity failure.   usage: tools/fuzz_campaign.py FIRST_SEED COUNT"""
 import os
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
 import sys, time
@@ -21,6 +20,7 @@ def synth_frames(k):
         p = hsk.synth_pose(k)
         cache[k] = (p, hsk.synth_depth(p))
     return cache[k]
+T.SEED_EXPECTATIONS = False   # parity only: the suite's seed-specific expectations are not in the path of any comparison here
 integrate_fuzz = getattr(T.test_integrate_and_raycast_fuzz, "__wrapped__", T.test_integrate_and_raycast_fuzz)
 tracker_fuzz = getattr(T.test_tracker_fuzz_vs_oracle, "__wrapped__", T.test_tracker_fuzz_vs_oracle)
 bad, other = [], []
@@ -33,11 +33,7 @@ for seed in range(first, first + count):
             import traceback
             line = (traceback.extract_tb(e.__traceback__)[-1].line or "")
             msg = (str(e).split("\n")[0] or line)[:200]
-            # the two expectations that depend on what a seed's random frames happen to be; everything else is parity
-            expectation = ("seed in (0, 3)" in line) or ("total > 30000" in line)
-            (other if expectation else bad).append((name, seed, msg))
-print(f"build {_lib.load().hsk_build_id().decode()}  fuzz seeds {first}..{first + count - 1} (two tests each): parity failures {len(bad)}, "
-      f"seed-specific expectations not met {len(other)} (not parity: e.g. a seed whose garbage frames happen to be tracked), {time.time() - t0:.0f} s")
+            bad.append((name, seed, msg))   # (the seed-specific expectations are switched off above: whatever fails here is parity)
+print(f"build {_lib.load().hsk_build_id().decode()}  fuzz seeds {first}..{first + count - 1} (two tests each, every comparison of every seed run): parity failures {len(bad)}, {time.time() - t0:.0f} s")
 for b in bad: print("  PARITY", b)
-for o in other[:6]: print("  other", o)
 sys.exit(1 if bad else 0)
