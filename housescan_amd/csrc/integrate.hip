@@ -246,19 +246,9 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
             for (int i = 0; i < 3; ++i) st_out->t[i] = p.t[i];
           }
           st_out->n_iter = p.n_iter;
-          if (early.slots) {
-            // The frame's pose and verdict are final HERE -- nothing after the ICP writes them -- so the host is told now,
-            // a whole integrate earlier than by the raycast's report (which stays: its mark says that the frame's
-            // inputs are consumed).  A caller that takes one frame at a time gets its pose back while the volume work
-            // is still running, and its next frame's filtering runs under that.
-            const unsigned n = *early.seq;  // (counted up by the raycast's report, not here)
-            TrackState* dst = early.slots + early.slot_fifo[n % HSK_RING_FIFO];
-            const int* src_w = (const int*)st_out;
-            int* dst_w = (int*)dst;
-            for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
-            __threadfence_system();
-            __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
+          // (the pose and verdict are final HERE; the host is told by pass A's first workgroup, one launch on -- round 5:
+          // the copy into the pinned ring slot and its system-scope fence kept this launch, which pass A waits for, open
+          // 2-3 us longer than its slowest block needed)
         }
       }
     }
@@ -801,7 +791,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
                                                    const float2* __restrict__ qtab, IntegrateConst k, const int2* __restrict__ zint,
-                                                   const unsigned* __restrict__ vmask, int mpitch) {
+                                                   const unsigned* __restrict__ vmask, int mpitch, RingOut early_ring) {
   // Most of the launch's waves have nothing to do -- their wave-chunk lies outside the view frustum, is wholly occluded, or
   // is wholly free space already recorded in its chunk byte -- and what they execute before they find that out is pure
   // overhead: the test comes FIRST and runs on what arrives with the wave -- the arguments preloaded into SGPRs (the
@@ -823,6 +813,21 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     if (icp_slot0)
       for (int i = threadIdx.y * 64 + threadIdx.x; i < ICP_SLOT_DOUBLES; i += 256)
         __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The frame's pose and verdict are final since k_column_zrange's solve -- nothing after the ICP writes them -- so the
+    // host is told now, a whole integrate earlier than by the raycast's report (which stays: its mark says that the
+    // frame's inputs are consumed).  A caller that takes one frame at a time gets its pose back while the volume work is
+    // still running, and its next frame's filtering runs under that.  (Here rather than in k_column_zrange: a launch of
+    // 16 k workgroups hides one thread's PCIe writes; the launch before it was waiting for them.)
+    const RingOut early = early_ring;
+    if (early.slots && threadIdx.x == 0 && threadIdx.y == 0) {
+      const unsigned n = *early.seq;  // (counted up by the raycast's report, not here)
+      TrackState* dst = early.slots + early.slot_fifo[n % HSK_RING_FIFO];
+      const int* src_w = (const int*)st;
+      int* dst_w = (int*)dst;
+      for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
+      __threadfence_system();
+      __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   const unsigned lin = (blockIdx.z * gdy + byr) * gdx + bxr;
   const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);  // the wave's quarter of the footprint
@@ -1429,7 +1434,8 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned* vmask = (const unsigned*)(tmax + hsk_tiles_mask_offset(W, H));  // validity of every pixel (k_bilateral_scale / k_tile_max)
   const CoarseArgs ca = {cflag, (count_only || uni == nullptr) ? nullptr : uni + hsk_lane_sum_bytes(vp), sparse, (unsigned)hsk_chunk_bytes_padded(vp), zchunk, kc.free_thr2, kc.cull_thr2};
   const RingOut quiet_ring = {nullptr, nullptr, nullptr};
-  const RingOut early_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;
+  const RingOut pa_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;  // reported by pass A's first workgroup
+  const RingOut early_ring = quiet_ring;
   hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, fin, tmax,
                      tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, dil_blocks, qcount, st, vp, W, H, in, zint,
                      const_cast<TrackState*>(st), wgz, early_ring, ca);
@@ -1449,19 +1455,19 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   if (count_only) {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
     else
       hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags, qmag_x, qmag_y);
   } else {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
     else
       hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags, qmag_x, qmag_y);
   }
