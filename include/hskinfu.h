@@ -111,10 +111,11 @@ int hsk_count_updates(hsk_ctx* k, const uint16_t* depth, int w, int h, const flo
 
 int hsk_download_tsdf(hsk_ctx* k, int16_t* tsdf_weight_pairs /* 2 * X*Y*stored_planes, x fastest */);
 int hsk_upload_tsdf(hsk_ctx* k, const int16_t* tsdf_weight_pairs);
-/* The weights of deep free space are kept in a side table (one byte per 16 voxels) and written back into the volume
- * when something is about to read them: hsk_download_tsdf, hsk_extract_cloud and hsk_extract_mesh do it themselves.
- * This call does only that write-back (enqueued; no host synchronisation) -- it changes nothing any call returns, and
- * exists so that the deferred work can be timed on its own (bench.py: readout_ms). */
+/* The weights of deep free space are kept in side tables (one byte per 16 voxels, one per 2048) and written back into the
+ * volume when something is about to read them: hsk_download_tsdf does it itself.  (The products -- hsk_extract_cloud,
+ * hsk_extract_mesh[_cubes] -- ask of a weight only whether it is zero, which no deferred weight is, and do not.)  This call
+ * does only that write-back (enqueued; no host synchronisation) -- it changes nothing any call returns, and exists so
+ * that the deferred work can be timed on its own (bench.py: readout_ms). */
 int hsk_flush_weights(hsk_ctx* k);
 int hsk_stored_planes(const hsk_ctx* k, int* z0, int* nz);
 int hsk_get_pose(hsk_ctx* k, float pose[16]);
@@ -209,7 +210,7 @@ int hsk_group_process_frame(hsk_group* g, const uint16_t* depth, int w, int h, f
  * shows as HSK_ERR_TIMEOUT from hsk_group_wait_frame on every other rank after HSK_FRAME_TIMEOUT_S seconds (environment
  * variable, default 20) -- which poisons the group.  Poisoning lets this rank's own queues drain (direct form: the
  * flags its streams wait for are raised from the host; RCCL form: ncclCommAbort), so hsk_group_destroy returns.
- * STATUS: groups of several slabs on ONE device -- RCCL form, direct form, and the direct form between 2 and 3 OS
+ * STATUS: groups of several slabs on ONE device -- RCCL form, direct form, and the direct form between 2, 3 and 8 OS
  * processes sharing the device -- are tested bit-exact against a single context; groups over more than one DEVICE
  * (ncclCommInitAll / ncclCommInitRank with world > 1, the direct form over xGMI peer mappings) have never run on
  * hardware -- no multi-GPU box was available (tests/test_gpu_multi_device.py runs all three forms when one is, and
