@@ -202,6 +202,39 @@ def test_free_space_weights_long_run(hsk, oracle, synth_frames):
     trk.close()
 
 
+def test_chunk_level_counts_long_run(hsk, oracle, synth_frames):
+    """round 5's coarse level: a wave-chunk (16 x 16 voxels x 8 planes) that is wholly free space records an observation as
+    ONE count in its chunk byte.  Run one pose long enough that the byte reaches its ceiling (254 pending observations: the
+    next free frame must push the count down into the lane-block bytes, where a rim block's own count overflows in turn and
+    its words are rewritten), with other poses in between (their frustums cut chunks that hold pending counts: the counts are
+    pushed down under blocks the frame does not touch) and a cloud taken while everything is pending -- no download until the
+    end, where the volume must be the oracle's.  256^3: small enough for the oracle, fine enough for chunks to be free."""
+    n = 256
+    cfg_o = oracle.default_config(n)
+    trk = hsk.KinfuTracker(n=n)
+    vol = np.zeros((n, n, n, 2), np.int16)
+    frames = [synth_frames(k) for k in (0, 40, 75)]
+    scaled = [oracle.scale_depth(cfg_o, d) for _, d in frames]
+    plan = [0] * 130 + [1] + [0] * 60 + [2, 1] + [0] * 75 + [1, 0, 0]
+    seen_quiet = seen_bumped = 0
+    for i, f in enumerate(plan):
+        oracle.integrate(cfg_o, vol, scaled[f], frames[f][0], omp=True)
+        trk.integrate(frames[f][1], frames[f][0])
+        if i in (5, 120, 200, len(plan) - 1):
+            mixed, settled, free_worked, quiet = trk.integrate_coarse_counts()
+            seen_quiet = max(seen_quiet, quiet)
+            seen_bumped = max(seen_bumped, settled)
+        if i == 150:   # a product in the middle: no flush, nothing may change
+            pts, total = trk.extract_cloud()
+            opts, ototal = oracle.extract_cloud(cfg_o, vol)
+            assert total == ototal and np.array_equal(pts.view(np.uint32), opts.view(np.uint32))
+    assert seen_quiet > 500, seen_quiet            # the chunk bytes were really in use
+    assert_same_bits(trk.download_tsdf(), vol, "tsdf after 270 integrations without a read-back")
+    w = vol[..., 1]
+    assert w.max() == 128 and ((w > 0) & (w < 128)).sum() > 10000
+    trk.close()
+
+
 def test_upload_then_integrate_more(hsk, oracle, synth_frames):
     """a volume uploaded into a fresh context (its free-space summaries rebuilt from the words) takes further frames exactly
     as the context it came from: both equal the oracle's volume, with and without a read-back in between"""
