@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1134,27 +1136,78 @@ static int ensure_pinned(hsk_ctx* k) {
   k->pin_bytes = HSK_PIN_BYTES;
   return HSK_OK;
 }
-static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-  size_t nt = bytes >> 22;  // a thread per 4 MiB, at most 8 (a core moves 10-20 GB/s)
-  unsigned hw = std::thread::hardware_concurrency();
-  if (hw == 0) hw = 1;
-  if (nt > 8) nt = 8;
-  if (nt > hw) nt = hw;
-  if (nt <= 1) {
-    memcpy(dst, src, bytes);
-    return;
+// Host copies out of (into) the pinned buffers are shared among a few worker threads that live with the process (started
+// on first use, asleep otherwise): a core moves 10-20 GB/s, the PCIe link 55.  A thread per copy cost ~20 us each to start,
+// which the pieces of a pipelined copy cannot afford.
+namespace {
+struct CopyPool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> workers;
+  struct Job { char* dst; const char* src; size_t len; };
+  std::vector<Job> jobs;
+  size_t pending = 0;
+  bool stop = false;
+  void worker() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
+      if (stop && jobs.empty()) return;
+      Job j = jobs.back();
+      jobs.pop_back();
+      lk.unlock();
+      memcpy(j.dst, j.src, j.len);
+      lk.lock();
+      if (--pending == 0) cv_done.notify_all();
+    }
   }
-  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-  std::vector<std::thread> th;
-  for (size_t t = 1; t < nt; ++t) {
-    const size_t off = t * per;
-    if (off >= bytes) break;
-    const size_t len = bytes - off < per ? bytes - off : per;
-    th.emplace_back([=]() { memcpy((char*)dst + off, (const char*)src + off, len); });
+  void run(void* dst, const void* src, size_t bytes) {
+    const size_t slice = (size_t)2 << 20;
+    if (bytes <= slice) {
+      memcpy(dst, src, bytes);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(m);   // (one copy at a time per process: the callers are read-outs, not the frame path)
+    if (workers.empty()) {
+      unsigned n = std::thread::hardware_concurrency();
+      n = n == 0 ? 1 : (n > 8 ? 7 : (n > 1 ? n - 1 : 1));
+      for (unsigned i = 0; i < n; ++i) workers.emplace_back([this] { worker(); });
+    }
+    cv_done.wait(lk, [&] { return pending == 0; });
+    size_t first_len = 0;
+    for (size_t off = 0; off < bytes; off += slice) {
+      const size_t len = bytes - off < slice ? bytes - off : slice;
+      if (off == 0) { first_len = len; continue; }   // the caller copies the first slice itself
+      jobs.push_back(Job{(char*)dst + off, (const char*)src + off, len});
+      ++pending;
+    }
+    lk.unlock();
+    cv_work.notify_all();
+    memcpy(dst, src, first_len);
+    lk.lock();
+    // (the caller helps with what is left instead of sleeping)
+    while (!jobs.empty()) {
+      Job j = jobs.back();
+      jobs.pop_back();
+      lk.unlock();
+      memcpy(j.dst, j.src, j.len);
+      lk.lock();
+      if (--pending == 0) cv_done.notify_all();
+    }
+    cv_done.wait(lk, [&] { return pending == 0; });
   }
-  memcpy(dst, src, per < bytes ? per : bytes);
-  for (auto& t : th) t.join();
-}
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : workers) t.join();
+  }
+};
+CopyPool g_copy_pool;
+}  // namespace
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) { g_copy_pool.run(dst, src, bytes); }
 // `bytes` of device memory at src into the caller's dst, in pieces through the pinned pair: the DMA of piece i + 1 runs
 // under the host's copy of piece i
 static int copy_out(hsk_ctx* k, void* dst, const void* src_dev, size_t bytes) {
@@ -1162,8 +1215,13 @@ static int copy_out(hsk_ctx* k, void* dst, const void* src_dev, size_t bytes) {
   if (r != HSK_OK) return r;
   size_t prev_off = 0, prev_len = 0;
   int i = 0;
-  for (size_t off = 0; off < bytes; off += k->pin_bytes, ++i) {
-    const size_t len = bytes - off < k->pin_bytes ? bytes - off : k->pin_bytes;
+  // (pieces of about a quarter of the whole, 2 MiB at least: the DMA of one piece and the host's copy of the one before it
+  // overlap only when there are several -- a 30 MB mesh as ONE piece was 0.6 ms of DMA and then 0.75 ms of host copy)
+  size_t piece = ((bytes / 4) + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+  if (piece < ((size_t)1 << 21)) piece = (size_t)1 << 21;
+  if (piece > k->pin_bytes) piece = k->pin_bytes;
+  for (size_t off = 0; off < bytes; off += piece, ++i) {
+    const size_t len = bytes - off < piece ? bytes - off : piece;
     HIPCHK(k, hipMemcpyAsync(k->h_pin[i & 1], (const char*)src_dev + off, len, hipMemcpyDeviceToHost, k->stream));
     HIPCHK(k, hipEventRecord(k->ev_pin[i & 1], k->stream));
     if (prev_len) {
