@@ -246,13 +246,35 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
             for (int i = 0; i < 3; ++i) st_out->t[i] = p.t[i];
           }
           st_out->n_iter = p.n_iter;
-          // (the pose and verdict are final HERE; the host is told by pass A's first workgroup, one launch on -- round 5:
-          // the copy into the pinned ring slot and its system-scope fence kept this launch, which pass A waits for, open
-          // 2-3 us longer than its slowest block needed)
+        }
+        if (early.slots && blockIdx.x == gridDim.x - 1) {
+          // The frame's pose and verdict are final HERE -- nothing after the ICP writes them -- so the host is told now, a
+          // whole integrate earlier than by the raycast's report (which stays: its mark says that the frame's inputs are
+          // consumed).  A caller that takes one frame at a time gets its pose back while the volume work is still running,
+          // and its next frame's filtering runs under that.  By a block of its OWN, launched for nothing else (round 5):
+          // the copy into the pinned ring slot and its system-scope fence take 2-3 us, and in block 0's path they kept
+          // this launch -- which pass A waits for -- open that much longer than its slowest block needed; a block that
+          // only solves and reports is done before the others have classified their chunks.  It composes the state from its
+          // own solve and from the fields of `st` that nobody writes in this launch (block 0 is writing the others).
+          const unsigned n = *early.seq;  // (counted up by the raycast's report, not here)
+          TrackState* dst = early.slots + early.slot_fifo[n % HSK_RING_FIFO];
+          const bool use_new = !p.lost;
+          for (int i = 0; i < 9; ++i) dst->R[i] = use_new ? p.R[i] : st->R[i];
+          for (int i = 0; i < 3; ++i) dst->t[i] = use_new ? p.t[i] : st->t[i];
+          for (int i = 0; i < 9; ++i) dst->Rp[i] = st->Rp[i];
+          for (int i = 0; i < 3; ++i) dst->tp[i] = st->tp[i];
+          dst->lost = p.lost ? 1 : st->lost;
+          dst->frame = st->frame;
+          dst->n_iter = p.n_iter;
+          dst->need_reset = p.lost ? 1 : st->need_reset;
+          for (int k = 0; k < 27; ++k) dst->sums[k] = fin_tot[k];
+          __threadfence_system();
+          __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
     __syncthreads();
+    if (early.slots && blockIdx.x == gridDim.x - 1) return;  // (the reporting block has no footprint of its own)
   }
   // One block = the x-y footprint of one pass-A workgroup (16 lane columns by 16 rows), so that the block can also leave
   // that workgroup's z range: pass A's workgroups of the chunks outside it (half of its waves lie outside the frustum)
@@ -348,6 +370,9 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
         const int w = item & 3, zc = item >> 2;
         const int4 r = wv_sh[w];
         const int zbeg = zc * ca.zchunk, zend = min(zbeg + ca.zchunk, vp.nzs);
+        const size_t ci = (((size_t)zc * gyn + fby) * gxn + fbx) * 4 + w;
+        // (the chunk's byte is requested now: it travels under the geometry and the table look-ups instead of behind them)
+        const unsigned c_now = ca.cs != nullptr ? (unsigned)ca.cs[ci] : 0u;
         unsigned verdict = HSK_CF_MIXED;
         if ((zbeg > r.y) | (zend - 1 < r.x)) {
           verdict = HSK_CF_SKIP;  // outside the padded frustum
@@ -407,9 +432,8 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
             }
           }
         }
-        const size_t ci = (((size_t)zc * gyn + fby) * gxn + fbx) * 4 + w;
         if (verdict == HSK_CF_FREE && ca.cs != nullptr && !lost) {
-          const unsigned c = ca.cs[ci];
+          const unsigned c = c_now;
           if (c >= 1u && c < 255u) {  // one more pending observation of the whole chunk: the frame's work on it is done
             ca.cs[ci] = (unsigned char)(c + 1u);
             ca.cs[ca.dirty_off + ci] = 1;
@@ -791,7 +815,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
                                                    unsigned* __restrict__ queue, unsigned* __restrict__ qcount,
                                                    unsigned qcap, const float2* __restrict__ ftab, int fw, int fh,
                                                    const float2* __restrict__ qtab, IntegrateConst k, const int2* __restrict__ zint,
-                                                   const unsigned* __restrict__ vmask, int mpitch, RingOut early_ring) {
+                                                   const unsigned* __restrict__ vmask, int mpitch) {
   // Most of the launch's waves have nothing to do -- their wave-chunk lies outside the view frustum, is wholly occluded, or
   // is wholly free space already recorded in its chunk byte -- and what they execute before they find that out is pure
   // overhead: the test comes FIRST and runs on what arrives with the wave -- the arguments preloaded into SGPRs (the
@@ -813,21 +837,6 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     if (icp_slot0)
       for (int i = threadIdx.y * 64 + threadIdx.x; i < ICP_SLOT_DOUBLES; i += 256)
         __hip_atomic_store(icp_slot0 + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // The frame's pose and verdict are final since k_column_zrange's solve -- nothing after the ICP writes them -- so the
-    // host is told now, a whole integrate earlier than by the raycast's report (which stays: its mark says that the
-    // frame's inputs are consumed).  A caller that takes one frame at a time gets its pose back while the volume work is
-    // still running, and its next frame's filtering runs under that.  (Here rather than in k_column_zrange: a launch of
-    // 16 k workgroups hides one thread's PCIe writes; the launch before it was waiting for them.)
-    const RingOut early = early_ring;
-    if (early.slots && threadIdx.x == 0 && threadIdx.y == 0) {
-      const unsigned n = *early.seq;  // (counted up by the raycast's report, not here)
-      TrackState* dst = early.slots + early.slot_fifo[n % HSK_RING_FIFO];
-      const int* src_w = (const int*)st;
-      int* dst_w = (int*)dst;
-      for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
-      __threadfence_system();
-      __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
   }
   const unsigned lin = (blockIdx.z * gdy + byr) * gdx + bxr;
   const unsigned wq = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.y);  // the wave's quarter of the footprint
@@ -982,8 +991,9 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       const int iv0 = (int)rintf(fminf(fmaxf(front ? vmin - ue : -8.0f, -8.0f), 65536.0f)), iv1 = (int)rintf(fminf(fmaxf(front ? vmax + ue : -8.0f, -8.0f), 65536.0f));
       // the 4-px table when the box spans at most 3 x 3 of its tiles, else the 8-px one (at most 3 x 3 again, else undecided)
       const bool in_img = front & (iu0 >= 0) & (iv0 >= 0) & (iu1 <= W - 1) & (iv1 <= H - 1);
-      // (the box, for the validity mask below: 10 + 9 bits of its corner, 5 + 2 of its extent; wider or taller: no look-up)
-      box_s[sidx] = ((iu1 - iu0 < 32) & (iv1 - iv0 < 4) & in_img & (W <= 1024) & (H <= 512)) ? ((unsigned)iu0 | ((unsigned)iv0 << 10) | ((unsigned)(iu1 - iu0) << 19) | ((unsigned)(iv1 - iv0) << 24) | (1u << 26)) : 0u;
+      // (the box, for the validity mask below: 11 + 11 bits of its corner, 5 + 2 of its extent; wider or taller, or an image
+      // beyond 2048 pixels a side: no look-up)
+      box_s[sidx] = ((iu1 - iu0 < 32) & (iv1 - iv0 < 4) & in_img & (W <= 2048) & (H <= 2048)) ? ((unsigned)iu0 | ((unsigned)iv0 << 11) | ((unsigned)(iu1 - iu0) << 22) | ((unsigned)(iv1 - iv0) << 27) | (1u << 29)) : 0u;
       const bool fine = ((iu1 >> 2) <= (iu0 >> 2) + 2) & ((iv1 >> 2) <= (iv0 >> 2) + 2);
       const int sh = fine ? 2 : 3;
       const int tu0 = iu0 >> sh, tv0 = iv0 >> sh;
@@ -1026,7 +1036,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
         unsigned bad = 1u;
         if (ask) {
           const unsigned bx = box_s[sidx];
-          const int iu0 = (int)(bx & 1023u), iv0 = (int)((bx >> 10) & 511u), wd = (int)((bx >> 19) & 31u), ht = (int)((bx >> 24) & 3u);
+          const int iu0 = (int)(bx & 2047u), iv0 = (int)((bx >> 11) & 2047u), wd = (int)((bx >> 22) & 31u), ht = (int)((bx >> 27) & 3u);
           const unsigned* __restrict__ row = vmask + (size_t)iv0 * mpitch + (iu0 >> 5);
           const unsigned long long sel = ((wd == 31 ? 0ull : (1ull << (wd + 1))) - 1ull) << (iu0 & 31);
           unsigned long long any = 0ull;
@@ -1434,9 +1444,9 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned* vmask = (const unsigned*)(tmax + hsk_tiles_mask_offset(W, H));  // validity of every pixel (k_bilateral_scale / k_tile_max)
   const CoarseArgs ca = {cflag, (count_only || uni == nullptr) ? nullptr : uni + hsk_lane_sum_bytes(vp), sparse, (unsigned)hsk_chunk_bytes_padded(vp), zchunk, kc.free_thr2, kc.cull_thr2};
   const RingOut quiet_ring = {nullptr, nullptr, nullptr};
-  const RingOut pa_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;  // reported by pass A's first workgroup
-  const RingOut early_ring = quiet_ring;
-  hipLaunchKernelGGL(k_column_zrange, dim3(col_blocks > dil_blocks ? col_blocks : dil_blocks), dim3(256), 0, s, fin, tmax,
+  const RingOut early_ring = (early && fin.slots && !count_only) ? *early : quiet_ring;
+  // (one block more when the launch reports the pose: that block solves, reports and leaves)
+  hipLaunchKernelGGL(k_column_zrange, dim3((col_blocks > dil_blocks ? col_blocks : dil_blocks) + (early_ring.slots ? 1 : 0)), dim3(256), 0, s, fin, tmax,
                      tmax + tw * th, (float2*)(tmax + 2 * tw * th), tw, th, dil_blocks, qcount, st, vp, W, H, in, zint,
                      const_cast<TrackState*>(st), wgz, early_ring, ca);
   dim3 block(64, 4, 1);
@@ -1455,19 +1465,19 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   if (count_only) {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     else
       hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
-                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
+                         W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags, qmag_x, qmag_y);
   } else {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     else
       hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
-                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W), pa_ring);
+                         (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags, qmag_x, qmag_y);
   }

@@ -530,7 +530,7 @@ def test_tracker_long_stream_vs_oracle(hsk, oracle):
     trk.close()
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (336, 252), (160, 120)])
+@pytest.mark.parametrize("w,h", [(320, 240), (336, 252), (160, 120), (1280, 960)])   # (1280 x 960: four times the pixels; 960 blocks at the ICP's fine level)
 def test_tracker_other_image_sizes(hsk, oracle, w, h):
     """image sizes other than 640x480 take other kernel shapes (ICP pixels per lane by level width, the raycast's fused
     pyramid only when both dimensions are multiples of 8, partial tiles otherwise): still bit-exact against the oracle,
