@@ -1129,11 +1129,21 @@ extern "C" int hsk_icp_solve(const double in27[27], float x6[6], int* ok) {
 #define HSK_PIN_BYTES ((size_t)32 << 20)
 static int ensure_pinned(hsk_ctx* k) {
   if (k->h_pin[0]) return HSK_OK;
+  // (at least one whole plane of the volume: the download and the upload move whole planes -- 4096 x 4096 voxels are 64 MiB)
+  const size_t plane = (size_t)k->vp.X * k->vp.Y * 4;
+  const size_t want = plane > HSK_PIN_BYTES ? plane : HSK_PIN_BYTES;
   for (int i = 0; i < 2; ++i) {
-    HIPCHK(k, hipHostMalloc(&k->h_pin[i], HSK_PIN_BYTES, hipHostMallocDefault));
-    HIPCHK(k, hipEventCreateWithFlags(&k->ev_pin[i], hipEventDisableTiming));
+    hipError_t e = hipHostMalloc(&k->h_pin[i], want, hipHostMallocDefault);
+    if (e == hipSuccess && !k->ev_pin[i]) e = hipEventCreateWithFlags(&k->ev_pin[i], hipEventDisableTiming);
+    if (e != hipSuccess) {  // (nothing half-made is left behind: the next call tries again)
+      for (auto& p : k->h_pin) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+      }
+      HIPCHK(k, e);
+    }
   }
-  k->pin_bytes = HSK_PIN_BYTES;
+  k->pin_bytes = want;
   return HSK_OK;
 }
 // Host copies out of (into) the pinned buffers are shared among a few worker threads that live with the process (started

@@ -9,16 +9,20 @@
 
 // ------------------------------------------------------------------------------------------------------
 // integrate (A.4).  Layout: each lane owns 4 x-adjacent voxels (one 16-B vector per plane, the four planes of a group
-// consecutive: a 64-B block), a wave covers 64 voxels of 4 consecutive rows, a block 16 rows and a chunk of 8 or 16 planes.
+// consecutive: a 64-B block = a lane-block), a wave covers 16 x 16 voxels (4 lanes by 16 rows), a workgroup four waves side
+// by side (64 x 16 voxels) and a chunk of 8 or 16 planes.
 //
-// Only vectors that hold at least one rewritten voxel are read or written, so HBM traffic tracks the
-// algorithmic 8 B x V_upd, not the 8 B x N^3 sweep.  Three conservative culls keep the
-// arithmetic off the voxels that cannot be rewritten (each only ever skips voxels the exact test rejects):
+// Only vectors that hold at least one voxel whose bits really change are read or written, so HBM traffic stays BELOW the
+// algorithmic 8 B x V_upd.  Conservative classifications -- each only ever replaces work whose outcome it
+// has proven -- keep the arithmetic off everything else:
+//   0. (round 5) a wave-chunk's box against the 16-px tile range under it: wholly free space (one count in the chunk's
+//      byte), wholly occluded or outside the frustum (nothing) -- k_column_zrange, once per frame and chunk;
 //   1. per-lane z interval of the column inside the (padded) view frustum, computed once per column;
-//   2. occlusion: a 16x16-pixel tile table of max scaled depth, 3x3-dilated and staged in LDS; a 4-voxel
-//      group whose nearest possible point is farther than that maximum + tau cannot pass sdf >= -tau;
+//   2. a lane-block's tight pixel box against the 4-px / 8-px tile windows and the validity mask (free space: a summary
+//      byte moves; occluded: nothing), with the dilated 16-px table as the fall-back near the camera;
 //   3. exact fast paths of the running mean (saturated free space, first observation).
-// Bricks (8^3 voxels) that ever received a negative TSDF are flagged for the raycaster's empty-space test.
+// What is left -- blocks near a surface, at the frustum's rim, or with a hole in the depth image under them -- takes the exact
+// per-voxel rule in pass B.  Bricks that ever received a negative TSDF are flagged for the raycaster's empty-space test.
 // ------------------------------------------------------------------------------------------------------
 #define HSK_TILE 16
 #define HSK_NQUEUES 256       // uncertain lane-blocks are spread over this many queues (pass A -> pass B)
@@ -279,7 +283,6 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
   // One block = the x-y footprint of one pass-A workgroup (16 lane columns by 16 rows), so that the block can also leave
   // that workgroup's z range: pass A's workgroups of the chunks outside it (half of its waves lie outside the frustum)
   // then leave on one scalar load instead of a vector load per lane and a wave-wide reduction.
-  __shared__ int wg_lo[4], wg_hi[4];
   __shared__ int4 wv_sh[4];
   const int ncol = vp.X / 4;
   const int gxn = (vp.X + 63) / 64, gyn = (vp.Y + 15) / 16;
@@ -342,15 +345,12 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
       hi_all = min(hi_all, __shfl_xor(hi_all, o, 64));
     }
     if ((threadIdx.x & 63) == 0) {
-      wg_lo[threadIdx.x >> 6] = lo;
-      wg_hi[threadIdx.x >> 6] = hi;
       // this wave's footprint (4 lane columns x 16 rows): union of its columns' ranges, then their intersection
       ((int4*)(wgz + (((size_t)gxn * gyn + 1) & ~(size_t)1)))[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = make_int4(lo, hi, lo_all, hi_all);
       wv_sh[threadIdx.x >> 6] = make_int4(lo, hi, lo_all, hi_all);
     }
     __syncthreads();
-    if (threadIdx.x == 0)
-      wgz[blockIdx.x] = make_int2(min(min(wg_lo[0], wg_lo[1]), min(wg_lo[2], wg_lo[3])), max(max(wg_hi[0], wg_hi[1]), max(wg_hi[2], wg_hi[3])));
+    // (the footprint-wide range that pass A's workgroups used to leave by is gone: they go by the coarse level's verdicts)
     // ---- the coarse level: one verdict per wave-chunk of this footprint (4 waves x the launch's chunks of planes).  The
     // chunk's voxel centres fill a box; a box in front of the camera projects into the pixel box of its 8 corners (+-1 px
     // for the rounding to a pixel), and its distances to the camera centre lie between the box's nearest and farthest
