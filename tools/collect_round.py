@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""After tools/profile_round.sh and the round's bench lines have run on the GPU box (gpurun_out/round, gpurun_out/final):
+copy the judged artefacts into profiles/rNN/ and print the numbers the READMEs quote.   usage: tools/collect_round.py r05"""
+import csv, json, os, shutil, sys, glob
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R, F, P = (os.path.join(ROOT, p) for p in ("gpurun_out/round", "gpurun_out/final", "profiles/" + rnd))
+os.makedirs(P, exist_ok=True)
+for src, dst in (("kernel_stats.csv", "final_kernel_stats.csv"), ("kernel_stats_1024.csv", "kernel_stats_1024.csv"), ("pmc_summary.txt", "final_pmc_summary.txt"),
+                 ("integrate_traffic.json", "integrate_traffic.json"), ("bench_profiled.json", "final_bench_under_rocprof.json"),
+                 ("bench_profiled_1024.json", "bench_1024_under_rocprof.json"), ("readout_kernel_stats_512.csv", None), ("readout_kernel_stats_1024.csv", None),
+                 ("readout_512.txt", None), ("readout_1024.txt", None)):
+    shutil.copy(os.path.join(R, src), os.path.join(P, dst or src))
+for f in glob.glob(os.path.join(R, "long_parity_*.txt")):
+    shutil.copy(f, P)
+for f in ("bench_default_200steps.json", "bench_driver_window_20steps.json", "bench_sync_api_quick.json", "bench_gpus2_share_gpu.json", "fuzz_campaign.txt", "gputest_final.txt"):
+    shutil.copy(os.path.join(F, f), P)
+g8 = os.path.join(F, "bench_gpus8_share_gpu.json")
+if os.path.exists(g8):
+    j = json.loads(open(g8).read())
+    j["_note"] = ("python bench.py --gpus 8 --share-gpu --volume 256 --steps 6 --warmup 2 --no-1024, bare, on a ONE-GPU box (tests/test_gpu_parity.py::"
+                  "test_bench_eight_ranks_share_the_gpu): eight OS processes, one z-slab each, all on device 0 -- the 8-way hipIpc handle exchange, the "
+                  "8 x 8 flag page and the launcher's 8-worker watchdog run and the result is checked against the single context plane for plane. "
+                  "NO SCALING CLAIM FOLLOWS FROM IT: the eight slabs share one GPU; the RCCL forms are recorded as failed (duplicate GPU).")
+    open(os.path.join(P, "bench_gpus8_share_gpu.json"), "w").write(json.dumps(j, indent=1) + "\n")
+for f in ("bench_default_200steps", "bench_driver_window_20steps"):
+    j = json.loads(open(os.path.join(F, f + ".json")).read().strip().splitlines()[-1])
+    r, n, b = j["roofline"], j.get("noise_512", {}), j.get("roofline_1024", {})
+    print(f, j["value"], "frames/s, build", j.get("build_id"), {k: v for k, v in j["stage_us"].items() if k in ("preprocess", "icp", "integrate", "raycast")},
+          "frac", r["frac"], "hbm_frac", r["hbm_frac"], "queue", r["pass_b_queue_entries_mean"])
+    print("   issue_util", {k: (v["us"], v["valu"], v["salu"]) for k, v in r.get("issue_util", {}).items() if k != "note"})
+    if n:
+        print("   noise", n["frames_per_s"], n["vs_clean_render"], n["stage_us"]["integrate"], n["integrate"]["pass_b_queue_entries_mean"])
+    if b:
+        print("   1024", b["frames_per_s"], b["stage_us"], "frac", b["frac"], "hbm_frac", b["hbm_frac"])
+        print("   readout 1024", {k: v for k, v in b.get("readout_ms", {}).items() if k.endswith("_ms") or k.endswith("host")})
+    print("   readout", {k: v for k, v in j.get("readout_ms", {}).items() if k.endswith("_ms") or k.endswith("host")})
+    cr = j.get("concurrent_rooms_one_gpu", {})
+    print("   rooms", cr.get("2_rooms", {}).get("frames_per_s_in_all"), cr.get("4_rooms", {}).get("frames_per_s_in_all"), "pcie", j.get("pcie_inclusive_pipelined_fps"),
+          "integrate+flush", r.get("integrate_plus_flush_every_frame_us"), r.get("frac_with_flush_every_frame"))
+print("sync api", json.loads(open(os.path.join(F, "bench_sync_api_quick.json")).read().strip().splitlines()[-1])["value"])
+for f in ("final_kernel_stats.csv", "kernel_stats_1024.csv"):
+    rows = list(csv.DictReader(open(os.path.join(P, f))))
+    print(f, {r["Name"].split("(")[0].replace("void ", "")[:28]: round(float(r["AverageNs"]) / 1e3, 1) for r in rows[:14]})
+print(open(os.path.join(P, "gputest_final.txt")).read().strip().splitlines()[-1])
+for f in sorted(glob.glob(os.path.join(P, "long_parity_*.txt"))) + [os.path.join(P, "fuzz_campaign.txt")]:
+    print(" ", [ln for ln in open(f).read().splitlines() if ln.startswith("build")][-1][:150])
