@@ -615,6 +615,8 @@ def run_single(args, hsk, torch, local_rank):
         # products -- cloud, meshes -- no longer flush: they only ask whether a weight is zero, which no deferred weight is)
         fl = out["readout_ms"]["flush_weights_ms"] * 1e3
         out["roofline"]["integrate_plus_flush_every_frame_us"] = round(out["stage_us"]["integrate"] + fl, 1)
+        out["roofline"]["flush_note"] = ("only hsk_download_tsdf flushes (it hands the weights out; %.1f ms by itself at this size); clouds and meshes "
+                                         "do not: a host that takes a product per frame pays the product, not the flush" % out["readout_ms"].get("download_tsdf_ms", 0.0))
         out["roofline"]["frac_with_flush_every_frame"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / ((out["stage_us"]["integrate"] + fl) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     trk.close()
     if not args.no_noise:
