@@ -11,7 +11,10 @@ JSON line (the task contract) with, beside the contract's keys (SURVEY.md 8(d), 
                   rocprofv3 over the same frames, run as child processes of THIS invocation (null when rocprofv3 is absent)
   roofline_1024   the same on a 1024^3 volume (the HBM measurement: 4 GiB, sixteen times the Infinity Cache)
   stage_us, icp_us_per_iter, frame_ms (median / p10 / p90), raycast (rays/s, algorithmic GB/s from oracle-counted steps)
-  pcie_inclusive  the same frames handed over as HOST buffers (the real shape of HoniHelper.hs:20), pipelined
+  host_frames_pipelined_fps / sync_process_frame_fps   the same frames through the boundary's own calls with HOST pointers
+                  (hsk_submit_frame / hsk_wait_frame; one hsk_process_frame per frame) -- device_frames_fps (= value) beside them
+  room_N / holes_N / noise_N   the timed region again on the room scan (camera inside the volume), on a stream with holes
+                  as a sensor makes them, and on SURVEY.md 8(d)'s noise run
   cpu_baseline    the CPU oracle (kind "port") on this box's host cores: all cores and one thread, built -O3 -march=native
   concurrent_rooms_one_gpu   2 and 4 independent rooms scanned at once on the one GPU (BASELINE configs[4] on a single device)
 
@@ -38,16 +41,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-W, H = 640, 480
-
-
-def make_frames(hsk, first, count):
-    poses = [hsk.synth_pose(k) for k in range(first, first + count)]
-    return poses, [hsk.synth_depth(p) for p in poses]
+from bench_common import HBM_PEAK_GBS, ROOT, SLAB_FORMS, W, H, check_build, emit, make_frames
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -133,7 +127,7 @@ def raycast_algorithmic_bytes(volume, trk, pose):
 # ---------------------------------------------------------------------------------------------------------------------
 # HBM traffic of the integrate stage from PMC counters, collected by child processes of this run
 # ---------------------------------------------------------------------------------------------------------------------
-def pmc_counters(volume, total, passes, timeout_s=240):
+def pmc_counters(volume, total, passes, timeout_s=240, stream="scripted"):
     """rocprofv3 --pmc passes (one child run of tools/replay_frames.py each, over the same frames as the timed region);
     returns {kernel name: {counter: [value per launch]}} or (None, reason)"""
     exe = shutil.which("rocprofv3")
@@ -145,7 +139,7 @@ def pmc_counters(volume, total, passes, timeout_s=240):
         for i, ctrs in enumerate(passes):
             out = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", out, "--", sys.executable,
-                                                   os.path.join(ROOT, "tools", "replay_frames.py"), str(volume), str(total)]
+                                                   os.path.join(ROOT, "tools", "replay_frames.py"), str(volume), str(total), stream]
             try:
                 subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=timeout_s, check=True)
@@ -162,7 +156,7 @@ def pmc_counters(volume, total, passes, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def kernel_durations(volume, total, window_first, timeout_s=240):
+def kernel_durations(volume, total, window_first, timeout_s=240, stream="scripted"):
     """mean duration (us) of every kernel over the launches of the timed window: a child run of tools/replay_frames.py under
     rocprofv3 --kernel-trace (the per-dispatch trace, so that the window can be cut out); {name prefix: us} or (None, reason)"""
     exe = shutil.which("rocprofv3")
@@ -172,7 +166,7 @@ def kernel_durations(volume, total, window_first, timeout_s=240):
     try:
         out = os.path.join(tmp, "kt")
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "replay_frames.py"),
-               str(volume), str(total)]
+               str(volume), str(total), stream]
         try:
             subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
         except (subprocess.SubprocessError, OSError) as e:
@@ -188,14 +182,14 @@ def kernel_durations(volume, total, window_first, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def issue_util_block(volume, total, window_first):
+def issue_util_block(volume, total, window_first, stream="scripted"):
     """how busy pass A and pass B keep the two issue pipes -- SQ_INSTS_VALU x 2 cycles (a wave64 instruction on a
     SIMD-32: MI355X_MICROARCH.md) over 1024 SIMDs x the kernel's cycles, SQ_INSTS_SALU over 256 scalar units x cycles (2.4 GHz);
     counters and durations from child runs over the frames of the timed window"""
-    per, why = pmc_counters(volume, total, ["SQ_INSTS_VALU SQ_INSTS_SALU"])
+    per, why = pmc_counters(volume, total, ["SQ_INSTS_VALU SQ_INSTS_SALU"], stream=stream)
     if per is None:
         return {"note": why}
-    dur, why = kernel_durations(volume, total, window_first)
+    dur, why = kernel_durations(volume, total, window_first, stream=stream)
     if dur is None:
         return {"note": why}
     out = {"note": "SQ_INSTS_VALU x 2 / (1024 SIMDs x cycles), SQ_INSTS_SALU / (256 x cycles), cycles = mean kernel duration x 2.4 GHz; "
@@ -216,13 +210,13 @@ def issue_util_block(volume, total, window_first):
 INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false", "void k_integrate_detail2<false")   # (name prefixes: pass A is k_integrate<false, 2 | 4>)
 
 
-def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True):
+def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True, stream="scripted"):
     """HBM-side bytes of the integrate stage per frame: FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes: they do not
     fit one), mean over the launches of the timed window.  gfx950: FETCH_SIZE counts 64 B per 128-B request on wide
     streams, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.  KiB units.  Also returns the
     raycast's counters (its 4-B gathers are an access width the guide calls uncalibrated: raw and doubled both given)."""
     passes = ["FETCH_SIZE", "WRITE_SIZE"] + (["TCC_HIT_sum TCC_MISS_sum"] if with_raycast else [])
-    per, why = pmc_counters(volume, total, passes, timeout_s)
+    per, why = pmc_counters(volume, total, passes, timeout_s, stream=stream)
     if per is None:
         return None, why, None
 
@@ -264,6 +258,9 @@ def readout_block(trk, n, with_download=True):
     what the library allocates on first use (the pinned staging pair, the row tables, the product buffer: `first_call_ms`);
     the second follows a DIFFERENT product, so its count pass runs again (the cache only serves query + fill of one product)."""
     trk.synchronize()
+    tp = time.perf_counter()
+    trk.prepare_readout()   # (hsk_prepare_readout: the pinned pair, row tables, cube table and a product buffer made NOW, off the GL thread)
+    prepare_ms = round((time.perf_counter() - tp) * 1e3, 3)
     t0 = time.perf_counter()
     trk.flush_weights()
     trk.synchronize()
@@ -289,6 +286,10 @@ def readout_block(trk, n, with_download=True):
             else:
                 out[name], out[key] = ms, cnt
     out["first_call_ms"] = first
+    out["prepare_readout_ms"] = prepare_ms
+    out["first_call_note"] = ("first_call_ms follows hsk_prepare_readout (prepare_readout_ms, once per context, from the worker thread that created "
+                              "it): what is left in a first call over the second is the count pass (the second follows a different product too) "
+                              "and a product buffer that has to grow")
     if with_download:
         t2 = time.perf_counter()
         vol = trk.download_tsdf()   # (a fresh host array: the page faults of its 512 MiB / 4 GiB are inside)
@@ -391,27 +392,34 @@ def stream_replay(hsk, n, path, local_rank=0, first=0, count=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, sync_api=False):
-    """the timed region at one GPU: warm-up, then K frames through hsk_submit_frame_dev / hsk_wait_frame"""
-    trk = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=graph)
+def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, sync_api=False, init_pose=None, host_frames=None):
+    """the timed region at one GPU: warm-up, then K frames through hsk_submit_frame_dev / hsk_wait_frame (frames resident in
+    HBM) -- or, host_frames given, the SAME frames as host buffers through hsk_submit_frame / hsk_wait_frame, the call the
+    Haskell host binds (include/hskinfu.h) -- or, sync_api, one hsk_process_frame[_dev] per frame"""
+    over = {} if init_pose is None else {"init_pose": init_pose}
+    trk = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=graph, **over)
     total = 1 + Wm + K
     lost = 0
+    if host_frames is not None:
+        first, submit = (lambda i: trk.process_frame(host_frames[i])), (lambda i: trk.submit_frame(host_frames[i]))
+    else:
+        first, submit = (lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())), (lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr()))
     for i in range(1 + Wm):
-        trk.process_frame_dev(dev_frames[i].data_ptr())
+        first(i)
     torch.cuda.synchronize()
     stamps = []
     t0 = time.perf_counter()
     if sync_api:
         for i in range(1 + Wm, total):
-            pose, ok = trk.process_frame_dev(dev_frames[i].data_ptr())
+            pose, ok = first(i)
             lost += (not ok)
             stamps.append(time.perf_counter())
     else:
         ahead = max(1, min(ahead, 2, K - 1)) if K > 1 else 1
         for i in range(1 + Wm, min(1 + Wm + ahead, total)):
-            trk.submit_frame_dev(dev_frames[i].data_ptr())
+            submit(i)
         for i in range(1 + Wm + ahead, total):
-            trk.submit_frame_dev(dev_frames[i].data_ptr())
+            submit(i)
             pose, ok = trk.wait_frame()
             lost += (not ok)
             stamps.append(time.perf_counter())
@@ -425,17 +433,17 @@ def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, s
     return trk, pose, lost, elapsed, per
 
 
-def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose):
+def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose, init_pose=None):
     """stage times, ICP level times and V_upd over exactly the timed frames (a second context with events around every
     stage: the timed loop carries none, they would sit in the pipelined stream)"""
     total = 1 + Wm + K
-    rep = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=0)
+    rep = hsk.KinfuTracker(n=n, device_id=local_rank, use_graph=0, **({} if init_pose is None else {"init_pose": init_pose}))
     rep.set_profiling(True)
     rep_poses = {}
     all_poses = []
     sample = list(range(1 + Wm, total, max(1, K // 10)))
     p = None
-    entries = []
+    entries, coarse = [], []
     per_frame = []   # stage times of every timed frame (the library sums them; read and reset after each frame)
     for i in range(total):
         if i == 1 + Wm:
@@ -449,6 +457,7 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
         if i in sample:
             rep_poses[i] = p.copy()
             entries.append(rep.integrate_queue_entries())   # lane-blocks pass A handed to pass B in this frame
+            coarse.append(rep.integrate_coarse_counts())    # the coarse level's verdicts over the wave-chunks of this frame
     per_frame = np.array(per_frame) if per_frame else np.zeros((1, 4))
     ms, nf = [float(v) for v in per_frame.sum(axis=0)], len(per_frame)
     replay_with_events.per_frame_us = per_frame * 1e3
@@ -467,6 +476,7 @@ def replay_with_events(hsk, n, K, Wm, frames, dev_frames, local_rank, final_pose
     rep.set_profiling(False)
     icp_ms = [v * nf / max(1, nf2) for v in icp_sum]   # scaled to the nf frames the caller divides by
     replay_with_events.queue_entries = float(np.mean(entries)) if entries else None
+    replay_with_events.coarse_counts = None if not coarse else dict(zip(("mixed", "settled_whole", "free_but_worked", "quiet_now"), (int(v) for v in np.mean(coarse, axis=0))))
     return rep, ms, nf, icp_ms, float(np.mean(vupd)), p
 
 
@@ -505,33 +515,66 @@ def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
     return block
 
 
-def noise_block(args, hsk, torch, n, local_rank, clean_fps):
-    """SURVEY.md 8(d)'s noise run on the measured path: the same timed region on the stream with sensor noise
-    (sigma = 1.2 mm z^2, 2 % dropout: what a real takeDepthSnapshot frame looks like where the render is exact)"""
-    K2, W2 = min(args.steps, 60), min(args.warmup, 10)
+STREAMS = {
+    "noise": ("SURVEY.md 8(d)'s noise run: the scripted stream + sigma = 1.2 mm x (z / 1 m)^2 per pixel (seed 1234) + 2 % INDEPENDENT dropout (seed 5678)",
+              "tests/test_gpu_parity.py::test_noisy_stream_512_vs_oracle (40 frames, bit-equal) and tools/long_parity.py N FRAMES --noise"),
+    "holes": ("holes as a structured-light sensor makes them (hsk_synth_render_sensor; housescan/HoniHelper.hs:20-36): the scripted stream with no "
+              "return from grazing rays (|n.d| < 0.15), a 3-5 px shadow band on the far side of every depth discontinuity, nothing beyond 3.5 m, "
+              "nothing from the absorbing block, sigma = 1.2 mm x z^2 on the rest -- contiguous invalid regions",
+              "tests/test_gpu_parity.py::test_sensor_holes_stream_512_vs_oracle (40 frames, bit-equal) and tools/long_parity.py N FRAMES --holes"),
+    "room0": ("THE ROOM SCAN: the camera stands INSIDE the volume (hsk_synth_room_*: closed room 0 with furniture, the level turn of the 720-frame "
+              "three-turn scan, 1.5 deg of yaw per frame) -- what HouseScan's rooms are made with (README.md:12, Main.hs:1738-1762)",
+              "tests/test_gpu_parity.py::test_room_scan_512_vs_oracle (three windows, bit-equal) and tools/long_parity.py N FRAMES --room 0"),
+}
+
+
+def stream_block(args, hsk, torch, n, local_rank, clean_fps, stream, with_counters=False, with_raycast_steps=False, max_steps=60):
+    """The timed region again on another synthetic stream (tools/replay_frames.py: stream_frames maps the name to the frames):
+    frames/s with the frames resident in HBM and as host buffers, stage times, the integrate stage's algorithmic rate and --
+    with_counters -- its counter traffic, the coarse level's verdicts, pass B's queue, lost frames, trajectory error"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from replay_frames import stream_frames
+    K2, W2 = min(args.steps, max_steps), min(args.warmup, 10)
     tot = 1 + W2 + K2
-    gts, frames = hsk.synth_noisy_frames(tot)
+    gts, frames, init = stream_frames(hsk, stream, tot)
     dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
     dev = [dev_all[i] for i in range(tot)]
     torch.cuda.synchronize()
-    trk, pose, lost, el, _ = timed_single(hsk, torch, n, K2, W2, args.ahead, dev, local_rank)
+    trk, pose, lost, el, _ = timed_single(hsk, torch, n, K2, W2, args.ahead, dev, local_rank, init_pose=init)
     trk.close()
-    rep, ms, nf, _, v_mean, _ = replay_with_events(hsk, n, K2, W2, frames, dev, local_rank, pose)
-    rep.close()
+    trk_h, pose_h, lost_h, el_h, _ = timed_single(hsk, torch, n, K2, W2, args.ahead, dev, local_rank, init_pose=init, host_frames=frames)
+    trk_h.close()
+    assert np.array_equal(pose, pose_h), "host frames and HBM-resident frames must give the same poses"
+    rep, ms, nf, _, v_mean, _ = replay_with_events(hsk, n, K2, W2, frames, dev, local_rank, pose, init_pose=init)
     poses = replay_with_events.poses
     terr = np.array([np.linalg.norm(p[:3, 3] - g[:3, 3]) * 1000.0 for p, g in zip(poses, gts)])
     aerr = np.array([angle_deg(p[:3, :3], g[:3, :3]) for p, g in zip(poses, gts)])
-    blk = roofline_block(n, ms, nf, v_mean, None, None)
+    traffic = tinfo = None
+    if with_counters and not args.no_traffic:
+        traffic, tinfo, _ = pmc_traffic(n, tot, 1 + W2, with_raycast=False, stream=stream)
+    blk = roofline_block(n, ms, nf, v_mean, traffic, tinfo if isinstance(tinfo, dict) else None)
     fps = K2 / el
-    out = {"stream": "scripted synthetic stream + sigma = 1.2 mm x (z / 1 m)^2 per pixel (seed 1234) + 2 % dropout (seed 5678)",
-           "frames_per_s": round(fps, 2), "steps": K2, "warmup": W2, "lost_frames": int(lost),
+    out = {"stream": STREAMS[stream][0],
+           "invalid_pixel_fraction": round(float(np.mean([(f == 0).mean() for f in frames])), 4),
+           "frames_per_s": round(fps, 2), "frames_per_s_host_frames": round(K2 / el_h, 2), "steps": K2, "warmup": W2, "lost_frames": int(lost),
            "vs_clean_render": None if not clean_fps else round(fps / clean_fps, 3),
            "stage_us": {"preprocess": round(ms[0] / nf * 1e3, 1), "icp": round(ms[1] / nf * 1e3, 1), "integrate": round(ms[2] / nf * 1e3, 1),
                         "raycast": round(ms[3] / nf * 1e3, 1)},
-           "integrate": {k: blk[k] for k in ("achieved", "frac", "v_upd_mean", "pass_b_queue_entries_mean", "avg_launch_us")},
+           "integrate": {k: blk[k] for k in ("achieved", "frac", "traffic", "hbm_GBps", "hbm_frac", "v_upd_mean", "pass_b_queue_entries_mean", "avg_launch_us")},
+           "integrate_coarse_counts": replay_with_events.coarse_counts,
            "trajectory": {"ate_rmse_mm": round(float(np.sqrt(np.mean(terr ** 2))), 3), "ate_max_mm": round(float(terr.max()), 3),
                           "max_angle_deg": round(float(aerr.max()), 4), "frames": len(poses), "against": "the scripted ground truth"},
-           "parity": "tests/test_gpu_parity.py::test_noisy_stream_512_vs_oracle (40 frames, bit-equal) and tools/long_parity.py N FRAMES --noise"}
+           "parity": STREAMS[stream][1]}
+    if traffic is None and with_counters:
+        out["integrate"]["traffic_note"] = "skipped (--no-traffic)" if args.no_traffic else str(tinfo)
+    if with_counters and not args.no_traffic:
+        out["integrate"]["issue_util"] = issue_util_block(n, tot, 1 + W2, stream=stream)
+    if with_raycast_steps and not args.no_cpu_baseline:
+        t_ray = ms[3] / nf * 1e-3
+        b_ray, n_steps, hits = raycast_algorithmic_bytes(n, rep, rep.get_pose())
+        out["raycast"] = {"us": round(t_ray * 1e6, 1), "rays_per_s": round(W * H / t_ray, 0), "march_steps_oracle": n_steps, "hit_rays": hits,
+                          "algorithmic_bytes": b_ray, "GBps": round(b_ray / t_ray / 1e9, 1)}
+    rep.close()
     return out
 
 
@@ -544,6 +587,16 @@ def run_single(args, hsk, torch, local_rank):
     torch.cuda.synchronize()
     trk, pose, lost, elapsed, per = timed_single(hsk, torch, n, K, Wm, args.ahead, dev_frames, local_rank, args.graph, args.sync_api)
     gt = poses_gt[total - 1]
+    # the SAME frames through the boundary's own calls: host pointers, pipelined (hsk_submit_frame /
+    # hsk_wait_frame: what INTEGRATION.md section 5 binds) and one hsk_process_frame per frame (SURVEY.md 8(d) metric (1))
+    api = {}
+    if not args.no_host_frames:
+        for key, kw in (("host_frames_pipelined_fps", {}), ("sync_process_frame_fps", {"sync_api": True})):
+            t_h, pose_h, lost_h, el_h, per_h = timed_single(hsk, torch, n, K, Wm, args.ahead, dev_frames, local_rank, args.graph, host_frames=frames, **kw)
+            t_h.close()
+            assert np.array_equal(pose_h, pose), "every API form must end on the same pose, bit for bit"
+            api[key] = round(K / el_h, 2)
+            api[key.replace("_fps", "_worst_frame_ms")] = round(float(per_h.max()), 3)
     out = {
         "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
         "value": round(K / elapsed, 2), "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": Wm,
@@ -555,6 +608,14 @@ def run_single(args, hsk, torch, local_rank):
                    "api": "process_frame (sync per frame)" if args.sync_api else "submit/wait (%d frame(s) in flight ahead)" % max(1, min(args.ahead, 2))},
         "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
                      "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
+        "device_frames_fps": round(K / elapsed, 2) if not args.sync_api else None,
+        "host_frames_pipelined_fps": api.get("host_frames_pipelined_fps"), "sync_process_frame_fps": api.get("sync_process_frame_fps"),
+        "api_note": ("value = device_frames_fps: the task contract defines `value` with the inputs already resident in HBM when the timed region "
+                     "starts and says the PCIe-inclusive rate is never `value`; the boundary's OWN call -- hsk_submit_frame / hsk_wait_frame with "
+                     "HOST pointers (HoniHelper.hs:45-46; INTEGRATION.md section 5), the same %d frames, memcpy into the pinned ring + H2D under the "
+                     "previous frame -- is host_frames_pipelined_fps, and SURVEY.md 8(d) metric (1), one hsk_process_frame(host pointer) per "
+                     "frame, is sync_process_frame_fps; all three end on the same pose bit for bit%s" % (K, "" if not api else
+                     "; worst single frame %.2f / %.2f ms" % (api["host_frames_pipelined_worst_frame_ms"], api["sync_process_frame_worst_frame_ms"]))),
         "frame_ms": {"median": round(float(np.median(per)), 4), "p10": round(float(np.percentile(per, 10)), 4),
                      "p90": round(float(np.percentile(per, 90)), 4),
                      "note": "host clock between consecutive hsk_wait_frame returns over the timed region"},
@@ -591,24 +652,6 @@ def run_single(args, hsk, torch, local_rank):
                                "note": "B_ray = steps x 4 B + hits x 64 taps x 4 B + map writes (SURVEY.md 8(d)); steps counted by the oracle on "
                                        "the volume and pose of the last timed frame; gather / latency-bound, reported as rays/s"})
     rep.close()
-    # ---- the frames handed over as HOST buffers (PCIe-inclusive), pipelined ----
-    if not args.no_host_frames:
-        hf = make_frames(hsk, total, min(60, max(8, K)))[1]
-        trk.synchronize()
-        t1 = time.perf_counter()
-        trk.submit_frame(hf[0])
-        stamps = []
-        for f in hf[1:]:
-            trk.submit_frame(f)
-            trk.wait_frame()
-            stamps.append(time.perf_counter())
-        trk.wait_frame()
-        trk.synchronize()   # (hsk_wait_frame returns when the POSE is final: the last frame's integrate and raycast may still be running)
-        t2 = time.perf_counter()
-        per_h = np.diff(np.array([t1] + stamps + [t2]))
-        out["pcie_inclusive_pipelined_fps"] = round(len(hf) / (t2 - t1), 2)
-        out["pcie_inclusive_note"] = ("hsk_submit_frame / hsk_wait_frame with HOST frames (memcpy into a pinned ring, H2D under the previous "
-                                      "frame), %d frames; worst single frame %.2f ms" % (len(hf), float(per_h.max()) * 1e3))
     if not args.no_readout:
         out["readout_ms"] = readout_block(trk, n)
         # the deferred weights' worst case: a host that DOWNLOADS THE VOLUME after every frame pays the flush every frame (the
@@ -620,7 +663,11 @@ def run_single(args, hsk, torch, local_rank):
         out["roofline"]["frac_with_flush_every_frame"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / ((out["stage_us"]["integrate"] + fl) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     trk.close()
     if not args.no_noise:
-        out["noise_%d" % n] = noise_block(args, hsk, torch, n, local_rank, out["value"])
+        # the room scan (camera INSIDE the volume: what HouseScan's rooms are made with), holes as a sensor makes them, and
+        # SURVEY.md 8(d)'s noise run -- each the timed region again on that stream
+        out["room_%d" % n] = stream_block(args, hsk, torch, n, local_rank, out["value"], "room0", with_counters=True, with_raycast_steps=True)
+        out["holes_%d" % n] = stream_block(args, hsk, torch, n, local_rank, out["value"], "holes")
+        out["noise_%d" % n] = stream_block(args, hsk, torch, n, local_rank, out["value"], "noise")
     if not args.no_rooms and n <= 512:
         out["concurrent_rooms_one_gpu"] = concurrent_rooms(hsk, n, dev_frames, local_rank)
     # ---- SURVEY.md 8(d) cfg2 / BASELINE configs[1]: the 300-frame scripted stream at 256^3, from a recorded file ----
@@ -663,634 +710,6 @@ def run_single(args, hsk, torch, local_rank):
     return out
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# N > 1.  `python bench.py --gpus N` is a LAUNCHER that never touches the GPU itself: for every form of the sharded path it
-# starts FRESH worker processes (one per GPU: `--child FORM`), watches them (heartbeat files; a form whose workers exit
-# non-zero or stall is killed and recorded as failed, the next form starts on new processes), and assembles ONE line from
-# what the workers of rank 0 wrote.  Bare invocation: this process starts all N workers.  Under torch.distributed.run
-# (the contract's launch line) every rank process is such a launcher for its own worker only; rank 0's is the director
-# (it decides the next form and publishes it as a file the others follow).  The workers of one form meet through a
-# torch.distributed FileStore in the launcher's scratch directory (gloo, host side only: the id, the barrier, the max of
-# the clocks); the data path's collectives are RCCL calls inside the library, or its one-hop peer exchange.
-# ---------------------------------------------------------------------------------------------------------------------
-SLAB_FORMS = ("rccl", "rccl_icp_allreduce", "direct")
-FORM_TEXT = {
-    "rccl": "RCCL: ncclAllReduce(MIN) of the raycast step keys + ncclAllReduce(SUM) of the winners' vertex / normal bits per frame; every slab "
-            "runs the whole ICP on the composited maps",
-    "rccl_icp_allreduce": "the north_star's literal form: the two RCCL composites per frame AND the ICP row-sharded over the slabs with its 27 sums "
-                          "ncclAllReduce'd at each of the 19 iterations (HSK_GROUP_ICP_ALLREDUCE)",
-    "direct": "one-hop peer writes over xGMI-mapped memory + stream wait / write-value flags (HSK_GROUP_DIRECT, no RCCL call on the frame path); "
-              "every slab runs the whole ICP",
-}
-
-
-def slab_range(i, n, Z):
-    base, rem = Z // n, Z % n
-    z0 = i * base + min(i, rem)
-    return z0, z0 + base + (1 if i < rem else 0)
-
-
-def slab_halo_planes(n, size_m=3.0, trunc=0.03):
-    """planes a slab stores beyond its own on each side (hskinfu_group.hip: slab_halo)"""
-    cell = size_m / n
-    tau = max(trunc, 2.1 * cell)
-    return int(np.ceil(2.0 * 0.8 * tau / cell)) + 3
-
-
-# single-GPU stage times (ICP, integrate, raycast; us) the multi-GPU prediction is priced from: this round's, and round 3's
-# (what DESIGN.md section 6's table was first written with: kept beside it as predicted_us_r03)
-STAGE_US_R05 = {512: (112.0, 58.0, 57.0), 1024: (113.0, 205.0, 73.0)}
-STAGE_US_R03 = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}
-
-
-def predicted_us(n, G, stage_us=None):
-    """the frame time of G z-slabs priced from the CURRENT single-GPU stage times and xGMI link rates
-    (arithmetic, never measured) -- carried in the line so that the first multi-GPU run adjudicates it"""
-    base = (stage_us or STAGE_US_R05).get(n)
-    if base is None or G < 2:
-        return None
-    icp, integ, ray = base
-    integ_g = integ * (1.0 / G + 2.0 * slab_halo_planes(n) / n)
-    ray_g = ray / G + 2.0
-    exch = {2: 30.0, 4: 38.0, 8: 45.0}.get(G, 30.0 + 2.5 * (G - 2))
-    adopt = 15.0
-    frame = icp + integ_g + ray_g + exch + adopt
-    return {"icp": icp, "integrate": round(integ_g, 1), "raycast": round(ray_g, 1), "slab_work_us": round(icp + integ_g + ray_g, 1),
-            "exchange_us": exch, "adopt_us": adopt, "frame_us": round(frame, 1), "frames_per_s": round(1e6 / frame, 1),
-            "single_gpu_frame_us": icp + integ + ray,
-            "source": "DESIGN.md section 6 (direct exchange; replicated ICP; from %s single-GPU stage times and ~100 GB/s per xGMI link)"
-                      % ("round 3's" if stage_us is STAGE_US_R03 else "round 5's")}
-
-
-def plane_crcs(vol):
-    """crc32 of every z plane of a [nz, Y, X, 2] int16 volume"""
-    import zlib
-    return [zlib.crc32(memoryview(np.ascontiguousarray(vol[z]))) for z in range(vol.shape[0])]
-
-
-def poses_digest(poses):
-    import hashlib
-    return hashlib.sha1(np.ascontiguousarray(np.stack(poses), np.float32).tobytes()).hexdigest()
-
-
-class Heartbeat:
-    """the worker's sign of life: a file whose content is the phase and whose mtime the launcher watches"""
-
-    def __init__(self, path):
-        self.path, self.phase = path, "start"
-
-    def __call__(self, phase=None):
-        if phase is not None:
-            self.phase = phase
-        if self.path:
-            try:
-                with open(self.path, "w") as f:
-                    f.write(self.phase)
-            except OSError:
-                pass
-
-
-def pipelined_run(first, submit, wait, total, Wm, barrier, hb):
-    """frame 0 and the warm-up through `first` (submit + wait), then the timed frames with one frame in flight ahead;
-    returns (seconds of the timed region, lost frames, pose of every frame)"""
-    poses, lost = [], 0
-    for i in range(1 + Wm):
-        p, _ = first(i)
-        poses.append(p.copy())
-    hb("warm")
-    barrier()
-    t0 = time.perf_counter()
-    submit(1 + Wm)
-    for i in range(2 + Wm, total):
-        submit(i)
-        p, ok = wait()
-        lost += (not ok)
-        poses.append(p.copy())
-        if (i & 63) == 0:
-            hb()
-    p, ok = wait()
-    lost += (not ok)
-    poses.append(p.copy())
-    barrier()
-    return time.perf_counter() - t0, lost, poses
-
-
-def child_main(args):
-    """one worker: rank RANK of WORLD_SIZE of form args.child, a fresh process on its own GPU"""
-    form, n = args.child, args.volume
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
-    tag = os.path.join(args.child_dir, args.child_tag)
-    hb = Heartbeat("%s.hb.%d" % (tag, rank))
-    hb("start")
-    import torch
-
-    import housescan_amd as hsk
-    have = check_build(args)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    hb("imported")
-    K, Wm = args.steps, args.warmup
-    total = 1 + Wm + K
-    single = form in ("single",)
-    dist = None
-    if not single:
-        import torch.distributed as dist
-        dist.init_process_group("gloo", init_method="file://" + tag + ".rdzv", rank=rank, world_size=world)
-    hb("rendezvous")
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    base, _, sub = form.partition(":")   # "pairs:direct" / "pairs:rccl"
-    room = rank // 2 if base == "pairs" else (rank if base == "rooms" else 0)
-    poses_gt, frames = make_frames(hsk, 25 * room, total)   # every room its own stretch of the trajectory; slabs: the stream's head
-    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
-    dev_frames = [dev_all[i] for i in range(total)]
-    torch.cuda.synchronize()
-    out = {"form": form, "volume": n, "world": world, "steps": K, "warmup": Wm, "build_id": have}
-    grp = trk = None
-    if base in ("single", "rooms"):
-        trk = hsk.KinfuTracker(n=n, device_id=local_rank)
-        submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
-        first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
-        wait = trk.wait_frame
-    else:
-        slab_form = sub if base == "pairs" else base
-        flags = hsk.GROUP_PROFILE | {"rccl": 0, "rccl_icp_allreduce": hsk.GROUP_ICP_ALLREDUCE, "direct": hsk.GROUP_DIRECT}[slab_form]
-        if base == "pairs":
-            pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
-            g_rank, g_world, g_src, g_pg = rank % 2, 2, 2 * room, pgs[room]
-        else:
-            g_rank, g_world, g_src, g_pg = rank, world, 0, None
-        if g_world == 1 and not (flags & hsk.GROUP_DIRECT):
-            flags |= hsk.GROUP_FORCE_RCCL   # a world of one rank still goes through ncclCommInitRank and the two all-reduces
-        ids = [(os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == g_src else None]
-        dist.broadcast_object_list(ids, src=g_src, group=g_pg)
-        try:
-            grp, why = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=g_rank, world=g_world, comm_id=ids[0], flags=flags), None
-        except hsk.KinfuError as e:
-            why = str(e)
-        ok = torch.tensor([0 if grp is None else 1])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if not bool(ok.item()):   # every rank learns it: nobody is left waiting in a collective
-            if rank == 0 or why:
-                sys.stderr.write("bench.py worker %d: the group of form %s could not be created: %s\n" % (rank, form, why or "a peer rank failed"))
-            raise SystemExit(3)
-        out["ranks_seen"] = grp.ranks_seen()
-        submit = lambda i: grp.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
-        wait = grp.wait_frame
-
-        def first(i):
-            submit(i)
-            return wait()
-    hb("created")
-    elapsed, lost, poses = pipelined_run(first, submit, wait, total, Wm, barrier, hb)
-    elapsed = max_over_ranks(elapsed)
-    hb("timed")
-    rooms = world if base == "rooms" else (world // 2 if base == "pairs" else 1)
-    gt = poses_gt[total - 1]
-    out.update({"value": round(rooms * K / elapsed, 2), "unit": "frames/s", "ms_per_step": round(1000.0 * elapsed / K, 4), "rooms": rooms,
-                "lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(poses[-1][:3, 3] - gt[:3, 3]) * 1000.0), 3),
-                "final_pose_f32_hex": np.ascontiguousarray(poses[-1][:3, :4], np.float32).tobytes().hex(), "poses_sha1": poses_digest(poses)})
-    if grp is not None:
-        ms, front, cnt = grp.exchange_ms()
-        if cnt:
-            out["stage_us"] = {"slab_work_us": round(1e3 * front / cnt, 1), "exchange_us": round(1e3 * ms / cnt, 1), "frames": int(cnt),
-                               "note": "rank 0's device, HIP events: slab work = ICP (with its all-reduces in the icp_allreduce form) + integrate + "
-                                       "slab-local raycast of a frame; exchange = the two composites, waits for the peers included"}
-    # ---- the check against ONE context on the same frames: every pose of the run, and every stored plane of every slab ----
-    ref_path = os.path.join(args.child_dir, "single_%d.json" % n)
-    if base == "single":
-        vol = trk.download_tsdf()
-        out["plane_crc"] = plane_crcs(vol)
-        del vol
-    elif base in SLAB_FORMS:
-        sl = grp.slab(0)
-        vol = sl.download_tsdf()
-        mine = {"rank": rank, "z0": int(sl.stored_z0), "crc": plane_crcs(vol)}
-        del vol
-        hb("crc")
-        got = [None] * world if rank == 0 else None
-        dist.gather_object(mine, got, dst=0)
-        if rank == 0 and os.path.exists(ref_path):
-            ref = json.load(open(ref_path))
-            planes_ok = all(g["crc"] == ref["plane_crc"][g["z0"]:g["z0"] + len(g["crc"])] for g in got)
-            covered = sum(slab_range(r, world, n)[1] - slab_range(r, world, n)[0] for r in range(world)) == n
-            out["matches_single_gpu"] = bool(planes_ok and covered and out["poses_sha1"] == ref["poses_sha1"] and
-                                             out["final_pose_f32_hex"] == ref["final_pose_f32_hex"])
-            out["matches_detail"] = {"every_pose_of_the_run": out["poses_sha1"] == ref["poses_sha1"],
-                                     "every_stored_plane_of_every_slab_crc32": bool(planes_ok), "planes_compared": int(sum(len(g["crc"]) for g in got))}
-    elif rank == 0 and os.path.exists(ref_path):   # rooms / pairs: rank 0's room runs the same frames as the single context
-        ref = json.load(open(ref_path))
-        out["matches_single_gpu"] = bool(out["poses_sha1"] == ref["poses_sha1"])
-        out["matches_detail"] = {"every_pose_of_room_0": out["matches_single_gpu"]}
-    hb("checked")
-    if grp is not None:
-        grp.close()
-    if trk is not None:
-        trk.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        for path in [tag + ".json"] + ([ref_path] if base == "single" else []):   # (the single context's result is also the later forms' reference)
-            with open(path + ".tmp", "w") as f:
-                json.dump(out, f)
-            os.replace(path + ".tmp", path)
-    hb("done")
-
-
-def visible_gpu_count():
-    """GPUs this process's workers could open, WITHOUT a HIP call (the launcher must stay a process that has never touched the
-    GPU): the kfd topology's nodes with SIMDs, cut down by a *_VISIBLE_DEVICES list.  0 = cannot tell (no kfd here)."""
-    import glob
-    n = 0
-    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-        try:
-            for line in open(path):
-                f = line.split()
-                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
-                    n += 1
-        except (OSError, ValueError):
-            pass
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if n and v is not None and v.strip():
-            n = min(n, len([x for x in v.split(",") if x.strip()]))
-    return n
-
-
-class Launcher:
-    """see the comment block above"""
-    # seconds without a sign of life before the workers of a form are killed: while torch / the library are being paged
-    # in (a fresh box: minutes), afterwards (HSK_BENCH_STALL_S overrides it), and a follower's wait for the director
-    IMPORT_STALL_S, STALL_S, STEP_FILE_S = 420.0, float(os.environ.get("HSK_BENCH_STALL_S", "150")), 1800.0
-
-    def __init__(self, args, argv):
-        self.args, self.world = args, args.gpus
-        self.torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-        if self.torchrun:
-            self.my_ranks = [int(os.environ["RANK"])]
-            # one scratch directory per RUN: the launcher's pid of torch.distributed.run, its port and its run id -- and the
-            # director empties it before it publishes anything, so that nothing a crashed earlier run left under the same
-            # name (step files, rendezvous files, a single-context reference) can be replayed; followers wait for the nonce
-            self.dir = os.path.join(tempfile.gettempdir(), "hskbench_%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"),
-                                                                                 "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "") if c.isalnum())[:24]))
-            if int(os.environ["RANK"]) == 0:
-                shutil.rmtree(self.dir, ignore_errors=True)
-                os.makedirs(self.dir, exist_ok=True)
-                with open(os.path.join(self.dir, "nonce.tmp"), "w") as f:
-                    f.write(str(os.getpid()))
-                os.replace(os.path.join(self.dir, "nonce.tmp"), os.path.join(self.dir, "nonce"))
-            else:
-                t_end = time.time() + 600.0
-                while not os.path.exists(os.path.join(self.dir, "nonce")) and time.time() < t_end:
-                    time.sleep(0.05)
-        else:
-            self.my_ranks = list(range(self.world))
-            self.dir = tempfile.mkdtemp(prefix="hskbench_")
-        self.director = 0 in self.my_ranks
-        self.step_no = 0
-        self.failed = {}
-        self.log_tail = {}
-
-    # ---- one step: the workers of one form at one volume ----
-    def spawn(self, step):
-        a = self.args
-        procs = []
-        for r in step["ranks"]:
-            if r not in self.my_ranks:
-                continue
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(len(step["ranks"])), GLOO_SOCKET_IFNAME=os.environ.get("GLOO_SOCKET_IFNAME", "lo"),
-                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                       HSK_FRAME_TIMEOUT_S=os.environ.get("HSK_FRAME_TIMEOUT_S", "30"))
-            if not self.torchrun or "LOCAL_RANK" not in os.environ:
-                env["LOCAL_RANK"] = str(r)
-            for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "OMP_NUM_THREADS"):
-                env.pop(v, None)
-            # (HSK_BENCH_WORKER: the CPU tests of the launcher put a scripted stand-in for the GPU worker here)
-            cmd = [sys.executable, os.environ.get("HSK_BENCH_WORKER") or os.path.join(ROOT, "bench.py"), "--child", step["form"], "--child-dir", self.dir, "--child-tag", step["tag"],
-                   "--gpus", str(self.world), "--steps", str(step["steps"]), "--warmup", str(step["warmup"]), "--volume", str(step["volume"])]
-            if a.share_gpu:
-                cmd.append("--share-gpu")
-            if a.allow_exp:
-                cmd.append("--allow-exp")
-            log = open(os.path.join(self.dir, "%s.log.%d" % (step["tag"], r)), "w")
-            procs.append((r, subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True), log))
-        return procs
-
-    def kill(self, procs):
-        import signal
-        for _, p, _ in procs:   # exactly the process groups this launcher started
-            if p.poll() is None:
-                try:
-                    os.killpg(p.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-        for _, p, _ in procs:
-            try:
-                p.wait(timeout=30)
-            except subprocess.TimeoutExpired:
-                pass
-
-    def watch(self, step, procs):
-        """wait for the workers; (ok, why)"""
-        t_start = time.time()
-        first_bad = None
-        while True:
-            codes = [p.poll() for _, p, _ in procs]
-            if all(c is not None for c in codes):
-                break
-            now = time.time()
-            if any(c not in (None, 0) for c in codes):
-                first_bad = first_bad or now
-                if now - first_bad > 20.0:   # a worker failed: its peers get a moment to notice, then go too
-                    self.kill(procs)
-                    break
-            newest, phases = t_start, []
-            for r, _, _ in procs:
-                hbp = os.path.join(self.dir, "%s.hb.%d" % (step["tag"], r))
-                try:
-                    newest = max(newest, os.path.getmtime(hbp))
-                    phases.append(open(hbp).read() or "start")
-                except OSError:
-                    phases.append("not started")
-            limit = self.IMPORT_STALL_S if any(ph in ("not started", "start") for ph in phases) else self.STALL_S
-            if now - newest > limit:
-                self.kill(procs)
-                for _, _, log in procs:
-                    log.close()
-                return False, "stalled for %.0f s in phase %s: workers killed" % (limit, "/".join(sorted(set(phases))))
-            time.sleep(0.05)
-        for _, _, log in procs:
-            log.close()
-        codes = [p.returncode for _, p, _ in procs]
-        if any(c != 0 for c in codes):
-            tails = []
-            for r, p, _ in procs:
-                if p.returncode != 0:
-                    try:
-                        lines = open(os.path.join(self.dir, "%s.log.%d" % (step["tag"], r))).read().strip().splitlines()
-                    except OSError:
-                        lines = []
-                    tails.append("rank %d rc %s: %s" % (r, p.returncode, " | ".join(lines[-3:])[-400:]))
-            return False, "; ".join(tails)
-        return True, None
-
-    def run_step(self, form, volume, ranks=None, steps=None, warmup=None):
-        """director: publish the step, run my share of it; returns rank 0's result dict or None"""
-        a = self.args
-        step = {"form": form, "volume": volume, "ranks": list(range(self.world)) if ranks is None else ranks,
-                "steps": a.steps if steps is None else steps, "warmup": a.warmup if warmup is None else warmup,
-                "tag": "s%02d_%s_%d" % (self.step_no, form.replace(":", "_"), volume)}
-        self.publish(step)
-        return self.execute(step)
-
-    def publish(self, step):
-        path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
-        with open(path + ".tmp", "w") as f:
-            json.dump(step, f)
-        os.replace(path + ".tmp", path)
-        self.step_no += 1
-
-    def execute(self, step):
-        procs = self.spawn(step)
-        if not procs:
-            return None
-        ok, why = self.watch(step, procs)
-        res_path = os.path.join(self.dir, step["tag"] + ".json")
-        if ok and (0 not in [r for r, _, _ in procs] or os.path.exists(res_path)):
-            return json.load(open(res_path)) if os.path.exists(res_path) else {}
-        self.failed["%s@%d" % (step["form"], step["volume"])] = why or "no result written"
-        return None
-
-    def follow(self):
-        """a launcher that is not the director (torch.distributed.run, rank != 0): run my worker of every published step"""
-        while True:
-            path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
-            t0 = time.time()
-            while not os.path.exists(path):
-                # the director removes the scratch directory when it has printed the line: that, too, says "done" (a
-                # follower whose last worker exits late must not wait for a file that will never come)
-                if not os.path.isdir(self.dir) or time.time() - t0 > self.STEP_FILE_S:
-                    return 0   # the director is done or gone; nothing of this rank's is left running
-                time.sleep(0.05)
-            step = json.load(open(path))
-            self.step_no += 1
-            if step["form"] == "done":
-                return 0
-            self.execute(step)
-
-    # ---- the director's plan and the line ----
-    def direct(self):
-        a, n, G = self.args, self.args.volume, self.world
-        t_begin = time.time()
-        single = self.run_step("single", n, ranks=[0])
-        rooms = self.run_step("rooms", n) if (a.mode in ("slab", "rooms") and not a.no_rooms) or a.mode == "rooms" else None
-        forms = {}
-        if a.mode == "slab":
-            for f in a.forms:
-                forms[f] = self.run_step(f, n)
-        # (a form counts only when it was CHECKED against the single context and matched: without the reference -- the
-        # `single` step failed -- nothing is "good", and the line falls back to the weak-scaling head below)
-        good = {f: r for f, r in forms.items() if r and r.get("matches_single_gpu") is True and not r["lost_frames"]}
-        best = max(good, key=lambda f: good[f]["value"]) if good else None
-        pairs = None
-        if a.mode == "pairs" or (a.mode == "slab" and G >= 4 and G % 2 == 0 and not a.no_rooms):
-            sub = "direct" if (a.mode == "pairs" and "direct" in a.forms) or (forms.get("direct") and "direct" in good) else "rccl"
-            pairs = self.run_step("pairs:" + sub, n)
-            if pairs is None and sub == "direct":
-                pairs = self.run_step("pairs:rccl", n)
-        big = None
-        if a.mode == "slab" and n == 512 and not a.no_1024 and best is not None:
-            K2, W2 = min(a.steps, 40), min(a.warmup, 5)
-            s2 = self.run_step("single", 1024, ranks=[0], steps=K2, warmup=W2)
-            order = [best] + [f for f in sorted(good, key=lambda f: -good[f]["value"]) if f != best]
-            r2 = f2 = None
-            for f in order:
-                r2, f2 = self.run_step(f, 1024, steps=K2, warmup=W2), f
-                if r2 and r2.get("matches_single_gpu") is True:
-                    break
-            big = {"workload": "configs[3]: ONE 1024^3 TSDF as %d z-slabs, the same synthetic stream, %d timed frames" % (G, K2),
-                   "single_gpu_same_frames": None if s2 is None else {k: s2[k] for k in ("value", "unit", "ms_per_step", "lost_frames")},
-                   "form": f2, "slabs": None if r2 is None else {k: r2[k] for k in r2 if k not in ("build_id", "form", "world", "volume")},
-                   "speedup_vs_single_gpu": None if not (r2 and s2) else round(r2["value"] / s2["value"], 3),
-                   "predicted_us": predicted_us(1024, G), "predicted_us_r03": predicted_us(1024, G, STAGE_US_R03)}
-        self.publish({"form": "done"})
-        # ---- the line ----
-        K, Wm = a.steps, a.warmup
-        strip = lambda r: None if r is None else {k: r[k] for k in r if k not in ("build_id", "form", "world", "volume", "steps", "warmup", "plane_crc")}  # noqa: E731
-        head = good[best] if best else None
-        if head is None and a.mode == "pairs" and pairs:
-            head = pairs
-        if head is None and rooms:
-            head = rooms   # no slab form ran to a checked result: the weak-scaling partition is what this node measured
-        if head is None:
-            sys.stderr.write("bench.py: no form of the %d-GPU path completed: %s\n" % (G, json.dumps(self.failed)))
-            self.dump_logs()
-            return None
-        slab_head = best is not None
-        out = {
-            "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
-            "value": head["value"], "unit": "frames/s", "n_gpus": G, "steps": K, "warmup": Wm, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong" if slab_head else "weak", "vs_baseline": None,
-            "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
-            "config": {"workload": ("configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n) if slab_head else
-                                   ("configs[4]: %d concurrent %d^3 rooms, a GPU pair (two z-slabs) each" % (head["rooms"], n) if head is pairs else
-                                    "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n),
-                       "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
-                       "parallelism": ("slab%d-%s" % (G, best)) if slab_head else ("pairs%d" % head["rooms"] if head is pairs else "rooms%d" % G),
-                       "exchange": FORM_TEXT.get(best) if slab_head else None,
-                       "api": "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI), 1 frame in flight ahead" if (slab_head or head is pairs)
-                              else "hsk_submit_frame_dev / hsk_wait_frame"},
-            "headline_form": best if slab_head else ("pairs" if head is pairs else "rooms"),
-            "headline_note": ("value = the fastest z-slab form whose every pose and every stored TSDF plane equal a single context's on the same "
-                              "frames (strong scaling of ONE volume); rooms_weak = the same GPUs with one independent room each") if slab_head else
-                             "no z-slab form completed with a checked result on this node (see forms / failed_forms): value is the weak-scaling partition",
-            "matches_single_gpu": head.get("matches_single_gpu"),
-            "ranks_seen": head.get("ranks_seen", G if not slab_head else None),
-            "tracking": {"lost_frames": head["lost_frames"], "final_translation_error_mm": head["final_translation_error_mm"],
-                         "final_pose_f32_hex": head["final_pose_f32_hex"]},
-            "rooms_weak": None if rooms is None else dict(strip(rooms), scaling="weak",
-                                                            workload="one %d^3 room per GPU, hsk_submit_frame_dev / hsk_wait_frame, %d frames each, no data-path collective" % (n, K)),
-            "forms": {f: (dict(strip(r), what=FORM_TEXT[f]) if r else {"failed": self.failed.get("%s@%d" % (f, n), "failed")}) for f, r in forms.items()},
-            "single_gpu_same_frames": None if single is None else {k: single[k] for k in ("value", "unit", "ms_per_step", "lost_frames", "final_pose_f32_hex")},
-            "speedup_vs_single_gpu": None if not (single and slab_head) else round(head["value"] / single["value"], 3),
-            "predicted_us": predicted_us(n, G), "predicted_us_r03": predicted_us(n, G, STAGE_US_R03),
-        }
-        if head.get("stage_us"):
-            out["stage_us"] = head["stage_us"]
-        if pairs is not None:
-            out["pairs_weak"] = dict(strip(pairs), scaling="weak", workload="BASELINE configs[4]: one %d^3 room per GPU pair (two z-slabs, own exchange)" % n)
-        if big is not None:
-            out["slabs_1024"] = big
-        out["launcher"] = {"mode": "torch.distributed.run: every rank process launches its own fresh worker per form" if self.torchrun else
-                                   "bare: this process launched all %d workers of every form" % G,
-                           "failed_forms": self.failed, "wall_s": round(time.time() - t_begin, 1),
-                           "share_gpu_check_only": bool(a.share_gpu)}
-        out["build_id"] = head.get("build_id")
-        # (build_id.py is loaded by path: importing the package would load libhskinfu.so -- and the HIP runtime -- into the launcher)
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("hsk_build_id", os.path.join(ROOT, "housescan_amd", "csrc", "build_id.py"))
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        if out["build_id"] != mod.build_id():
-            out["experimental_build"] = True
-        return out
-
-    def dump_logs(self):
-        for f in sorted(glob.glob(os.path.join(self.dir, "*.log.*"))):
-            try:
-                txt = open(f).read().strip().splitlines()[-6:]
-            except OSError:
-                continue
-            if txt:
-                sys.stderr.write("--- %s\n%s\n" % (os.path.basename(f), "\n".join(txt)))
-
-    def cleanup(self):
-        if self.director:
-            time.sleep(0.2)
-            shutil.rmtree(self.dir, ignore_errors=True)
-
-
-def check_build(args):
-    """The measured library must be the default build of THIS tree: "+exp" marks other compiler flags (timing experiments,
-    some of which give wrong results by construction), a different hash a stale .so.  tests/conftest.py refuses both too."""
-    from housescan_amd import _lib
-    from housescan_amd.csrc import build_id as tree_id
-    have, want = _lib.load().hsk_build_id().decode(), tree_id.build_id()
-    if have != want and not args.allow_exp:
-        raise SystemExit("bench.py: housescan_amd/libhskinfu.so is build %s, the tree is %s -- rebuild with "
-                         "`python -c 'import __graft_entry__ as g; g.build()'` (or pass --allow-exp for a timing experiment)" % (have, want))
-    return have
-
-
-def run_multi_torch(args, hsk, torch, world, rank, local_rank):
-    """The N > 1 slab flow with the collectives issued from Python through torch.distributed (housescan_amd/sharded.py:
-    the harness the group call was checked against).  --backend gloo --share-gpu runs all ranks on device 0: a logic
-    check of the flow on a one-GPU box, its numbers mean nothing."""
-    import torch.distributed as dist
-    from housescan_amd.sharded import ShardedKinfu
-    if args.backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    K, Wm, n = args.steps, args.warmup, args.volume
-    total = 1 + Wm + K
-    poses_gt, frames = make_frames(hsk, 0, total)
-    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
-    dev_frames = [dev_all[i] for i in range(total)]
-    torch.cuda.synchronize()
-    eng = ShardedKinfu(n, rank, world, local_rank, mode="slab", icp=args.icp)
-
-    def barrier():
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    lost = 0
-    for i in range(1 + Wm):
-        eng.process_frame_dev(dev_frames[i])
-    barrier()
-    t0 = time.perf_counter()
-    if args.icp == "replicated":
-        nxt = lambda i: dev_frames[i + 1] if i + 1 < total else None  # noqa: E731
-        eng.submit_frame_dev(dev_frames[1 + Wm], nxt(1 + Wm))
-        for i in range(2 + Wm, total):
-            eng.submit_frame_dev(dev_frames[i], nxt(i))
-            pose, ok = eng.wait_frame()
-            lost += (not ok)
-        pose, ok = eng.wait_frame()
-        lost += (not ok)
-    else:
-        for i in range(1 + Wm, total):
-            pose, ok = eng.process_frame_dev(dev_frames[i], dev_frames[i + 1] if i + 1 < total else None)
-            lost += (not ok)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
-    gt = poses_gt[total - 1]
-    out = {
-        "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
-        "value": round(K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
-        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n, "volume": n, "image": [W, H],
-                   "icp_iters": [10, 5, 4], "parallelism": "slab%d-icp-%s" % (world, args.icp),
-                   "api": "housescan_amd/sharded.py over torch.distributed (%s)" % args.backend,
-                   **({"check_only": "all ranks share device 0 over %s" % args.backend} if args.share_gpu else {})},
-        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
-                     "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
-    }
-    dist.barrier()
-    dist.destroy_process_group()
-    return out if rank == 0 else None
-
-
-def emit(out, have=None, want=None):
-    """the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's buffer until then"""
-    sys.stdout.flush()
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except OSError:
-        pass
-    print(json.dumps(out))
-    sys.stdout.flush()
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1300,14 +719,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the oracle-counted raycast bytes)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--no-1024", action="store_true", help="skip the 1024^3 block (N = 1: roofline_1024; N > 1: slabs_1024)")
-    ap.add_argument("--no-host-frames", action="store_true", help="skip the PCIe-inclusive (host frame) figure")
+    ap.add_argument("--no-host-frames", action="store_true", help="skip the host-pointer figures (host_frames_pipelined_fps, sync_process_frame_fps)")
     ap.add_argument("--no-readout", action="store_true", help="skip the read-out timings (flush of the deferred weights, cloud, volume download)")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 300-frame recorded-stream replay at 256^3 (trajectory report)")
     ap.add_argument("--stream", default=None, metavar="FILE.hskd",
                     help="time the replay of a recorded depth stream through hsk_track_stream instead of the synthetic in-HBM frames "
                          "(a missing FILE is first recorded from the 300-frame synthetic stream)")
     ap.add_argument("--no-rooms", action="store_true", help="skip the concurrent-room blocks (N = 1: 2 and 4 rooms at once on the one GPU; N > 1, --mode slab: one room per GPU, a room per GPU pair)")
-    ap.add_argument("--no-noise", action="store_true", help="skip the noise run (the timed region again on the stream with sensor noise: noise_<volume>)")
+    ap.add_argument("--no-noise", action="store_true", help="skip the other-stream blocks (the timed region again on the room scan, the sensor-holes stream and the noise run: room_ / holes_ / noise_<volume>)")
     ap.add_argument("--quick", action="store_true", help="all of the above")
     ap.add_argument("--ahead", type=int, default=1, help="frames submitted ahead of the one being waited for (1 or 2)")
     ap.add_argument("--graph", type=int, default=0, help="synchronous frames replayed from a hipGraph (default: eager, through the ring)")
@@ -1348,34 +767,15 @@ def main():
         args.forms = list(SLAB_FORMS)
 
     if args.child:
-        return child_main(args)
+        import bench_launcher
+        return bench_launcher.child_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     multi = args.gpus > 1 or world > 1 or bool(os.environ.get("HSK_BENCH_FORCE_MULTI"))  # (the variable: the N > 1 flow on one rank, for the tests)
     if multi and not args.stream and not (args.engine == "torch" and args.mode == "slab"):
-        # the launcher: no GPU call, no torch import in THIS process (its workers are fresh processes, never an exec)
-        if world > 1 and world != args.gpus:
-            raise SystemExit("bench.py: --gpus %d under a launch of %d ranks" % (args.gpus, world))
-        if args.mode == "pairs" and args.gpus % 2:
-            raise SystemExit("--mode pairs needs an even number of GPUs")
-        seen = visible_gpu_count()
-        if 0 < seen < args.gpus and not args.share_gpu:
-            # (said at once, by the launcher: the workers would each find it out after their imports, a minute and a half later)
-            sys.stderr.write("bench.py: --gpus %d, but this box shows %d GPU%s; --share-gpu runs the ranks on one device (a correctness "
-                             "run of the N > 1 paths, not a measurement)\n" % (args.gpus, seen, "" if seen == 1 else "s"))
-            raise SystemExit(2)
-        L = Launcher(args, sys.argv)
-        if not L.director:
-            return L.follow()
-        try:
-            out = L.direct()
-        finally:
-            L.cleanup()
-        if out is None:
-            raise SystemExit(1)
-        emit(out)
-        return 0
+        import bench_launcher   # (no GPU call, no torch import in THIS process: its workers are fresh processes, never an exec)
+        return bench_launcher.launch(args)
 
     import torch
 
@@ -1401,7 +801,8 @@ def main():
     elif multi:   # --engine torch --mode slab, launched by torch.distributed.run
         if world != args.gpus:
             raise SystemExit("--engine torch must be launched with torch.distributed.run --nproc-per-node N")
-        out = run_multi_torch(args, hsk, torch, world, rank, local_rank)
+        import bench_launcher
+        out = bench_launcher.run_multi_torch(args, hsk, torch, world, rank, local_rank)
     else:
         out = run_single(args, hsk, torch, local_rank)
     if rank == 0 and out is not None:

@@ -1,0 +1,651 @@
+"""bench_launcher.py -- `python bench.py --gpus N` (N > 1): the launcher, its watchdog, the workers and the torchrun bridge.
+
+Split out of bench.py in round 6: bench.py holds the single-GPU line the driver hashes, this file
+everything that exists because there is more than one rank.  bench.py's main() hands over to launch() / child_main() /
+run_multi_torch(); the workers are started as `bench.py --child FORM`, so there is one entry point.
+"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+from bench_common import ROOT, SLAB_FORMS, W, H, check_build, emit, make_frames
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1.  `python bench.py --gpus N` is a LAUNCHER that never touches the GPU itself: for every form of the sharded path it
+# starts FRESH worker processes (one per GPU: `--child FORM`), watches them (heartbeat files; a form whose workers exit
+# non-zero or stall is killed and recorded as failed, the next form starts on new processes), and assembles ONE line from
+# what the workers of rank 0 wrote.  Bare invocation: this process starts all N workers.  Under torch.distributed.run
+# (the contract's launch line) every rank process is such a launcher for its own worker only; rank 0's is the director
+# (it decides the next form and publishes it as a file the others follow).  The workers of one form meet through a
+# torch.distributed FileStore in the launcher's scratch directory (gloo, host side only: the id, the barrier, the max of
+# the clocks); the data path's collectives are RCCL calls inside the library, or its one-hop peer exchange.
+# ---------------------------------------------------------------------------------------------------------------------
+FORM_TEXT = {
+    "rccl": "RCCL: ncclAllReduce(MIN) of the raycast step keys + ncclAllReduce(SUM) of the winners' vertex / normal bits per frame; every slab "
+            "runs the whole ICP on the composited maps",
+    "rccl_icp_allreduce": "the north_star's literal form: the two RCCL composites per frame AND the ICP row-sharded over the slabs with its 27 sums "
+                          "ncclAllReduce'd at each of the 19 iterations (HSK_GROUP_ICP_ALLREDUCE)",
+    "direct": "one-hop peer writes over xGMI-mapped memory + stream wait / write-value flags (HSK_GROUP_DIRECT, no RCCL call on the frame path); "
+              "every slab runs the whole ICP",
+}
+
+
+def slab_range(i, n, Z):
+    base, rem = Z // n, Z % n
+    z0 = i * base + min(i, rem)
+    return z0, z0 + base + (1 if i < rem else 0)
+
+
+def slab_halo_planes(n, size_m=3.0, trunc=0.03):
+    """planes a slab stores beyond its own on each side (hskinfu_group.hip: slab_halo)"""
+    cell = size_m / n
+    tau = max(trunc, 2.1 * cell)
+    return int(np.ceil(2.0 * 0.8 * tau / cell)) + 3
+
+
+# single-GPU stage times (ICP, integrate, raycast; us) the multi-GPU prediction is priced from: this round's, and round 3's
+# (what DESIGN.md section 6's table was first written with: kept beside it as predicted_us_r03)
+STAGE_US_R05 = {512: (112.0, 58.0, 57.0), 1024: (113.0, 205.0, 73.0)}
+STAGE_US_R03 = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}
+
+
+def predicted_us(n, G, stage_us=None):
+    """the frame time of G z-slabs priced from the CURRENT single-GPU stage times and xGMI link rates
+    (arithmetic, never measured) -- carried in the line so that the first multi-GPU run adjudicates it"""
+    base = (stage_us or STAGE_US_R05).get(n)
+    if base is None or G < 2:
+        return None
+    icp, integ, ray = base
+    integ_g = integ * (1.0 / G + 2.0 * slab_halo_planes(n) / n)
+    ray_g = ray / G + 2.0
+    exch = {2: 30.0, 4: 38.0, 8: 45.0}.get(G, 30.0 + 2.5 * (G - 2))
+    adopt = 15.0
+    frame = icp + integ_g + ray_g + exch + adopt
+    return {"icp": icp, "integrate": round(integ_g, 1), "raycast": round(ray_g, 1), "slab_work_us": round(icp + integ_g + ray_g, 1),
+            "exchange_us": exch, "adopt_us": adopt, "frame_us": round(frame, 1), "frames_per_s": round(1e6 / frame, 1),
+            "single_gpu_frame_us": icp + integ + ray,
+            "source": "DESIGN.md section 6 (direct exchange; replicated ICP; from %s single-GPU stage times and ~100 GB/s per xGMI link)"
+                      % ("round 3's" if stage_us is STAGE_US_R03 else "round 5's")}
+
+
+def plane_crcs(vol):
+    """crc32 of every z plane of a [nz, Y, X, 2] int16 volume"""
+    import zlib
+    return [zlib.crc32(memoryview(np.ascontiguousarray(vol[z]))) for z in range(vol.shape[0])]
+
+
+def poses_digest(poses):
+    import hashlib
+    return hashlib.sha1(np.ascontiguousarray(np.stack(poses), np.float32).tobytes()).hexdigest()
+
+
+class Heartbeat:
+    """the worker's sign of life: a file whose content is the phase and whose mtime the launcher watches"""
+
+    def __init__(self, path):
+        self.path, self.phase = path, "start"
+
+    def __call__(self, phase=None):
+        if phase is not None:
+            self.phase = phase
+        if self.path:
+            try:
+                with open(self.path, "w") as f:
+                    f.write(self.phase)
+            except OSError:
+                pass
+
+
+def pipelined_run(first, submit, wait, total, Wm, barrier, hb):
+    """frame 0 and the warm-up through `first` (submit + wait), then the timed frames with one frame in flight ahead;
+    returns (seconds of the timed region, lost frames, pose of every frame)"""
+    poses, lost = [], 0
+    for i in range(1 + Wm):
+        p, _ = first(i)
+        poses.append(p.copy())
+    hb("warm")
+    barrier()
+    t0 = time.perf_counter()
+    submit(1 + Wm)
+    for i in range(2 + Wm, total):
+        submit(i)
+        p, ok = wait()
+        lost += (not ok)
+        poses.append(p.copy())
+        if (i & 63) == 0:
+            hb()
+    p, ok = wait()
+    lost += (not ok)
+    poses.append(p.copy())
+    barrier()
+    return time.perf_counter() - t0, lost, poses
+
+
+def child_main(args):
+    """one worker: rank RANK of WORLD_SIZE of form args.child, a fresh process on its own GPU"""
+    form, n = args.child, args.volume
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
+    tag = os.path.join(args.child_dir, args.child_tag)
+    hb = Heartbeat("%s.hb.%d" % (tag, rank))
+    hb("start")
+    import torch
+
+    import housescan_amd as hsk
+    have = check_build(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    hb("imported")
+    K, Wm = args.steps, args.warmup
+    total = 1 + Wm + K
+    single = form in ("single",)
+    dist = None
+    if not single:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="file://" + tag + ".rdzv", rank=rank, world_size=world)
+    hb("rendezvous")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    base, _, sub = form.partition(":")   # "pairs:direct" / "pairs:rccl"
+    room = rank // 2 if base == "pairs" else (rank if base == "rooms" else 0)
+    poses_gt, frames = make_frames(hsk, 25 * room, total)   # every room its own stretch of the trajectory; slabs: the stream's head
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+    dev_frames = [dev_all[i] for i in range(total)]
+    torch.cuda.synchronize()
+    out = {"form": form, "volume": n, "world": world, "steps": K, "warmup": Wm, "build_id": have}
+    grp = trk = None
+    if base in ("single", "rooms"):
+        trk = hsk.KinfuTracker(n=n, device_id=local_rank)
+        submit = lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
+        first = lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())  # noqa: E731
+        wait = trk.wait_frame
+    else:
+        slab_form = sub if base == "pairs" else base
+        flags = hsk.GROUP_PROFILE | {"rccl": 0, "rccl_icp_allreduce": hsk.GROUP_ICP_ALLREDUCE, "direct": hsk.GROUP_DIRECT}[slab_form]
+        if base == "pairs":
+            pgs = [dist.new_group([2 * p, 2 * p + 1]) for p in range(world // 2)]  # (every rank creates every group)
+            g_rank, g_world, g_src, g_pg = rank % 2, 2, 2 * room, pgs[room]
+        else:
+            g_rank, g_world, g_src, g_pg = rank, world, 0, None
+        if g_world == 1 and not (flags & hsk.GROUP_DIRECT):
+            flags |= hsk.GROUP_FORCE_RCCL   # a world of one rank still goes through ncclCommInitRank and the two all-reduces
+        ids = [(os.urandom(128) if (flags & hsk.GROUP_DIRECT) else hsk.KinfuGroup.unique_id()) if rank == g_src else None]
+        dist.broadcast_object_list(ids, src=g_src, group=g_pg)
+        try:
+            grp, why = hsk.KinfuGroup(hsk.default_config(n, device_id=local_rank), rank=g_rank, world=g_world, comm_id=ids[0], flags=flags), None
+        except hsk.KinfuError as e:
+            why = str(e)
+        ok = torch.tensor([0 if grp is None else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not bool(ok.item()):   # every rank learns it: nobody is left waiting in a collective
+            if rank == 0 or why:
+                sys.stderr.write("bench.py worker %d: the group of form %s could not be created: %s\n" % (rank, form, why or "a peer rank failed"))
+            raise SystemExit(3)
+        out["ranks_seen"] = grp.ranks_seen()
+        submit = lambda i: grp.submit_frame_dev([dev_frames[i].data_ptr()])  # noqa: E731
+        wait = grp.wait_frame
+
+        def first(i):
+            submit(i)
+            return wait()
+    hb("created")
+    elapsed, lost, poses = pipelined_run(first, submit, wait, total, Wm, barrier, hb)
+    elapsed = max_over_ranks(elapsed)
+    hb("timed")
+    rooms = world if base == "rooms" else (world // 2 if base == "pairs" else 1)
+    gt = poses_gt[total - 1]
+    out.update({"value": round(rooms * K / elapsed, 2), "unit": "frames/s", "ms_per_step": round(1000.0 * elapsed / K, 4), "rooms": rooms,
+                "lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(poses[-1][:3, 3] - gt[:3, 3]) * 1000.0), 3),
+                "final_pose_f32_hex": np.ascontiguousarray(poses[-1][:3, :4], np.float32).tobytes().hex(), "poses_sha1": poses_digest(poses)})
+    if grp is not None:
+        ms, front, cnt = grp.exchange_ms()
+        if cnt:
+            out["stage_us"] = {"slab_work_us": round(1e3 * front / cnt, 1), "exchange_us": round(1e3 * ms / cnt, 1), "frames": int(cnt),
+                               "note": "rank 0's device, HIP events: slab work = ICP (with its all-reduces in the icp_allreduce form) + integrate + "
+                                       "slab-local raycast of a frame; exchange = the two composites, waits for the peers included"}
+    # ---- the check against ONE context on the same frames: every pose of the run, and every stored plane of every slab ----
+    ref_path = os.path.join(args.child_dir, "single_%d.json" % n)
+    if base == "single":
+        vol = trk.download_tsdf()
+        out["plane_crc"] = plane_crcs(vol)
+        del vol
+    elif base in SLAB_FORMS:
+        sl = grp.slab(0)
+        vol = sl.download_tsdf()
+        mine = {"rank": rank, "z0": int(sl.stored_z0), "crc": plane_crcs(vol)}
+        del vol
+        hb("crc")
+        got = [None] * world if rank == 0 else None
+        dist.gather_object(mine, got, dst=0)
+        if rank == 0 and os.path.exists(ref_path):
+            ref = json.load(open(ref_path))
+            planes_ok = all(g["crc"] == ref["plane_crc"][g["z0"]:g["z0"] + len(g["crc"])] for g in got)
+            covered = sum(slab_range(r, world, n)[1] - slab_range(r, world, n)[0] for r in range(world)) == n
+            out["matches_single_gpu"] = bool(planes_ok and covered and out["poses_sha1"] == ref["poses_sha1"] and
+                                             out["final_pose_f32_hex"] == ref["final_pose_f32_hex"])
+            out["matches_detail"] = {"every_pose_of_the_run": out["poses_sha1"] == ref["poses_sha1"],
+                                     "every_stored_plane_of_every_slab_crc32": bool(planes_ok), "planes_compared": int(sum(len(g["crc"]) for g in got))}
+    elif rank == 0 and os.path.exists(ref_path):   # rooms / pairs: rank 0's room runs the same frames as the single context
+        ref = json.load(open(ref_path))
+        out["matches_single_gpu"] = bool(out["poses_sha1"] == ref["poses_sha1"])
+        out["matches_detail"] = {"every_pose_of_room_0": out["matches_single_gpu"]}
+    hb("checked")
+    if grp is not None:
+        grp.close()
+    if trk is not None:
+        trk.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        for path in [tag + ".json"] + ([ref_path] if base == "single" else []):   # (the single context's result is also the later forms' reference)
+            with open(path + ".tmp", "w") as f:
+                json.dump(out, f)
+            os.replace(path + ".tmp", path)
+    hb("done")
+
+
+def visible_gpu_count():
+    """GPUs this process's workers could open, WITHOUT a HIP call (the launcher must stay a process that has never touched the
+    GPU): the kfd topology's nodes with SIMDs, cut down by a *_VISIBLE_DEVICES list.  0 = cannot tell (no kfd here)."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(path):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if n and v is not None and v.strip():
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
+class Launcher:
+    """see the comment block above"""
+    # seconds without a sign of life before the workers of a form are killed: while torch / the library are being paged
+    # in (a fresh box: minutes), afterwards (HSK_BENCH_STALL_S overrides it), and a follower's wait for the director
+    IMPORT_STALL_S, STALL_S, STEP_FILE_S = 420.0, float(os.environ.get("HSK_BENCH_STALL_S", "150")), 1800.0
+
+    def __init__(self, args, argv):
+        self.args, self.world = args, args.gpus
+        self.torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+        if self.torchrun:
+            self.my_ranks = [int(os.environ["RANK"])]
+            # one scratch directory per RUN: the launcher's pid of torch.distributed.run, its port and its run id -- and the
+            # director empties it before it publishes anything, so that nothing a crashed earlier run left under the same
+            # name (step files, rendezvous files, a single-context reference) can be replayed; followers wait for the nonce
+            # (TORCHELASTIC_RESTART_COUNT: a restarted attempt of the same launcher, port and run id gets a directory of its own
+            # -- a follower can never meet the nonce or the step files of the attempt that crashed)
+            self.dir = os.path.join(tempfile.gettempdir(), "hskbench_%d_%s_%s_a%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                                                                                     "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "") if c.isalnum())[:24],
+                                                                                     "".join(c for c in os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") if c.isalnum())[:8]))
+            if int(os.environ["RANK"]) == 0:
+                shutil.rmtree(self.dir, ignore_errors=True)
+                os.makedirs(self.dir, exist_ok=True)
+                with open(os.path.join(self.dir, "nonce.tmp"), "w") as f:
+                    f.write(str(os.getpid()))
+                os.replace(os.path.join(self.dir, "nonce.tmp"), os.path.join(self.dir, "nonce"))
+            else:
+                t_end = time.time() + 600.0
+                while not os.path.exists(os.path.join(self.dir, "nonce")) and time.time() < t_end:
+                    time.sleep(0.05)
+                if not os.path.exists(os.path.join(self.dir, "nonce")):
+                    raise SystemExit("bench.py: rank %s waited 600 s for rank 0's scratch directory %s: giving up" % (os.environ["RANK"], self.dir))
+        else:
+            self.my_ranks = list(range(self.world))
+            self.dir = tempfile.mkdtemp(prefix="hskbench_")
+        self.director = 0 in self.my_ranks
+        self.step_no = 0
+        self.failed = {}
+        self.log_tail = {}
+
+    # ---- one step: the workers of one form at one volume ----
+    def spawn(self, step):
+        a = self.args
+        procs = []
+        for r in step["ranks"]:
+            if r not in self.my_ranks:
+                continue
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(len(step["ranks"])), GLOO_SOCKET_IFNAME=os.environ.get("GLOO_SOCKET_IFNAME", "lo"),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                       HSK_FRAME_TIMEOUT_S=os.environ.get("HSK_FRAME_TIMEOUT_S", "30"))
+            if not self.torchrun or "LOCAL_RANK" not in os.environ:
+                env["LOCAL_RANK"] = str(r)
+            for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "OMP_NUM_THREADS"):
+                env.pop(v, None)
+            # (HSK_BENCH_WORKER: the CPU tests of the launcher put a scripted stand-in for the GPU worker here)
+            cmd = [sys.executable, os.environ.get("HSK_BENCH_WORKER") or os.path.join(ROOT, "bench.py"), "--child", step["form"], "--child-dir", self.dir, "--child-tag", step["tag"],
+                   "--gpus", str(self.world), "--steps", str(step["steps"]), "--warmup", str(step["warmup"]), "--volume", str(step["volume"])]
+            if a.share_gpu:
+                cmd.append("--share-gpu")
+            if a.allow_exp:
+                cmd.append("--allow-exp")
+            log = open(os.path.join(self.dir, "%s.log.%d" % (step["tag"], r)), "w")
+            procs.append((r, subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True), log))
+        return procs
+
+    def kill(self, procs):
+        import signal
+        for _, p, _ in procs:   # exactly the process groups this launcher started
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for _, p, _ in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def watch(self, step, procs):
+        """wait for the workers; (ok, why)"""
+        t_start = time.time()
+        first_bad = None
+        while True:
+            codes = [p.poll() for _, p, _ in procs]
+            if all(c is not None for c in codes):
+                break
+            now = time.time()
+            if any(c not in (None, 0) for c in codes):
+                first_bad = first_bad or now
+                if now - first_bad > 20.0:   # a worker failed: its peers get a moment to notice, then go too
+                    self.kill(procs)
+                    break
+            newest, phases = t_start, []
+            for r, _, _ in procs:
+                hbp = os.path.join(self.dir, "%s.hb.%d" % (step["tag"], r))
+                try:
+                    newest = max(newest, os.path.getmtime(hbp))
+                    phases.append(open(hbp).read() or "start")
+                except OSError:
+                    phases.append("not started")
+            limit = self.IMPORT_STALL_S if any(ph in ("not started", "start") for ph in phases) else self.STALL_S
+            if now - newest > limit:
+                self.kill(procs)
+                for _, _, log in procs:
+                    log.close()
+                return False, "stalled for %.0f s in phase %s: workers killed" % (limit, "/".join(sorted(set(phases))))
+            time.sleep(0.05)
+        for _, _, log in procs:
+            log.close()
+        codes = [p.returncode for _, p, _ in procs]
+        if any(c != 0 for c in codes):
+            tails = []
+            for r, p, _ in procs:
+                if p.returncode != 0:
+                    try:
+                        lines = open(os.path.join(self.dir, "%s.log.%d" % (step["tag"], r))).read().strip().splitlines()
+                    except OSError:
+                        lines = []
+                    tails.append("rank %d rc %s: %s" % (r, p.returncode, " | ".join(lines[-3:])[-400:]))
+            return False, "; ".join(tails)
+        return True, None
+
+    def run_step(self, form, volume, ranks=None, steps=None, warmup=None):
+        """director: publish the step, run my share of it; returns rank 0's result dict or None"""
+        a = self.args
+        step = {"form": form, "volume": volume, "ranks": list(range(self.world)) if ranks is None else ranks,
+                "steps": a.steps if steps is None else steps, "warmup": a.warmup if warmup is None else warmup,
+                "tag": "s%02d_%s_%d" % (self.step_no, form.replace(":", "_"), volume)}
+        self.publish(step)
+        return self.execute(step)
+
+    def publish(self, step):
+        path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
+        with open(path + ".tmp", "w") as f:
+            json.dump(step, f)
+        os.replace(path + ".tmp", path)
+        self.step_no += 1
+
+    def execute(self, step):
+        procs = self.spawn(step)
+        if not procs:
+            return None
+        ok, why = self.watch(step, procs)
+        res_path = os.path.join(self.dir, step["tag"] + ".json")
+        if ok and (0 not in [r for r, _, _ in procs] or os.path.exists(res_path)):
+            return json.load(open(res_path)) if os.path.exists(res_path) else {}
+        self.failed["%s@%d" % (step["form"], step["volume"])] = why or "no result written"
+        return None
+
+    def follow(self):
+        """a launcher that is not the director (torch.distributed.run, rank != 0): run my worker of every published step"""
+        while True:
+            path = os.path.join(self.dir, "step_%03d.json" % self.step_no)
+            t0 = time.time()
+            while not os.path.exists(path):
+                # the director removes the scratch directory when it has printed the line: that, too, says "done" (a
+                # follower whose last worker exits late must not wait for a file that will never come)
+                if not os.path.isdir(self.dir) or time.time() - t0 > self.STEP_FILE_S:
+                    return 0   # the director is done or gone; nothing of this rank's is left running
+                time.sleep(0.05)
+            step = json.load(open(path))
+            self.step_no += 1
+            if step["form"] == "done":
+                return 0
+            self.execute(step)
+
+    # ---- the director's plan and the line ----
+    def direct(self):
+        a, n, G = self.args, self.args.volume, self.world
+        t_begin = time.time()
+        single = self.run_step("single", n, ranks=[0])
+        rooms = self.run_step("rooms", n) if (a.mode in ("slab", "rooms") and not a.no_rooms) or a.mode == "rooms" else None
+        forms = {}
+        if a.mode == "slab":
+            for f in a.forms:
+                forms[f] = self.run_step(f, n)
+        # (a form counts only when it was CHECKED against the single context and matched: without the reference -- the
+        # `single` step failed -- nothing is "good", and the line falls back to the weak-scaling head below)
+        good = {f: r for f, r in forms.items() if r and r.get("matches_single_gpu") is True and not r["lost_frames"]}
+        best = max(good, key=lambda f: good[f]["value"]) if good else None
+        pairs = None
+        if a.mode == "pairs" or (a.mode == "slab" and G >= 4 and G % 2 == 0 and not a.no_rooms):
+            sub = "direct" if (a.mode == "pairs" and "direct" in a.forms) or (forms.get("direct") and "direct" in good) else "rccl"
+            pairs = self.run_step("pairs:" + sub, n)
+            if pairs is None and sub == "direct":
+                pairs = self.run_step("pairs:rccl", n)
+        big = None
+        if a.mode == "slab" and n == 512 and not a.no_1024 and best is not None:
+            K2, W2 = min(a.steps, 40), min(a.warmup, 5)
+            s2 = self.run_step("single", 1024, ranks=[0], steps=K2, warmup=W2)
+            order = [best] + [f for f in sorted(good, key=lambda f: -good[f]["value"]) if f != best]
+            r2 = f2 = None
+            for f in order:
+                r2, f2 = self.run_step(f, 1024, steps=K2, warmup=W2), f
+                if r2 and r2.get("matches_single_gpu") is True:
+                    break
+            big = {"workload": "configs[3]: ONE 1024^3 TSDF as %d z-slabs, the same synthetic stream, %d timed frames" % (G, K2),
+                   "single_gpu_same_frames": None if s2 is None else {k: s2[k] for k in ("value", "unit", "ms_per_step", "lost_frames")},
+                   "form": f2, "slabs": None if r2 is None else {k: r2[k] for k in r2 if k not in ("build_id", "form", "world", "volume")},
+                   "speedup_vs_single_gpu": None if not (r2 and s2) else round(r2["value"] / s2["value"], 3),
+                   "predicted_us": predicted_us(1024, G), "predicted_us_r03": predicted_us(1024, G, STAGE_US_R03)}
+        self.publish({"form": "done"})
+        # ---- the line ----
+        K, Wm = a.steps, a.warmup
+        strip = lambda r: None if r is None else {k: r[k] for k in r if k not in ("build_id", "form", "world", "volume", "steps", "warmup", "plane_crc")}  # noqa: E731
+        head = good[best] if best else None
+        if head is None and a.mode == "pairs" and pairs:
+            head = pairs
+        if head is None and rooms:
+            head = rooms   # no slab form ran to a checked result: the weak-scaling partition is what this node measured
+        if head is None:
+            sys.stderr.write("bench.py: no form of the %d-GPU path completed: %s\n" % (G, json.dumps(self.failed)))
+            self.dump_logs()
+            return None
+        slab_head = best is not None
+        out = {
+            "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
+            "value": head["value"], "unit": "frames/s", "n_gpus": G, "steps": K, "warmup": Wm, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if slab_head else "weak", "vs_baseline": None,
+            "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+            "config": {"workload": ("configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n) if slab_head else
+                                   ("configs[4]: %d concurrent %d^3 rooms, a GPU pair (two z-slabs) each" % (head["rooms"], n) if head is pairs else
+                                    "configs[4]-shaped: one %d^3 room per GPU, no data-path collective" % n),
+                       "volume": n, "image": [W, H], "icp_iters": [10, 5, 4],
+                       "parallelism": ("slab%d-%s" % (G, best)) if slab_head else ("pairs%d" % head["rooms"] if head is pairs else "rooms%d" % G),
+                       "exchange": FORM_TEXT.get(best) if slab_head else None,
+                       "api": "hsk_group_submit_frame_dev / hsk_group_wait_frame (C ABI), 1 frame in flight ahead" if (slab_head or head is pairs)
+                              else "hsk_submit_frame_dev / hsk_wait_frame"},
+            "headline_form": best if slab_head else ("pairs" if head is pairs else "rooms"),
+            "headline_note": ("value = the fastest z-slab form whose every pose and every stored TSDF plane equal a single context's on the same "
+                              "frames (strong scaling of ONE volume); rooms_weak = the same GPUs with one independent room each") if slab_head else
+                             "no z-slab form completed with a checked result on this node (see forms / failed_forms): value is the weak-scaling partition",
+            "matches_single_gpu": head.get("matches_single_gpu"),
+            "ranks_seen": head.get("ranks_seen", G if not slab_head else None),
+            "tracking": {"lost_frames": head["lost_frames"], "final_translation_error_mm": head["final_translation_error_mm"],
+                         "final_pose_f32_hex": head["final_pose_f32_hex"]},
+            "rooms_weak": None if rooms is None else dict(strip(rooms), scaling="weak",
+                                                            workload="one %d^3 room per GPU, hsk_submit_frame_dev / hsk_wait_frame, %d frames each, no data-path collective" % (n, K)),
+            "forms": {f: (dict(strip(r), what=FORM_TEXT[f]) if r else {"failed": self.failed.get("%s@%d" % (f, n), "failed")}) for f, r in forms.items()},
+            "single_gpu_same_frames": None if single is None else {k: single[k] for k in ("value", "unit", "ms_per_step", "lost_frames", "final_pose_f32_hex")},
+            "speedup_vs_single_gpu": None if not (single and slab_head) else round(head["value"] / single["value"], 3),
+            "predicted_us": predicted_us(n, G), "predicted_us_r03": predicted_us(n, G, STAGE_US_R03),
+        }
+        if head.get("stage_us"):
+            out["stage_us"] = head["stage_us"]
+        if pairs is not None:
+            out["pairs_weak"] = dict(strip(pairs), scaling="weak", workload="BASELINE configs[4]: one %d^3 room per GPU pair (two z-slabs, own exchange)" % n)
+        if big is not None:
+            out["slabs_1024"] = big
+        out["launcher"] = {"mode": "torch.distributed.run: every rank process launches its own fresh worker per form" if self.torchrun else
+                                   "bare: this process launched all %d workers of every form" % G,
+                           "failed_forms": self.failed, "wall_s": round(time.time() - t_begin, 1),
+                           "share_gpu_check_only": bool(a.share_gpu)}
+        out["build_id"] = head.get("build_id")
+        # (build_id.py is loaded by path: importing the package would load libhskinfu.so -- and the HIP runtime -- into the launcher)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("hsk_build_id", os.path.join(ROOT, "housescan_amd", "csrc", "build_id.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if out["build_id"] != mod.build_id():
+            out["experimental_build"] = True
+        return out
+
+    def dump_logs(self):
+        for f in sorted(glob.glob(os.path.join(self.dir, "*.log.*"))):
+            try:
+                txt = open(f).read().strip().splitlines()[-6:]
+            except OSError:
+                continue
+            if txt:
+                sys.stderr.write("--- %s\n%s\n" % (os.path.basename(f), "\n".join(txt)))
+
+    def cleanup(self):
+        if self.director:
+            time.sleep(0.2)
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def run_multi_torch(args, hsk, torch, world, rank, local_rank):
+    """The N > 1 slab flow with the collectives issued from Python through torch.distributed (housescan_amd/sharded.py:
+    the harness the group call was checked against).  --backend gloo --share-gpu runs all ranks on device 0: a logic
+    check of the flow on a one-GPU box, its numbers mean nothing."""
+    import torch.distributed as dist
+    from housescan_amd.sharded import ShardedKinfu
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    K, Wm, n = args.steps, args.warmup, args.volume
+    total = 1 + Wm + K
+    poses_gt, frames = make_frames(hsk, 0, total)
+    dev_all = torch.from_numpy(np.stack(frames).view(np.int16)).cuda(local_rank)
+    dev_frames = [dev_all[i] for i in range(total)]
+    torch.cuda.synchronize()
+    eng = ShardedKinfu(n, rank, world, local_rank, mode="slab", icp=args.icp)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    lost = 0
+    for i in range(1 + Wm):
+        eng.process_frame_dev(dev_frames[i])
+    barrier()
+    t0 = time.perf_counter()
+    if args.icp == "replicated":
+        nxt = lambda i: dev_frames[i + 1] if i + 1 < total else None  # noqa: E731
+        eng.submit_frame_dev(dev_frames[1 + Wm], nxt(1 + Wm))
+        for i in range(2 + Wm, total):
+            eng.submit_frame_dev(dev_frames[i], nxt(i))
+            pose, ok = eng.wait_frame()
+            lost += (not ok)
+        pose, ok = eng.wait_frame()
+        lost += (not ok)
+    else:
+        for i in range(1 + Wm, total):
+            pose, ok = eng.process_frame_dev(dev_frames[i], dev_frames[i + 1] if i + 1 < total else None)
+            lost += (not ok)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    gt = poses_gt[total - 1]
+    out = {
+        "metric": "frames/sec fused (640x480 into %d^3 TSDF): integrate+ICP+raycast" % n,
+        "value": round(K / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1000.0 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (int16 fixed-point TSDF storage, f64 ICP sums)", "data": "synthetic",
+        "config": {"workload": "configs[3]-shaped: ONE %d^3 TSDF sharded as z-slabs over the GPUs" % n, "volume": n, "image": [W, H],
+                   "icp_iters": [10, 5, 4], "parallelism": "slab%d-icp-%s" % (world, args.icp),
+                   "api": "housescan_amd/sharded.py over torch.distributed (%s)" % args.backend,
+                   **({"check_only": "all ranks share device 0 over %s" % args.backend} if args.share_gpu else {})},
+        "tracking": {"lost_frames": int(lost), "final_translation_error_mm": round(float(np.linalg.norm(pose[:3, 3] - gt[:3, 3]) * 1000.0), 3),
+                     "final_pose_f32_hex": np.ascontiguousarray(pose[:3, :4], np.float32).tobytes().hex()},
+    }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def launch(args):
+    """bench.py's N > 1 path (bare, or one rank of torch.distributed.run): no GPU call and no torch import in THIS process"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d under a launch of %d ranks" % (args.gpus, world))
+    if args.mode == "pairs" and args.gpus % 2:
+        raise SystemExit("--mode pairs needs an even number of GPUs")
+    seen = visible_gpu_count()
+    if 0 < seen < args.gpus and not args.share_gpu:
+        # (said at once, by the launcher: the workers would each find it out after their imports, a minute and a half later)
+        sys.stderr.write("bench.py: --gpus %d, but this box shows %d GPU%s; --share-gpu runs the ranks on one device (a correctness "
+                         "run of the N > 1 paths, not a measurement)\n" % (args.gpus, seen, "" if seen == 1 else "s"))
+        raise SystemExit(2)
+    L = Launcher(args, sys.argv)
+    if not L.director:
+        return L.follow()
+    try:
+        out = L.direct()
+    finally:
+        L.cleanup()
+    if out is None:
+        raise SystemExit(1)
+    emit(out)
+    return 0

@@ -62,6 +62,7 @@ SYMBOLS = {
     "hsk_download_tsdf": (C.c_int, [_P, _P]),
     "hsk_upload_tsdf": (C.c_int, [_P, _P]),
     "hsk_flush_weights": (C.c_int, [_P]),
+    "hsk_prepare_readout": (C.c_int, [_P, C.c_size_t]),
     "hsk_stored_planes": (C.c_int, [_P, _I, _I]),
     "hsk_get_pose": (C.c_int, [_P, _F]),
     "hsk_set_pose": (C.c_int, [_P, _F]),
@@ -93,6 +94,7 @@ SYMBOLS = {
     "hsk_stage_ms": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
     "hsk_icp_level_ms": (C.c_int, [_P, _D]),
     "hsk_integrate_queue_entries": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "hsk_integrate_light_entries": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hsk_integrate_coarse_counts": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hsk_bilateral_tables": (C.c_int, [_F, _F]),
     "hsk_selftest_exact_ops": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
@@ -116,6 +118,7 @@ SYMBOLS = {
     "hsk_synth_room_extents": (C.c_int, [C.c_int, _F]),
     "hsk_synth_room_pose": (C.c_int, [C.c_int, C.c_int, C.c_int, _F]),
     "hsk_synth_room_render": (C.c_int, [C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "hsk_synth_render_sensor": (C.c_int, [C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_float, C.c_float, C.c_int, _P, _D]),
     "hsk_write_pcd_xyz": (C.c_int, [C.c_char_p, _P, C.c_size_t]),
     "hsk_write_ply_mesh": (C.c_int, [C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hsk_weld_triangles": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t), _P]),

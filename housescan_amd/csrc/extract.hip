@@ -57,10 +57,12 @@ static __device__ __forceinline__ unsigned long long row_brick_mask(const unsign
   for (int bz = bz0; bz <= bz1; ++bz)
     for (int by = by0; by <= by1; ++by) {
       const int bit0 = (bz * byn + by) * bxn;  // the brick row's first bit; its bxn bits span at most three words
-      const int w0 = bit0 >> 5, sh = bit0 & 31;
-      const unsigned long long lo = (unsigned long long)flags[w0] | ((unsigned long long)flags[w0 + 1] << 32);
+      // (the words behind the last brick row's own are clamped into the field -- they are super-brick words today, but
+      // nothing here depends on what follows the brick bits: whatever is read beyond the row's bxn bits is masked off below)
+      const int w0 = bit0 >> 5, sh = bit0 & 31, wlast = hsk_flag_words_total(vp) - 1;
+      const unsigned long long lo = (unsigned long long)flags[w0] | ((unsigned long long)flags[min(w0 + 1, wlast)] << 32);
       unsigned long long bits = lo >> sh;
-      if (sh != 0 && sh + bxn > 64) bits |= (unsigned long long)flags[w0 + 2] << (64 - sh);
+      if (sh != 0 && sh + bxn > 64) bits |= (unsigned long long)flags[min(w0 + 2, wlast)] << (64 - sh);
       m |= bits;
     }
   return bxn == 64 ? m : m & ((1ull << bxn) - 1ull);

@@ -15,6 +15,7 @@ void launch_materialize(hipStream_t s, void* vol, const VolParams& vp, unsigned 
 size_t integrate_queue_words(const VolParams& vp);
 size_t integrate_queue_counter_words();  // the head of the queue buffer that holds the counters ...
 unsigned long long integrate_queue_entries(const unsigned* counter_words);  // ... and their sum, from a host copy of it
+unsigned long long integrate_queue_light_entries(const unsigned* counter_words);  // ... and of the light class (free space over holes)
 size_t integrate_cflag_offset_bytes(const VolParams& vp);  // the coarse level's verdict bytes inside the zint buffer ...
 size_t integrate_chunk_count(const VolParams& vp);         // ... one per wave-chunk
 size_t integrate_zint_entries(const VolParams& vp);  // column z ranges + workgroup z ranges (launch_integrate's zint)

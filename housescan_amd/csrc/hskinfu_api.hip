@@ -14,7 +14,9 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <new>
 #include <string>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -390,6 +392,7 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     CK(hipMalloc((void**)&b.d_raw, P0 * 2));
     CK(hipMalloc((void**)&b.d_scaled, P0 * 4));
     CK(hipMalloc((void**)&b.d_tmax, tile_table_bytes(c->width, c->height)));
+    CK(hipMemset(b.d_tmax, 0, tile_table_bytes(c->width, c->height)));  // (the validity mask's pad words are read, never written: they are zero)
     for (int l = 0; l < HSK_NLEVELS; ++l) {
       const size_t P = (size_t)k->lv[l].W * k->lv[l].H;
       CK(hipMalloc((void**)&b.d_dep[l], P * 2));
@@ -1152,12 +1155,17 @@ static int ensure_pinned(hsk_ctx* k) {
 namespace {
 struct CopyPool {
   std::mutex m;
-  std::condition_variable cv_work, cv_done;
+  std::condition_variable cv_work;
   std::vector<std::thread> workers;
-  struct Job { char* dst; const char* src; size_t len; };
+  // a call's slices carry the call's own latch: a read-out waits for ITS slices only, whoever copies them (read-outs of
+  // different contexts on different threads -- concurrent rooms, a group's slabs -- used to wait on one global count)
+  struct Latch { size_t left = 0; std::condition_variable cv; };
+  struct Job { char* dst; const char* src; size_t len; Latch* latch; };
   std::vector<Job> jobs;
-  size_t pending = 0;
   bool stop = false;
+  void done(Latch* l) {   // (under m)
+    if (--l->left == 0) l->cv.notify_all();
+  }
   void worker() {
     std::unique_lock<std::mutex> lk(m);
     for (;;) {
@@ -1168,7 +1176,7 @@ struct CopyPool {
       lk.unlock();
       memcpy(j.dst, j.src, j.len);
       lk.lock();
-      if (--pending == 0) cv_done.notify_all();
+      done(j.latch);
     }
   }
   void run(void* dst, const void* src, size_t bytes) {
@@ -1177,35 +1185,47 @@ struct CopyPool {
       memcpy(dst, src, bytes);
       return;
     }
-    std::unique_lock<std::mutex> lk(m);   // (one copy at a time per process: the callers are read-outs, not the frame path)
+    Latch latch;
+    std::unique_lock<std::mutex> lk(m);
     if (workers.empty()) {
       unsigned n = std::thread::hardware_concurrency();
       n = n == 0 ? 1 : (n > 8 ? 7 : (n > 1 ? n - 1 : 1));
       for (unsigned i = 0; i < n; ++i) workers.emplace_back([this] { worker(); });
     }
-    cv_done.wait(lk, [&] { return pending == 0; });
     size_t first_len = 0;
     for (size_t off = 0; off < bytes; off += slice) {
       const size_t len = bytes - off < slice ? bytes - off : slice;
       if (off == 0) { first_len = len; continue; }   // the caller copies the first slice itself
-      jobs.push_back(Job{(char*)dst + off, (const char*)src + off, len});
-      ++pending;
+      jobs.push_back(Job{(char*)dst + off, (const char*)src + off, len, &latch});
+      ++latch.left;
     }
     lk.unlock();
     cv_work.notify_all();
     memcpy(dst, src, first_len);
     lk.lock();
-    // (the caller helps with what is left instead of sleeping)
-    while (!jobs.empty()) {
+    // (the caller helps with what is left -- its own slices or another call's -- instead of sleeping)
+    while (latch.left != 0 && !jobs.empty()) {
       Job j = jobs.back();
       jobs.pop_back();
       lk.unlock();
       memcpy(j.dst, j.src, j.len);
       lk.lock();
-      if (--pending == 0) cv_done.notify_all();
+      done(j.latch);
     }
-    cv_done.wait(lk, [&] { return pending == 0; });
+    latch.cv.wait(lk, [&] { return latch.left == 0; });
   }
+  // fork(): the child inherits `workers` without the threads behind it (joining them is undefined behaviour and hung at
+  // exit) and possibly a mutex some other thread held.  The pool is quiesced round the fork and the child starts empty.
+  void fork_prepare() { m.lock(); }
+  void fork_parent() { m.unlock(); }
+  void fork_child() {
+    new (&m) std::mutex();
+    new (&cv_work) std::condition_variable();
+    new (&workers) std::vector<std::thread>();   // (the old vector's thread objects are abandoned, never destroyed)
+    new (&jobs) std::vector<Job>();
+    stop = false;
+  }
+  CopyPool();
   ~CopyPool() {
     {
       std::lock_guard<std::mutex> lk(m);
@@ -1216,6 +1236,9 @@ struct CopyPool {
   }
 };
 CopyPool g_copy_pool;
+CopyPool::CopyPool() {
+  pthread_atfork([] { g_copy_pool.fork_prepare(); }, [] { g_copy_pool.fork_parent(); }, [] { g_copy_pool.fork_child(); });
+}
 }  // namespace
 static void parallel_memcpy(void* dst, const void* src, size_t bytes) { g_copy_pool.run(dst, src, bytes); }
 // `bytes` of device memory at src into the caller's dst, in pieces through the pinned pair: the DMA of piece i + 1 runs
@@ -1364,6 +1387,31 @@ extern "C" int hsk_download_scaled_depth(hsk_ctx* k, float* out) {
   return HSK_OK;
 }
 
+static int ensure_cube_table(hsk_ctx* k) {
+  if (k->d_cube_tab) return HSK_OK;
+  CubeTable ct;
+  if (hsk_build_cube_table(&ct) != HSK_MC_MAXT) return fail(k, HSK_ERR_STATE, "marching-cubes table: a case with more triangles than the table holds");
+  HIPCHK(k, hipMalloc((void**)&k->d_cube_tab, sizeof(CubeTable)));
+  HIPCHK(k, hipMemcpy(k->d_cube_tab, &ct, sizeof(CubeTable), hipMemcpyHostToDevice));
+  return HSK_OK;
+}
+static int ensure_row_tables(hsk_ctx* k) {
+  if (k->d_rowcnt) return HSK_OK;
+  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // (>= the mesh rows: one pair of buffers for every product)
+  HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
+  HIPCHK(k, hipMalloc((void**)&k->d_rowoff, hsk_scan_scratch_entries(nrows) * 8));
+  return HSK_OK;
+}
+static int ensure_product_bytes(hsk_ctx* k, size_t want) {
+  if (k->out_bytes >= want) return HSK_OK;
+  if (k->d_out) (void)hipFree(k->d_out);
+  k->d_out = nullptr;
+  k->out_bytes = 0;
+  HIPCHK(k, hipMalloc(&k->d_out, want));
+  k->out_bytes = want;
+  return HSK_OK;
+}
+
 // A product of the volume (cloud, mesh): counted row by row, the rows' offsets scanned, then written in voxel order.  The
 // callers' protocol is a size query (null buffer) followed by the fill: the second call finds the counts and offsets of
 // the first in place when nothing has touched the volume in between (ro_kind / ro_epoch) -- the count sweep ran twice
@@ -1371,10 +1419,9 @@ extern "C" int hsk_download_scaled_depth(hsk_ctx* k, float* out) {
 // the pinned pair (copy_out).
 template <class Count, class Fill>
 static int extract_product(hsk_ctx* k, int kind, size_t elem_bytes, float* out, size_t cap, size_t* n_out, Count count, Fill fill) {
-  const int nrows = k->vp.Y * (k->vp.zo1 - k->vp.zo0);  // (>= the mesh rows: one pair of buffers for every product)
-  if (!k->d_rowcnt) {
-    HIPCHK(k, hipMalloc((void**)&k->d_rowcnt, (size_t)nrows * 4));
-    HIPCHK(k, hipMalloc((void**)&k->d_rowoff, hsk_scan_scratch_entries(nrows) * 8));
+  {
+    const int r = ensure_row_tables(k);
+    if (r != HSK_OK) return r;
   }
   // (NO flush of the deferred weights here, round 5: the products ask of a weight only whether it is zero, and a weight the
   // summaries hold ahead of the volume's copy is never that -- a block leaves "never observed" with a store of (+1, 1),
@@ -1395,15 +1442,21 @@ static int extract_product(hsk_ctx* k, int kind, size_t elem_bytes, float* out, 
   if (!out || cap == 0 || k->ro_total == 0) return HSK_OK;
   const size_t nw = k->ro_total < cap ? (size_t)k->ro_total : cap;
   if (k->out_bytes < nw * elem_bytes) {
-    if (k->d_out) (void)hipFree(k->d_out);
-    k->d_out = nullptr;
-    k->out_bytes = 0;
-    const size_t want = nw * elem_bytes + (nw * elem_bytes >> 2);  // (a quarter more: a scan grows from call to call)
-    HIPCHK(k, hipMalloc(&k->d_out, want));
-    k->out_bytes = want;
+    const int r = ensure_product_bytes(k, nw * elem_bytes + (nw * elem_bytes >> 2));  // (a quarter more: a scan grows from call to call)
+    if (r != HSK_OK) return r;
   }
   fill((float*)k->d_out, nw);
   return copy_out(k, out, k->d_out, nw * elem_bytes);
+}
+
+extern "C" int hsk_prepare_readout(hsk_ctx* k, size_t product_bytes) {
+  if (!k) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  int r = ensure_pinned(k);
+  if (r == HSK_OK) r = ensure_row_tables(k);
+  if (r == HSK_OK) r = ensure_cube_table(k);
+  if (r == HSK_OK) r = ensure_product_bytes(k, product_bytes ? product_bytes : (size_t)48 << 20);
+  return r;
 }
 
 extern "C" int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_points) {
@@ -1432,11 +1485,9 @@ extern "C" int hsk_extract_mesh(hsk_ctx* k, float* tri_xyz, size_t cap_triangles
 extern "C" int hsk_extract_mesh_cubes(hsk_ctx* k, float* tri_xyz, size_t cap_triangles, size_t* n_triangles) {
   if (!k || !n_triangles) return HSK_ERR_ARG;
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  if (!k->d_cube_tab) {
-    CubeTable ct;
-    if (hsk_build_cube_table(&ct) != HSK_MC_MAXT) return fail(k, HSK_ERR_STATE, "marching-cubes table: a case with more triangles than the table holds");
-    HIPCHK(k, hipMalloc((void**)&k->d_cube_tab, sizeof(CubeTable)));
-    HIPCHK(k, hipMemcpy(k->d_cube_tab, &ct, sizeof(CubeTable), hipMemcpyHostToDevice));
+  {
+    const int r = ensure_cube_table(k);
+    if (r != HSK_OK) return r;
   }
   return extract_product(
       k, 3, 36, tri_xyz, cap_triangles, n_triangles,
@@ -1475,6 +1526,22 @@ extern "C" int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries) {
   hipError_t e = hipMemcpyAsync(h, k->d_queue, words * 4, hipMemcpyDeviceToHost, k->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
   const uint64_t n = e == hipSuccess ? integrate_queue_entries(h) : 0;
+  free(h);
+  HIPCHK(k, e);
+  *n_entries = n;
+  return HSK_OK;
+}
+// ... and of those, the lane-blocks of the LIGHT class (free space with holes in the depth image under it: hsk_integrate_queue_entries
+// counts the per-voxel class only)
+extern "C" int hsk_integrate_light_entries(hsk_ctx* k, uint64_t* n_entries) {
+  if (!k || !n_entries) return HSK_ERR_ARG;
+  HIPCHK(k, hipSetDevice(k->cfg.device_id));
+  const size_t words = integrate_queue_counter_words();
+  unsigned* h = (unsigned*)malloc(words * 4);
+  if (!h) return fail(k, HSK_ERR_STATE, "out of host memory");
+  hipError_t e = hipMemcpyAsync(h, k->d_queue, words * 4, hipMemcpyDeviceToHost, k->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(k->stream);
+  const uint64_t n = e == hipSuccess ? integrate_queue_light_entries(h) : 0;
   free(h);
   HIPCHK(k, e);
   *n_entries = n;

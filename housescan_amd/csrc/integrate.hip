@@ -219,7 +219,7 @@ __global__ void k_column_zrange(IcpFinal fin, const float* __restrict__ tmax, co
   // extra blocks: at 512^3 the column work alone is exactly one block per CU).
   {
     if (blockIdx.x == 0)
-      for (int q = threadIdx.x; q < HSK_NQUEUES; q += blockDim.x) qcount[q * HSK_QCOUNT_STRIDE] = 0u;
+      for (int q = threadIdx.x; q < HSK_NQUEUES; q += blockDim.x) *(unsigned long long*)&qcount[q * HSK_QCOUNT_STRIDE] = 0ull;  // (heavy count, light count)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < tw * th && (int)blockIdx.x < dil_blocks) {
       const int ty = i / tw, tx = i - ty * tw;
@@ -785,6 +785,117 @@ static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0,
   return cnt;
 }
 
+// (round 6) One LIGHT lane-block (pass A: "the light class") -- all four planes inside the lane's range, every pixel of its box
+// inside the image and in front of the camera, and every pixel WITH depth a truncation distance or more behind the block: a voxel
+// is rewritten with F = 1 when its pixel has depth and left alone when it has none.  What is needed per voxel is the
+// specification's pixel (the same expressions as detail_entry's, so the same bits) and whether the scaled depth there is 0.
+// Afterwards the block is classified again: when all 16 voxels hold +1 with a weight, its summary byte says so (pass A had
+// cleared it), and the next free-space observation of the block moves that byte instead of the volume.
+// `have`: the lane holds an entry.  Returns the voxels rewritten.
+template <bool COUNT_ONLY>
+static __device__ __forceinline__ unsigned light_entry(bool have, int x0, int y, int zb, uint4* __restrict__ vol,
+                                                       const float* __restrict__ scaled, const DetailPose& P, const VolParams& vp,
+                                                       int W, int H, const Intr& in, unsigned char* __restrict__ uni) {
+  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
+  uint4 q[4];
+  if (!COUNT_ONLY) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      q[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (have) q[u] = vol[VIDX(zb, u)];
+    }
+  }
+  float ax[4], ay[4], az[4];
+  const float gy = ((float)y + 0.5f) * vp.cell[1] - P.ty;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - P.tx;
+    ax[j] = P.i00 * gx + P.i01 * gy;
+    ay[j] = P.i10 * gx + P.i11 * gy;
+    az[j] = P.i20 * gx + P.i21 * gy;
+  }
+  const int last = W * H - 1;
+  float D[4][4];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    int pix[2][4];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int u = 2 * half + v;
+      const float gz = ((float)(vp.zs0 + zb + u) + 0.5f) * vp.cell[2] - P.tz;
+      const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float camz = az[j] + bz;
+        const float inv_z = hsk_rcp_exact(camz);
+        const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
+        const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
+        const int uu = (int)rintf(fu), vv = (int)rintf(fv);
+        pix[v][j] = min(max(vv * W + uu, 0), last);  // (inside the image by the class; the clamp only guards the address)
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) D[2 * half + v][j] = scaled[pix[v][j]];
+    if (half == 0) asm volatile("" ::: "memory");  // (the first planes' gathers travel under the last planes' projections)
+  }
+  unsigned cnt = 0;
+  if (COUNT_ONLY) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cnt += (have && D[u][j] != 0.0f) ? 1u : 0u;
+    return cnt;
+  }
+  bool gen_any = false;
+  unsigned nw[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool upd = have && D[u][j] != 0.0f;
+      const bool unseen = (w4[j] >> 16) == 0u;
+      const bool simple = unseen || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
+      const unsigned ws = unseen ? (0x10000u | (unsigned)HSK_DIVISOR) : min(w4[j] + 0x10000u, cap);
+      nw[u][j] = (upd && simple) ? ws : w4[j];
+      gen_any = gen_any || (upd && !simple);
+    }
+  }
+  if (__ballot(gen_any) != 0ull) {  // a voxel that was inside the band in an earlier frame: the running mean with F = 1 (update_vector_free4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool upd = have && D[u][j] != 0.0f;
+        const unsigned wp = w4[j] >> 16;
+        const bool simple = wp == 0u || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
+        const int tp = (int)(short)(w4[j] & 0xffffu);
+        const float Wp = (float)wp;
+        const float Fn = hsk_div_small_exact(hsk_tsdf_unpack(tp) * Wp + 1.0f, Wp + 1.0f);
+        int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
+        fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
+        const unsigned wg = ((unsigned)fixed & 0xffffu) | (min(wp + 1u, (unsigned)HSK_MAX_WEIGHT) << 16);
+        nw[u][j] = (upd && !simple) ? wg : nw[u][j];
+      }
+    }
+  }
+  // (F = 1 cannot turn a non-negative value negative: no brick flag can newly be due)
+  uint4 r[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    r[u] = make_uint4(nw[u][0], nw[u][1], nw[u][2], nw[u][3]);
+    if (have && (r[u].x != q[u].x || r[u].y != q[u].y || r[u].z != q[u].z || r[u].w != q[u].w)) vol[VIDX(zb, u)] = r[u];
+  }
+  if (uni != nullptr && have) {
+    const unsigned code = hsk_sum_classify(r);
+    if (code != 0u) uni[hsk_sum_index(vp, x0, y, zb)] = (unsigned char)code;
+  }
+  return 0u;
+}
+
 #ifdef HSK_PA_TIMING
 // timing build (tools/pa_timing.sh): per working wave of pass A (slot = its wave-chunk), s_memrealtime stamps (100 MHz) at
 // the phase boundaries; slot 7 = free | uncertain << 32 lane-blocks of the chunk
@@ -916,13 +1027,13 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     // byte, whether the wave's z range reaches the group or not)
     const int zb0 = zbeg;
     int zbs[NS];
-    bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS];
+    bool actv[NS], in_all_s[NS], free44_s[NS], other_s[NS], light_s[NS];
     float dc_s[NS];
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       zbs[sidx] = zb0 + 4 * sidx;
       actv[sidx] = (zbs[sidx] + 3 >= wl) & (zbs[sidx] <= wh);  // wave-uniform
-      free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = false;
+      free44_s[sidx] = other_s[sidx] = in_all_s[sidx] = light_s[sidx] = false;
       dc_s[sidx] = 0.0f;
     }
     // ---- stage 1 (round 5: the levels changed places).  With the coarse level above it, pass A only meets chunks that hold
@@ -1024,7 +1135,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     bool need1 = false;
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
-      const bool dead2 = ok2_s[sidx] & (dlo_s[sidx] * 0.99999f - t9_s[sidx].x > k.cull_thr2);
+      bool dead2 = ok2_s[sidx] & (dlo_s[sidx] * 0.99999f - t9_s[sidx].x > k.cull_thr2);
       // free space: every pixel of the box WITH depth lies far enough behind the block (.y: the minimum over those,
       // negated when a pixel under the tiles has none) -- and every pixel of the box has depth: by the tiles when they say
       // so, else by the validity mask over the box itself.  A depth image with holes (a real sensor's: 2 % of the pixels
@@ -1033,25 +1144,38 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       bool whole = t9_s[sidx].y > 0.0f;
       const bool ask = free2v & !whole & (box_s[sidx] != 0u);
       if (__ballot(ask) != 0ull) {
-        unsigned bad = 1u;
+        unsigned bad = 1u, allbad = 0u;
         if (ask) {
           const unsigned bx = box_s[sidx];
           const int iu0 = (int)(bx & 2047u), iv0 = (int)((bx >> 11) & 2047u), wd = (int)((bx >> 22) & 31u), ht = (int)((bx >> 27) & 3u);
           const unsigned* __restrict__ row = vmask + (size_t)iv0 * mpitch + (iu0 >> 5);
-          const unsigned long long sel = ((wd == 31 ? 0ull : (1ull << (wd + 1))) - 1ull) << (iu0 & 31);
-          unsigned long long any = 0ull;
+          const unsigned long long sel = ((1ull << (wd + 1)) - 1ull) << (iu0 & 31);  // (wd + 1 <= 32 columns from bit iu0 & 31: never beyond the row's two words)
+          unsigned long long any = 0ull, all = ~0ull;
 #pragma unroll
           for (int h = 0; h < 4; ++h) {
             const unsigned* __restrict__ rp = row + (size_t)min(h, ht) * mpitch;
-            any |= ((unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32)) & sel;
+            const unsigned long long w2 = (unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32);
+            any |= w2 & sel;
+            all &= w2 | ~sel;
           }
           bad = any != 0ull ? 1u : 0u;
+          allbad = all == ~0ull ? 1u : 0u;
         }
         whole = whole | (ask & (bad == 0u));
+        // (round 6) every pixel of the box is a hole -- the inside of a shadow, of an absorbing surface's silhouette: no voxel
+        // of the block has a pixel with depth, the rule writes nothing
+        dead2 = dead2 | (ask & (allbad != 0u));
       }
       const bool free2 = free2v & whole;
       free44_s[sidx] = free2;
-      other_s[sidx] = in_any_s[sidx] & !dead2 & !free2;
+      // (round 6) THE LIGHT CLASS: every pixel of the box that HAS depth lies a truncation distance or more behind the block
+      // (free2v), but the box holds holes.  Each voxel is then either rewritten with F = 1 (its pixel has depth) or left alone
+      // (it has none): pass B needs its pixel and one bit -- no distance, no square root, no division -- where the per-voxel
+      // path spends ~60 vector instructions a voxel.  A depth image with holes (SURVEY.md 8(d)'s noise run: every third
+      // lane-block's box holds one) sent all of these through that path.
+      const bool light2 = free2v & !whole & !dead2;
+      light_s[sidx] = light2;
+      other_s[sidx] = in_any_s[sidx] & !dead2 & !free2 & !light2;
       need1 = need1 | (in_any_s[sidx] & !ok2_s[sidx]);
     }
     // the lane's summaries with the chunk's pending observations pushed into them (kpend > 0 only over quiet bytes); a rim
@@ -1113,14 +1237,20 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     // runs under the volume's -- one dependent round trip less in a wave's life)
     const unsigned qi = (lin + (lin / HSK_NQUEUES) * 37u + wq * (HSK_NQUEUES / 4)) % HSK_NQUEUES;
     // (ONE ticket for the wave's groups: every vector-memory instruction counts, see the note on k_tile_tables)
-    unsigned long long bo[NS];
-    unsigned n_other = 0u, base_all = 0u;
+    // (round 6: a queue is filled from both ends -- the per-voxel entries from its head, the light ones from its tail; the
+    // two counts are the halves of ONE 64-bit counter, so a wave still draws one ticket)
+    unsigned long long bo[NS], bl[NS];
+    unsigned n_other = 0u, n_light = 0u;
+    unsigned long long base_all = 0ull;
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
       bo[sidx] = actv[sidx] ? __ballot(other_s[sidx]) : 0ull;
+      bl[sidx] = actv[sidx] ? __ballot(light_s[sidx]) : 0ull;
       n_other += (unsigned)__popcll(bo[sidx]);
+      n_light += (unsigned)__popcll(bl[sidx]);
     }
-    if (n_other != 0u && lane == 0) base_all = atomicAdd(&qcount[qi * HSK_QCOUNT_STRIDE], n_other);
+    if ((n_other | n_light) != 0u && lane == 0)
+      base_all = atomicAdd((unsigned long long*)&qcount[qi * HSK_QCOUNT_STRIDE], (unsigned long long)n_other | ((unsigned long long)n_light << 32));
     // ---- stage 3: deep free space -- four batched vector updates per group, the loads of both groups in flight together
     if (COUNT_ONLY) {
 #pragma unroll
@@ -1144,7 +1274,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       bool rd[NS];
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) {
-        const bool fr = actv[sidx] & free44_s[sidx], ot = actv[sidx] & other_s[sidx];
+        const bool fr = actv[sidx] & free44_s[sidx], ot = actv[sidx] & (other_s[sidx] | light_s[sidx]);
         const unsigned sm = sum8[sidx];
         const int sbit = 8 * sidx;  // where the group's summary sits in new16
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
@@ -1197,7 +1327,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
               store_vec(VIDX(zbs[sidx], u), q4[u]);
             }
           }
-          if (!(actv[sidx] && other_s[sidx])) {  // (a block on its way to pass B has lost its summary above)
+          if (!(actv[sidx] && (other_s[sidx] | light_s[sidx]))) {  // (a block on its way to pass B has lost its summary above)
             const int sbit = 8 * sidx;
             new16 = (new16 & ~(0xffu << sbit)) | (hsk_sum_classify(q4) << sbit);
           }
@@ -1226,19 +1356,26 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp below sees the loads back and the stores acknowledged
 #endif
     PA_STAMP(4);
-    unsigned b0 = n_other != 0u ? (unsigned)__builtin_amdgcn_readfirstlane((int)base_all) : 0u;
+    unsigned b0 = 0u, l0 = 0u;
+    if ((n_other | n_light) != 0u) {
+      b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base_all);
+      l0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base_all >> 32));
+    }
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
-      if (bo[sidx] == 0ull) continue;
+      if ((bo[sidx] | bl[sidx]) == 0ull) continue;
+      const unsigned id = (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
       if (other_s[sidx]) {
         // the entry: lane-block id, and (when it fits: id_mask_shift != 0) which of its 4 planes lie in the lane's z range
         unsigned pm = 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) pm |= ((zbs[sidx] + u >= zl && zbs[sidx] + u <= zh) ? 1u : 0u) << u;
-        const unsigned id = (unsigned)(((zbs[sidx] >> 2) * vp.Y + y) * qx + (x0 >> 2));
         queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] = id | (pm << 28);
       }
+      // (a light block lies with all four planes in the lane's range -- in_all is part of its class: the id alone, from the tail)
+      if (light_s[sidx]) queue[(size_t)qi * qcap + (qcap - 1u) - (l0 + (unsigned)__popcll(bl[sidx] & ((1ull << lane) - 1ull)))] = id;
       b0 += (unsigned)__popcll(bo[sidx]);
+      l0 += (unsigned)__popcll(bl[sidx]);
     }
   }
   PA_STAMP(5);
@@ -1294,7 +1431,7 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
                                                                         const float* __restrict__ scaled, Intr in, VolParams vp,
                                                                         unsigned long long* __restrict__ counter,
                                                                         unsigned* __restrict__ flags, unsigned long long qmag_x,
-                                                                        unsigned long long qmag_y) {
+                                                                        unsigned long long qmag_y, unsigned char* __restrict__ uni) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
 #ifdef HSK_PB_TIMING
@@ -1307,26 +1444,37 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
   // The HSK_NQUEUES queues are walked as ONE list (their lengths differ by 1.6x: a grid that strides over each queue
   // by itself ends with the longest queue's last round, a third of the chip idle).  Every block scans the 256 counters
   // once (LDS prefix array); an entry's queue is then found by bisection.
-  __shared__ unsigned pre[HSK_NQUEUES + 1];
+  // (round 6: two lists -- the per-voxel entries at the heads of the queues, the light ones at their tails; counter words 0 / 1)
+  __shared__ unsigned pre[HSK_NQUEUES + 1], pre2[HSK_NQUEUES + 1];
   {
     static_assert(HSK_NQUEUES == 256, "one counter per thread of the block");
-    const unsigned c = qcount[threadIdx.x * HSK_QCOUNT_STRIDE];
-    unsigned incl = c;  // inclusive scan inside the wave, then across the four waves
+    const uint2 c = *(const uint2*)&qcount[threadIdx.x * HSK_QCOUNT_STRIDE];
+    unsigned incl = c.x, incl2 = c.y;  // inclusive scans inside the wave, then across the four waves
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const unsigned v = (unsigned)__shfl_up((int)incl, o, 64);
-      if (lane >= o) incl += v;
+      const unsigned v = (unsigned)__shfl_up((int)incl, o, 64), v2 = (unsigned)__shfl_up((int)incl2, o, 64);
+      if (lane >= o) {
+        incl += v;
+        incl2 += v2;
+      }
     }
-    __shared__ unsigned wsum[4];
-    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __shared__ unsigned wsum[4], wsum2[4];
+    if (lane == 63) {
+      wsum[threadIdx.x >> 6] = incl;
+      wsum2[threadIdx.x >> 6] = incl2;
+    }
     __syncthreads();
-    unsigned base = 0;
-    for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
+    unsigned base = 0, base2 = 0;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) {
+      base += wsum[w];
+      base2 += wsum2[w];
+    }
     pre[threadIdx.x + 1] = base + incl;
-    if (threadIdx.x == 0) pre[0] = 0u;
+    pre2[threadIdx.x + 1] = base2 + incl2;
+    if (threadIdx.x == 0) pre[0] = pre2[0] = 0u;
     __syncthreads();
   }
-  const unsigned n = pre[HSK_NQUEUES];
+  const unsigned n = pre[HSK_NQUEUES], n2 = pre2[HSK_NQUEUES];
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned long long cnt = 0;
   PB_STAMP(1);
@@ -1361,6 +1509,32 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
     if (pb_trip < 5) PB_STAMP(2 + pb_trip);
     ++pb_trip;
 #endif
+  }
+  // ---- the light list (round 6): the waves start on it where the per-voxel list left them; an entry is a lane-block id
+  if (n2 != 0u) {
+    auto light_at = [&](unsigned g) -> unsigned {
+      if (g >= n2) return 0xffffffffu;
+      unsigned lo = 0, hi = HSK_NQUEUES;  // pre2[lo] <= g < pre2[hi]
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (pre2[mid] <= g) lo = mid; else hi = mid;
+      }
+      return queue_all[(size_t)lo * qcap + (qcap - 1u) - (g - pre2[lo])];
+    };
+    // (the waves that came last out of the list above go first into this one: the grid is walked from its other end)
+    unsigned g0 = (gridDim.x - 1u - blockIdx.x) * blockDim.x + (threadIdx.x & ~63u);
+    unsigned lid_next = light_at(g0 + lane);
+    for (; g0 < n2; g0 += stride) {
+      const unsigned lid = lid_next;
+      lid_next = light_at(g0 + stride + lane);
+      const bool have = lid != 0xffffffffu;
+      const unsigned lb = have ? lid : 0u;
+      const unsigned row = (unsigned)(((unsigned long long)lb * qmag_x) >> 40);
+      const unsigned zq = (unsigned)(((unsigned long long)row * qmag_y) >> 40);
+      const int x0 = (int)(lb - row * (unsigned)qx) * 4, y = (int)(row - zq * (unsigned)vp.Y);
+      cnt += light_entry<COUNT_ONLY>(have, x0, y, (int)zq * 4, vol, scaled, P, vp, W, H, in, uni);
+    }
   }
   if (COUNT_ONLY) {
 #pragma unroll
@@ -1410,6 +1584,11 @@ size_t integrate_queue_counter_words() { return (size_t)HSK_NQUEUES * HSK_QCOUNT
 unsigned long long integrate_queue_entries(const unsigned* counter_words) {
   unsigned long long n = 0;
   for (size_t q = 0; q < HSK_NQUEUES; ++q) n += counter_words[q * HSK_QCOUNT_STRIDE];
+  return n;
+}
+unsigned long long integrate_queue_light_entries(const unsigned* counter_words) {  // (round 6: the light class, counted in word 1)
+  unsigned long long n = 0;
+  for (size_t q = 0; q < HSK_NQUEUES; ++q) n += counter_words[q * HSK_QCOUNT_STRIDE + 1];
   return n;
 }
 // words of the pass A -> pass B queues: HSK_NQUEUES counters (one 256-B line each) + HSK_NQUEUES queues
@@ -1470,7 +1649,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
       hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
                          W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
-                       counter, flags, qmag_x, qmag_y);
+                       counter, flags, qmag_x, qmag_y, (unsigned char*)nullptr);
   } else {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<false, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
@@ -1479,7 +1658,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
       hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
                          (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
     hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
-                       counter, flags, qmag_x, qmag_y);
+                       counter, flags, qmag_x, qmag_y, uni);
   }
 }
 

@@ -307,3 +307,226 @@ extern "C" int hsk_synth_room_render(int variant, const float pose[16], int w, i
     }
   return HSK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Holes as a sensor makes them.  A takeDepthSnapshot frame (housescan/HoniHelper.hs:20-36) of a
+// structured-light camera has 10-30 % invalid pixels in CONTIGUOUS regions, not SURVEY.md 8(d)'s independent 2 %:
+//   * grazing rays: no return where the ray meets the surface at |n . d| < 0.15 (81 deg from the normal);
+//   * shadows: the projector sits 75 mm beside the camera, so behind every depth discontinuity along x the far surface
+//     is unlit over a band of  b f (1 / z_near - 1 / z_far)  pixels -- kept within 3..5 px; 3 px under horizontal edges;
+//   * the range cut: nothing beyond range_cut_m (<= 0: 3.5 m);
+//   * absorbing != 0: dark furniture returns nothing (the block of the open scene; the chest and the wardrobe of a room);
+//   * and 8(d)'s noise, sigma_mm x (z / 1 m)^2, on what is left -- a counter-based generator keyed by (seed, pixel): the
+//     frame is a pure function of its arguments.
+// scene < 0: the open scene of 8(d) (hsk_synth_render); 0..3: closed room `scene` (hsk_synth_room_render).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Hit {
+  double s;
+  double n[3];
+  int object;   // 0 = a wall of the room, 1 + k = piece of furniture k, 100 = the sphere
+};
+inline void set_axis_normal(Hit& h, int ax) {
+  h.n[0] = h.n[1] = h.n[2] = 0.0;
+  h.n[ax] = 1.0;
+}
+// the entry face of a box (slab method) with its axis
+double trace_box_axis(const double lo[3], const double hi[3], const double o[3], const double d[3], int* axis) {
+  double t0 = 0.0, t1 = std::numeric_limits<double>::infinity();
+  int a0 = 0;
+  for (int ax = 0; ax < 3; ++ax) {
+    if (d[ax] == 0.0) {
+      if (o[ax] < lo[ax] || o[ax] > hi[ax]) return std::numeric_limits<double>::infinity();
+      continue;
+    }
+    double a = (lo[ax] - o[ax]) / d[ax], c = (hi[ax] - o[ax]) / d[ax];
+    if (a > c) {
+      const double t = a;
+      a = c;
+      c = t;
+    }
+    if (a > t0) {
+      t0 = a;
+      a0 = ax;
+    }
+    if (c < t1) t1 = c;
+    if (t0 > t1) return std::numeric_limits<double>::infinity();
+  }
+  *axis = a0;
+  return t0 > 1e-9 ? t0 : std::numeric_limits<double>::infinity();
+}
+bool trace_sphere(const double c[3], double r, const double o[3], const double d[3], Hit& best) {
+  const double oc[3] = {o[0] - c[0], o[1] - c[1], o[2] - c[2]};
+  const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const double b = 2.0 * (oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2]);
+  const double cc = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - r * r;
+  const double disc = b * b - 4.0 * a * cc;
+  if (disc < 0.0) return false;
+  const double t = (-b - std::sqrt(disc)) / (2.0 * a);
+  if (!(t > 1e-9 && t < best.s)) return false;
+  best.s = t;
+  best.object = 100;
+  for (int i = 0; i < 3; ++i) best.n[i] = (o[i] + t * d[i] - c[i]) / r;
+  return true;
+}
+// the same surfaces as trace() / trace_room(), with the normal at the hit (the depths agree with those renders bit for bit:
+// the same expressions decide the nearest hit)
+Hit trace_open_n(const double o[3], const double d[3]) {
+  Hit best;
+  best.object = 0;
+  best.s = std::numeric_limits<double>::infinity();
+  set_axis_normal(best, 2);
+  const double planes[5][2] = {{0, WX0}, {0, WX1}, {1, WY0}, {1, WY1}, {2, WZ1}};
+  for (int i = 0; i < 5; ++i) {
+    const int ax = (int)planes[i][0];
+    const double c = planes[i][1];
+    if (d[ax] == 0.0) continue;
+    const double s = (c - o[ax]) / d[ax];
+    if (!(s > 1e-9) || s >= best.s) continue;
+    const bool low = (i == 0 || i == 2);
+    if (low ? !(d[ax] < 0.0) : !(d[ax] > 0.0)) continue;
+    const double p[3] = {o[0] + s * d[0], o[1] + s * d[1], o[2] + s * d[2]};
+    if (in_room(p, ax)) {
+      best.s = s;
+      set_axis_normal(best, ax);
+    }
+  }
+  trace_sphere(SC, SR, o, d, best);
+  int ax = 0;
+  const double t = trace_box_axis(B0, B1, o, d, &ax);
+  if (t < best.s) {
+    best.s = t;
+    best.object = 1;
+    set_axis_normal(best, ax);
+  }
+  return best;
+}
+Hit trace_room_n(const RoomScene& sc, const double o[3], const double d[3]) {
+  Hit best;
+  best.object = 0;
+  best.s = std::numeric_limits<double>::infinity();
+  set_axis_normal(best, 2);
+  {
+    double t1 = std::numeric_limits<double>::infinity();
+    int a1 = 0;
+    bool inside = true;
+    for (int ax = 0; ax < 3; ++ax) {
+      if (o[ax] < sc.room.lo[ax] || o[ax] > sc.room.hi[ax]) inside = false;
+      if (d[ax] == 0.0) continue;
+      const double c = ((d[ax] > 0.0 ? sc.room.hi[ax] : sc.room.lo[ax]) - o[ax]) / d[ax];
+      if (c < t1) {
+        t1 = c;
+        a1 = ax;
+      }
+    }
+    if (inside && t1 > 1e-9) {
+      best.s = t1;
+      set_axis_normal(best, a1);
+    }
+  }
+  int piece = 0;
+  for (const Box& b : sc.blocks) {
+    int ax = 0;
+    const double t = trace_box_axis(b.lo, b.hi, o, d, &ax);
+    ++piece;
+    if (t < best.s) {
+      best.s = t;
+      best.object = piece;
+      set_axis_normal(best, ax);
+    }
+  }
+  trace_sphere(sc.sphere_c, sc.sphere_r, o, d, best);
+  return best;
+}
+inline uint64_t mix64(uint64_t x) {  // splitmix64's finaliser
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+inline double gauss(uint64_t seed, uint64_t index) {  // Box-Muller on two counter-based uniforms
+  const uint64_t a = mix64(seed ^ mix64(2 * index)), b = mix64(seed ^ mix64(2 * index + 1));
+  const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1)
+  const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);            // [0, 1)
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * kPi * u2);
+}
+}  // namespace
+
+extern "C" int hsk_synth_render_sensor(int scene, const float pose[16], int w, int h, float fx, float fy, float cx, float cy,
+                                       uint64_t seed, float sigma_mm, float range_cut_m, int absorbing, uint16_t* depth,
+                                       double* hole_fraction) {
+  if (!pose || !depth || w <= 0 || h <= 0) return HSK_ERR_ARG;
+  const double kGraze = 0.15, kRange = range_cut_m > 0.0f ? (double)range_cut_m : 3.5, kEdge = 0.05, kBaseline = 0.075;
+  double R[9], o[3];
+  for (int i = 0; i < 3; ++i) {
+    R[i * 3] = pose[i * 4];
+    R[i * 3 + 1] = pose[i * 4 + 1];
+    R[i * 3 + 2] = pose[i * 4 + 2];
+    o[i] = pose[i * 4 + 3];
+  }
+  RoomScene room;
+  if (scene >= 0) room = make_room(scene);
+  const size_t P = (size_t)w * h;
+  double* z = new double[P];          // z-depth in metres, 0 = no return
+  unsigned char* bad = new unsigned char[P]();
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      const double dc[3] = {((double)u - (double)cx) / (double)fx, ((double)v - (double)cy) / (double)fy, 1.0};
+      const double d[3] = {R[0] * dc[0] + R[1] * dc[1] + R[2] * dc[2], R[3] * dc[0] + R[4] * dc[1] + R[5] * dc[2],
+                           R[6] * dc[0] + R[7] * dc[1] + R[8] * dc[2]};
+      const Hit hit = scene >= 0 ? trace_room_n(room, o, d) : trace_open_n(o, d);
+      const size_t i = (size_t)v * w + u;
+      z[i] = 0.0;
+      if (!(hit.s < 10.0)) continue;
+      z[i] = hit.s;  // (unit camera-z direction: the ray parameter is the z-depth)
+      const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      const double cosang = std::fabs(hit.n[0] * d[0] + hit.n[1] * d[1] + hit.n[2] * d[2]) / len;
+      if (cosang < kGraze || hit.s > kRange) bad[i] = 1;
+      // absorbing surfaces (dark furniture returns nothing): the block of the open scene; the chest and the wardrobe of a room
+      if (absorbing && (scene >= 0 ? (hit.object == 2 || hit.object == 8) : hit.object == 1)) bad[i] = 1;
+    }
+  // shadow bands on the far side of the discontinuities of the TRUE depth (before any pixel is dropped)
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u + 1 < w; ++u) {
+      const double a = z[(size_t)v * w + u], b = z[(size_t)v * w + u + 1];
+      if (a == 0.0 || b == 0.0 || std::fabs(a - b) <= kEdge) continue;
+      const double zn = a < b ? a : b, zf = a < b ? b : a;
+      int band = (int)std::nearbyint(kBaseline * (double)fx * (1.0 / zn - 1.0 / zf));
+      band = band < 3 ? 3 : (band > 5 ? 5 : band);
+      const int dir = a < b ? 1 : -1, u0 = a < b ? u + 1 : u;   // the far pixel and outwards from the edge
+      for (int k = 0; k < band; ++k) {
+        const int uu = u0 + dir * k;
+        if (uu < 0 || uu >= w) break;
+        if (std::fabs(z[(size_t)v * w + uu] - zf) > kEdge && k > 0) break;   // (the band ends where the far surface does)
+        bad[(size_t)v * w + uu] = 1;
+      }
+    }
+  for (int v = 0; v + 1 < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      const double a = z[(size_t)v * w + u], b = z[(size_t)(v + 1) * w + u];
+      if (a == 0.0 || b == 0.0 || std::fabs(a - b) <= kEdge) continue;
+      const double zf = a < b ? b : a;
+      const int dir = a < b ? 1 : -1, v0 = a < b ? v + 1 : v;
+      for (int k = 0; k < 3; ++k) {
+        const int vv = v0 + dir * k;
+        if (vv < 0 || vv >= h) break;
+        if (std::fabs(z[(size_t)vv * w + u] - zf) > kEdge && k > 0) break;
+        bad[(size_t)vv * w + u] = 1;
+      }
+    }
+  size_t holes = 0;
+  for (size_t i = 0; i < P; ++i) {
+    uint16_t mm = 0;
+    if (z[i] != 0.0 && !bad[i]) {
+      const double noisy = z[i] * 1000.0 + (sigma_mm > 0.0f ? gauss(seed, (uint64_t)i) * (double)sigma_mm * z[i] * z[i] : 0.0);
+      const double r = std::nearbyint(noisy);
+      if (r >= 1.0 && r <= 65535.0) mm = (uint16_t)r;
+    }
+    holes += mm == 0;
+    depth[i] = mm;
+  }
+  if (hole_fraction) *hole_fraction = (double)holes / (double)P;
+  delete[] z;
+  delete[] bad;
+  return HSK_OK;
+}

@@ -118,6 +118,10 @@ class KinfuTracker:
         """write the deferred free-space weights back into the volume (what a read-out does first); enqueued only"""
         self._ck(self.lib.hsk_flush_weights(self.h))
 
+    def prepare_readout(self, product_bytes=0):
+        """allocate now what a read-out would allocate on its first use (pinned staging, row tables, product buffer)"""
+        self._ck(self.lib.hsk_prepare_readout(self.h, int(product_bytes)))
+
     def reset(self):
         self._ck(self.lib.hsk_reset(self.h))
 
@@ -145,6 +149,12 @@ class KinfuTracker:
         """lane-blocks the last integrate's classification pass handed to its per-voxel pass"""
         n = C.c_uint64()
         self._ck(self.lib.hsk_integrate_queue_entries(self.h, C.byref(n)))
+        return n.value
+
+    def integrate_light_entries(self):
+        """lane-blocks of the last integrate's light class (free space with holes in the depth image under it)"""
+        n = C.c_uint64()
+        self._ck(self.lib.hsk_integrate_light_entries(self.h, C.byref(n)))
         return n.value
 
     def raycast(self, pose, want_keys=False):
@@ -178,13 +188,16 @@ class KinfuTracker:
         """the stored planes as a row-major [nz, Y, X, 2] int16 array (into `out` when given: no fresh pages to fault in)"""
         if out is None:
             out = np.empty((self.stored_nz, self.cfg.vol_y, self.cfg.vol_x, 2), np.int16)
-        assert out.dtype == np.int16 and out.flags.c_contiguous and out.size == self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2
+        want = self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2
+        if not (isinstance(out, np.ndarray) and out.dtype == np.int16 and out.flags.c_contiguous and out.flags.writeable and out.size == want):
+            raise ValueError(f"download_tsdf(out=...): a writeable C-contiguous int16 array of {want} elements is needed (the C side takes a bare pointer)")
         self._ck(self.lib.hsk_download_tsdf(self.h, out.ctypes.data))
         return out
 
     def upload_tsdf(self, vol):
         v = np.ascontiguousarray(vol, np.int16)
-        assert v.size == self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2
+        if v.size != self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2:
+            raise ValueError(f"upload_tsdf: {self.stored_nz * self.cfg.vol_y * self.cfg.vol_x * 2} int16 elements are needed, got {v.size}")
         self._ck(self.lib.hsk_upload_tsdf(self.h, v.ctypes.data))
 
     def get_pose(self):
@@ -406,6 +419,30 @@ def synth_noisy_frames(count, first=0, sigma_mm=1.2, dropout=0.02, seeds=(1234, 
             poses.append(gt)
             frames.append(np.clip(np.rint(d), 0, 65535).astype(np.uint16))
     return poses, frames
+
+
+def synth_sensor_depth(pose, scene=-1, seed=1234, sigma_mm=1.2, range_cut_m=3.5, absorbing=False, w=640, h=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
+    """one frame with holes as a structured-light sensor makes them (hsk_synth_render_sensor: grazing rays, shadow bands behind
+    depth discontinuities, the 3.5 m range cut, sigma_mm x z^2 noise); scene -1 = the open scene of synth_depth, 0..3 = the
+    closed rooms -> (uint16 depth, share of pixels without depth)"""
+    p = np.ascontiguousarray(pose, np.float32).reshape(16)
+    d = np.empty((h, w), np.uint16)
+    frac = C.c_double()
+    rc = _lib.load().hsk_synth_render_sensor(int(scene), _fp(p), w, h, fx, fy, cx, cy, int(seed), float(sigma_mm), float(range_cut_m), int(bool(absorbing)),
+                                             d.ctypes.data, C.byref(frac))
+    if rc != 0:
+        raise KinfuError(f"hsk_synth_render_sensor failed ({rc})")
+    return d, frac.value
+
+
+def synth_sensor_frames(count, first=0, seed=1234, sigma_mm=1.2, range_cut_m=3.5, absorbing=False, room=None, scan=720):
+    """the scripted stream of SURVEY.md 8(d) -- or, room = 0..3, the three-turn scan inside a closed room -- seen by a sensor
+    (synth_sensor_depth; frame k's noise is keyed by seed + k) -> (ground-truth poses, uint16 frames)"""
+    if room is None:
+        poses = [synth_pose(k) for k in range(first, first + count)]
+    else:
+        poses = [synth_room_pose(room, k, scan) for k in range(first, first + count)]
+    return poses, [synth_sensor_depth(p, -1 if room is None else room, seed + first + i, sigma_mm, range_cut_m, absorbing)[0] for i, p in enumerate(poses)]
 
 
 def synth_room_extents(variant):

@@ -126,6 +126,12 @@ int hsk_upload_map(hsk_ctx* k, int kind, int level, const float* in);
 int hsk_download_depth_level(hsk_ctx* k, int level, uint16_t* out); /* filtered pyramid */
 int hsk_download_scaled_depth(hsk_ctx* k, float* out);
 
+/* Everything a read-out allocates on its first use -- the pinned staging pair (2 x 32 MiB, or a plane of the volume if that is
+ * more), the row tables of the count pass, the marching-cubes table, a product buffer of `product_bytes` (0: 48 MiB, a scan's
+ * cloud and cubes mesh at 512^3) -- made NOW.  A host that shows a cloud from its GL thread (addPointCloud, Main.hs:806)
+ * calls this once from the worker thread that created the context: the first hsk_extract_* then costs what every later
+ * one does (it was 7 ms against 0.7).  Optional; idempotent; the buffers still grow on demand. */
+int hsk_prepare_readout(hsk_ctx* k, size_t product_bytes);
 /* TSDF zero-crossing cloud: packed float32 xyz (the layout of Cloud.cloudPoints, Main.hs:120) in voxel order. */
 int hsk_extract_cloud(hsk_ctx* k, float* xyz, size_t cap_points, size_t* n_points);
 /* TSDF zero level set as a triangle soup, 9 floats per triangle, marching tetrahedra (6 Kuhn tetrahedra per cube),
@@ -248,6 +254,9 @@ int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]);
 /* lane-blocks (4 x 1 x 4 voxels) the last integrate's classification pass could not settle and handed to its per-voxel
  * pass (a measure of the classification's slack: bench.py reports it beside V_upd); synchronises the context's stream */
 int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries);
+/* ... and the lane-blocks of the last integrate's LIGHT class: free space with holes in the depth image under it (each voxel is
+   rewritten with F = 1 or left alone according to whether its pixel has depth); not counted by hsk_integrate_queue_entries */
+int hsk_integrate_light_entries(hsk_ctx* k, uint64_t* n_entries);
 /* the coarse level of the last integrate (one verdict per wave-chunk of 16 x 16 voxels x the pass-A chunk of planes):
  * counts[0] = chunks pass A had to classify lane-block by lane-block ("mixed"), [1] = chunks settled as a whole (outside the
  * frustum, wholly occluded, or wholly free space with the observation recorded in the chunk's byte), [2] = wholly free
@@ -267,6 +276,13 @@ int hsk_synth_render(const float pose[16], int w, int h, float fx, float fy, flo
 int hsk_synth_room_extents(int variant, float extents[6] /* x0 x1 y0 y1 z0 z1 */);
 int hsk_synth_room_pose(int variant, int frame, int n_frames, float pose[16]); /* three turns from near the centre: level, up, down */
 int hsk_synth_room_render(int variant, const float pose[16], int w, int h, float fx, float fy, float cx, float cy, uint16_t* depth);
+/* The same scenes as a structured-light sensor returns them (housescan/HoniHelper.hs:20-36: a real takeDepthSnapshot frame
+   has its invalid pixels in contiguous regions): no return from grazing rays (|n.d| < 0.15), a 3-5 px shadow band on the
+   far side of every depth discontinuity, nothing beyond range_cut_m (<= 0: 3.5 m), nothing from absorbing furniture when
+   `absorbing` is set, and sigma_mm x (z / 1 m)^2 of Gaussian noise keyed by (seed, pixel).  scene < 0: the open scene of
+   hsk_synth_render; 0..3: closed room `scene`.  hole_fraction (may be NULL): the share of pixels without depth. */
+int hsk_synth_render_sensor(int scene, const float pose[16], int w, int h, float fx, float fy, float cx, float cy, uint64_t seed,
+                            float sigma_mm, float range_cut_m, int absorbing, uint16_t* depth, double* hole_fraction);
 
 /* Products on the file seam (Main.hs:1740, :1320-1345): binary PCD with float32 x y z */
 int hsk_write_pcd_xyz(const char* path, const float* xyz, size_t n_points);

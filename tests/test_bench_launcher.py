@@ -141,7 +141,7 @@ def test_visible_gpu_count_reads_the_topology_without_a_gpu_call(tmp_path, monke
     """the launcher's device count: kfd topology nodes with SIMDs (CPU nodes have none), cut down by a *_VISIBLE_DEVICES
     list; 0 (cannot tell) where there is no kfd, in which case the launcher lets the workers find out"""
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_launcher as bench
     import glob as globmod
     nodes = []
     for i, simds in enumerate((0, 256, 256, 0, 256)):

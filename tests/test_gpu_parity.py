@@ -926,6 +926,75 @@ def test_noisy_stream_512_vs_oracle(hsk, oracle):
     ot.close()
 
 
+def test_sensor_holes_stream_512_vs_oracle(hsk, oracle):
+    """HOLES AS A SENSOR MAKES THEM on the measured path: hsk_synth_render_sensor -- no return from grazing
+    rays, shadow bands behind depth discontinuities, the range cut, an absorbing block, sigma = 1.2 mm z^2 -- i.e. CONTIGUOUS
+    invalid regions (5-18 % of the pixels; housescan/HoniHelper.hs:20-36), 40 pipelined frames at 512^3: every pose, the TSDF and
+    the model maps bit-equal to the oracle's.  Contiguous holes are what pass A's light path and the coarse level's
+    whole-column rule are for: blocks and chunks whose pixels are ALL holes or all far."""
+    n, frames_n = 512, 40
+    gts, frames = hsk.synth_sensor_frames(frames_n, absorbing=True)
+    frac = float(np.mean([(f == 0).mean() for f in frames]))
+    assert 0.04 < frac < 0.30, frac
+    ot = oracle.Tracker(oracle.default_config(n), omp=True)
+    want = [ot.process(d) for d in frames]
+    trk = hsk.KinfuTracker(n=n)
+    got = []
+    trk.submit_frame(frames[0])
+    for d in frames[1:]:
+        trk.submit_frame(d)
+        got.append(trk.wait_frame())
+    got.append(trk.wait_frame())
+    for k, ((ph, okh), (po, oko)) in enumerate(zip(got, want)):
+        assert okh == oko, (k, okh, oko)
+        assert_same_bits(ph, po, f"sensor-holes 512^3 pose frame {k}")
+    assert sum(1 for _, ok in got[1:] if not ok) == 0, "the sensor-holes stream must stay tracked"
+    dt, ang = _pose_err(got[-1][0], gts[-1])
+    assert dt < 10.0 and ang < 0.5, (dt, ang)
+    assert_same_bits(trk.download_tsdf(), ot.volume(), "sensor-holes 512^3 tsdf after 40 frames")
+    for level in range(3):
+        assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"sensor-holes 512^3 model vmap {level}")
+        assert_same_bits(trk.download_map(3, level), ot.model_map(3, level), f"sensor-holes 512^3 model nmap {level}")
+    trk.close()
+    ot.close()
+
+
+@pytest.mark.parametrize("variant,first,count", [(0, 0, 64), (1, 225, 45), (0, 470, 40)])
+def test_room_scan_512_vs_oracle(hsk, oracle, variant, first, count):
+    """THE ROOM SCAN ON THE MEASURED PATH: the camera stands INSIDE the volume (hsk_synth_room_*: a closed
+    room with furniture, the three-turn turntable scan of 720 frames HouseScan's rooms are made with, README.md:12,
+    Main.hs:1738-1762), 512^3, pipelined host frames -- every pose, the TSDF and the model maps bit-equal to the oracle's
+    tracker started from the same init_pose.  Three windows: 64 frames of the level turn (room 0); the end of the level turn
+    and 30 frames of the turn that swings UP to 38 deg (room 1: the ceiling with its beams comes into view); 40 frames
+    round the start of the turn that swings DOWN (room 0).  Every headline figure before round 6 was a camera OUTSIDE the
+    volume looking in: here the frustum starts inside it (near plane, rim and apex within the grid), rays leave through
+    five walls, and the free space in front of the camera is the room itself."""
+    n, scan = 512, 720
+    gts = [hsk.synth_room_pose(variant, first + k, scan) for k in range(count)]
+    frames = [hsk.synth_room_depth(variant, p) for p in gts]
+    ot = oracle.Tracker(oracle.default_config(n, omp=True, init_R=gts[0][:3, :3], init_t=gts[0][:3, 3]), omp=True)
+    want = [ot.process(d) for d in frames]
+    trk = hsk.KinfuTracker(n=n, init_pose=gts[0])
+    got = []
+    trk.submit_frame(frames[0])
+    for d in frames[1:]:
+        trk.submit_frame(d)
+        got.append(trk.wait_frame())
+    got.append(trk.wait_frame())
+    for k, ((ph, okh), (po, oko)) in enumerate(zip(got, want)):
+        assert okh == oko, (k, okh, oko)
+        assert_same_bits(ph, po, f"room {variant} 512^3 pose frame {first + k}")
+    assert sum(1 for _, ok in got[1:] if not ok) == 0, "the room scan must stay tracked"
+    dt, ang = _pose_err(got[-1][0], gts[-1])
+    assert dt < 10.0 and ang < 0.3, (dt, ang)
+    assert_same_bits(trk.download_tsdf(), ot.volume(), f"room {variant} 512^3 tsdf after frames {first}..{first + count - 1}")
+    for level in range(3):
+        assert_same_bits(trk.download_map(2, level), ot.model_map(2, level), f"room 512^3 model vmap {level}")
+        assert_same_bits(trk.download_map(3, level), ot.model_map(3, level), f"room 512^3 model nmap {level}")
+    trk.close()
+    ot.close()
+
+
 def test_1024_properties(hsk, synth_frames):
     """BASELINE configs[3] volume (1024^3, 4 GiB) on one GPU: size-independent properties, nothing downloaded"""
     trk = hsk.KinfuTracker(n=1024)

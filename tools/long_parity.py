@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Long-horizon parity: FRAMES frames of the scripted synthetic stream through the pipelined tracker at N^3 against the CPU
 oracle's tracker -- every pose and the final TSDF bit for bit.  (The pytest suite holds shorter runs at these sizes: the
-oracle takes 0.14 s per frame at 512^3 and 0.5 s at 1024^3 on 16 cores.)   usage: tools/long_parity.py N FRAMES [--noise]
---noise: SURVEY.md 8(d)'s noise run instead of the exact render (sigma = 1.2 mm z^2 on every pixel, 2 % dropout; seeds 1234 / 5678)"""
+oracle takes 0.14 s per frame at 512^3 and 0.5 s at 1024^3 on 16 cores.)
+usage: tools/long_parity.py N FRAMES [--noise | --holes | --room V [--first K] [--scan F]]
+--noise: SURVEY.md 8(d)'s noise run instead of the exact render (sigma = 1.2 mm z^2 on every pixel, 2 % dropout; seeds 1234 / 5678)
+--holes: the scripted stream with holes as a sensor makes them (hsk.synth_sensor_frames: grazing rays, shadow bands, range cut, sigma)
+--room V: the ROOM SCAN -- camera inside the volume: frames K .. K + FRAMES - 1 of the F-frame (default 720) three-turn scan of
+          closed room V (hsk_synth_room_*), the tracker started at the ground-truth pose of frame K"""
 import os
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))  # (a 256-CPU box behind a 16-core quota)
 import sys, time, numpy as np
@@ -10,11 +14,31 @@ sys.path.insert(0, '.')
 import housescan_amd as hsk
 from oracle import oracle
 n, frames = int(sys.argv[1]), int(sys.argv[2])
-cfg_o = oracle.default_config(n, omp=True)
+opts = sys.argv[3:]
+noise, holes = "--noise" in opts, "--holes" in opts
+room = int(opts[opts.index("--room") + 1]) if "--room" in opts else None
+what = ""
+if room is not None:
+    first = int(opts[opts.index("--first") + 1]) if "--first" in opts else 0
+    scan = int(opts[opts.index("--scan") + 1]) if "--scan" in opts else 720
+    gts = [hsk.synth_room_pose(room, first + k, scan) for k in range(frames)]
+    fr = [hsk.synth_room_depth(room, p) for p in gts]
+    cfg_o = oracle.default_config(n, omp=True, init_R=gts[0][:3, :3], init_t=gts[0][:3, 3])
+    trk = hsk.KinfuTracker(n=n, init_pose=gts[0])
+    what = f" ROOM SCAN (camera inside the volume): room {room}, frames {first}..{first + frames - 1} of a {scan}-frame three-turn scan"
+else:
+    cfg_o = oracle.default_config(n, omp=True)
+    trk = hsk.KinfuTracker(n=n)
+    if noise:
+        gts, fr = hsk.synth_noisy_frames(frames)
+        what = " NOISY stream (1.2 mm z^2, 2 % dropout)"
+    elif holes:
+        gts, fr = hsk.synth_sensor_frames(frames)
+        what = " SENSOR-HOLES stream (grazing rays, shadow bands, range cut, 1.2 mm z^2; %.1f %% of the pixels invalid)" % (100.0 * np.mean([(d == 0).mean() for d in fr]))
+    else:
+        gts = [hsk.synth_pose(k) for k in range(frames)]
+        fr = [hsk.synth_depth(p) for p in gts]
 ot = oracle.Tracker(cfg_o, omp=True)
-trk = hsk.KinfuTracker(n=n)
-noise = "--noise" in sys.argv[3:]
-fr = hsk.synth_noisy_frames(frames)[1] if noise else [hsk.synth_depth(hsk.synth_pose(k)) for k in range(frames)]
 t0 = time.time()
 want = [ot.process(d) for d in fr]
 t1 = time.time()
@@ -32,6 +56,7 @@ for k, ((p, ok), (po, oko)) in enumerate(zip(got, want)):
 vol = trk.download_tsdf()
 dv = int((vol != ot.volume()).any(axis=-1).sum())
 from housescan_amd import _lib
-print(f"build {_lib.load().hsk_build_id().decode()}  n={n} frames={frames}{' NOISY stream (1.2 mm z^2, 2 % dropout)' if noise else ''}: pose mismatches {bad} of {frames}, differing voxels {dv} of {vol.shape[0] * vol.shape[1] * vol.shape[2]}, "
-      f"lost frames {sum(1 for _, ok in got[1:] if not ok)}, oracle {t1 - t0:.1f} s")
+worst = max(float(np.linalg.norm(p[:3, 3] - g[:3, 3])) for (p, _), g in zip(got, gts)) * 1e3
+print(f"build {_lib.load().hsk_build_id().decode()}  n={n} frames={frames}{what}: pose mismatches {bad} of {frames}, differing voxels {dv} of {vol.shape[0] * vol.shape[1] * vol.shape[2]}, "
+      f"lost frames {sum(1 for _, ok in got[1:] if not ok)}, worst translation error vs ground truth {worst:.2f} mm, oracle {t1 - t0:.1f} s")
 sys.exit(1 if (bad or dv) else 0)
