@@ -21,8 +21,10 @@
 //   2. a lane-block's tight pixel box against the 4-px / 8-px tile windows and the validity mask (free space: a summary
 //      byte moves; occluded: nothing), with the dilated 16-px table as the fall-back near the camera;
 //   3. exact fast paths of the running mean (saturated free space, first observation).
-// What is left -- blocks near a surface, at the frustum's rim, or with a hole in the depth image under them -- takes the exact
-// per-voxel rule in pass B.  Bricks that ever received a negative TSDF are flagged for the raycaster's empty-space test.
+// What is left takes pass B, a lane per plane of a queued lane-block: blocks near a surface or at the frustum's rim the exact
+// per-voxel rule; (round 6) free-space blocks with a hole in the depth image under them the LIGHT class -- F = 1 where the
+// voxel's pixel has depth, nothing where it has none.  Bricks that ever received a negative TSDF are flagged for the
+// raycaster's empty-space test.
 // ------------------------------------------------------------------------------------------------------
 #define HSK_TILE 16
 #define HSK_NQUEUES 256       // uncertain lane-blocks are spread over this many queues (pass A -> pass B)
@@ -526,6 +528,7 @@ static __device__ __forceinline__ void mark_brick_negative(unsigned* __restrict_
 // down as well; hsk_reset (0: the blocks are in state 1, not quiet); hsk_upload_tsdf (k_summaries<false> rebuilds both levels).
 #define HSK_SUM_RAGGED 130u
 #define HSK_SUM_MAX 255u
+#define HSK_LIGHT_PEND 15u  // pending observations of a rim block that a light queue entry can carry (four bits)
 // (NS = groups, i.e. summary bytes, per lane and chunk: 2 or 4 -- vp.zchunk / 4; a power of two, so shifts and masks)
 static __host__ __device__ __forceinline__ size_t hsk_chunk_count(const VolParams& vp) {  // wave-chunks (4 per workgroup-chunk)
   return (size_t)((vp.nzs + vp.zchunk - 1) / vp.zchunk) * ((vp.Y + 15) / 16) * ((vp.X + 63) / 64) * 4;
@@ -643,257 +646,6 @@ static __device__ __forceinline__ DetailPose detail_pose(const TrackState* __res
   p.i10 = st->R[1]; p.i11 = st->R[4]; p.i12 = st->R[7];
   p.i20 = st->R[2]; p.i21 = st->R[5]; p.i22 = st->R[8];
   return p;
-}
-
-// One lane-block (4 x-voxels at x0, row y, stored planes zb .. zb + 3) through the per-voxel path, U planes per trip.
-// `planes`: bit u set = plane zb + u lies in the lane's z range (0: the lane holds no entry and idles inside the
-// wave-uniform branches).  Returns the voxels rewritten.
-template <bool COUNT_ONLY, int U>
-static __device__ __forceinline__ unsigned detail_entry(unsigned planes, int x0, int y, int zb, uint4* __restrict__ vol,
-                                                        const float* __restrict__ scaled, const DetailPose& P,
-                                                        const VolParams& vp, int W, int H, const Intr& in,
-                                                        unsigned* __restrict__ flags) {
-  static_assert(U == 1 || U == 2 || U == 4, "planes per trip");
-  const int lane = threadIdx.x & 63;
-  (void)lane;
-  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
-  unsigned cnt = 0;
-  float ax[4], ay[4], az[4], pn[4];
-  const float gy = ((float)y + 0.5f) * vp.cell[1] - P.ty;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - P.tx;
-    ax[j] = P.i00 * gx + P.i01 * gy;
-    ay[j] = P.i10 * gx + P.i11 * gy;
-    az[j] = P.i20 * gx + P.i21 * gy;
-    pn[j] = gx * gx + gy * gy;
-  }
-  // The brick flag of the lane-block (its 4 planes lie in one brick: zb is a multiple of 4, a brick's edge of 8 or more) is
-  // requested HERE, with the trip's first loads, and acted on once after the last plane.  Looked up where a plane turns
-  // out to hold a new negative value, it was a load whose result the very next branch needs: a full drain of the
-  // wave's memory queue (the stores of the planes before it included) up to four times a trip.
-  unsigned flag_word = 0u;
-  bool neg_any = false;
-  const int fbit = ((zb >> vp.bshift) * (vp.Y >> vp.bshift) + (y >> vp.bshift)) * (vp.X >> vp.bshift) + (x0 >> vp.bshift);
-  if (!COUNT_ONLY && planes != 0u) flag_word = flags[fbit >> 5];
-#pragma unroll
-  for (int h0 = 0; h0 < 4; h0 += U) {
-    bool inr[U];
-    bool any_in = false;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      inr[u] = ((planes >> (h0 + u)) & 1u) != 0u;
-      any_in = any_in || inr[u];
-    }
-    if (__ballot(any_in) == 0ull) continue;
-    // 1. the volume vectors of the trip: in flight while the projections run
-    uint4 q[U];
-    if (!COUNT_ONLY) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        q[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (inr[u]) q[u] = vol[VIDX(zb, h0 + u)];
-      }
-    }
-    // 2. projection of the 4U voxel centres (A.4, exact), then their depth gathers
-    float D[U][4];  // scaled depth at the voxel's pixel, 0 when it has none; afterwards the observation F
-    float gz2[U];
-    int pix[U][4];
-    // the gathers of the trip's first planes are requested before the later planes are projected: their round trip
-    // runs under that arithmetic instead of ahead of a wait
-    static_assert(U == 4, "the trip is taken as two halves of two planes");
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int u = 2 * half; u < 2 * half + 2; ++u) {
-        const float gz = ((float)(vp.zs0 + zb + h0 + u) + 0.5f) * vp.cell[2] - P.tz;
-        const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
-        gz2[u] = gz * gz;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float camz = az[j] + bz;
-          const float inv_z = hsk_rcp_exact(camz);
-          const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
-          const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
-          const int uu = (int)rintf(fu), vv = (int)rintf(fv);
-          const bool ok = inr[u] && camz >= 1.17549435e-38f && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H;
-          pix[u][j] = ok ? vv * W + uu : -1;
-        }
-      }
-#pragma unroll
-      for (int u = 2 * half; u < 2 * half + 2; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) D[u][j] = scaled[max(pix[u][j], 0)];
-      if (half == 0) asm volatile("" ::: "memory");  // (keeps the first half's gathers ahead of the second half's arithmetic)
-    }
-    // 3. the observation: F in [-1, 1] for a voxel the rule rewrites, -4 for one it leaves alone
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float Ds = pix[u][j] >= 0 ? D[u][j] : 0.0f;
-        const float sdf = Ds - hsk_sqrt_exact(gz2[u] + pn[j]);
-        const float f = sdf * vp.tau_inv;
-        D[u][j] = (Ds != 0.0f && sdf >= -vp.tau) ? (f < 1.0f ? f : 1.0f) : -4.0f;
-      }
-    if (COUNT_ONLY) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cnt += D[u][j] > -2.0f ? 1u : 0u;
-      continue;
-    }
-    // 4. running mean, repack, store
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-      unsigned nw[4];
-      bool gen[4], gen_any = false;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool upd = D[u][j] > -2.0f;
-        const bool unseen = (w4[j] >> 16) == 0u;
-        // free space (F == 1) onto a stored +1, or onto an unseen voxel: the mean is +1 exactly, only the weight moves
-        const bool simple = D[u][j] == 1.0f && (unseen || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR);
-        const unsigned ws = unseen ? (0x10000u | (unsigned)HSK_DIVISOR) : min(w4[j] + 0x10000u, cap);
-        nw[j] = (upd && simple) ? ws : w4[j];
-        gen[j] = upd && !simple;
-        gen_any = gen_any || gen[j];
-      }
-      bool neg = false;
-      if (__ballot(gen_any) != 0ull) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int tp = (int)(short)(w4[j] & 0xffffu);
-          const unsigned wp = w4[j] >> 16;
-          const float Wp = (float)wp;
-          const float Fn = hsk_div_small_exact(hsk_tsdf_unpack(tp) * Wp + D[u][j], Wp + 1.0f);
-          int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
-          fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
-          const unsigned wg = ((unsigned)fixed & 0xffffu) | (min(wp + 1u, (unsigned)HSK_MAX_WEIGHT) << 16);
-          nw[j] = gen[j] ? wg : nw[j];
-          neg = neg || (gen[j] && fixed < 0);
-        }
-      }
-      // (saturated free space -- +1 at the weight cap -- comes back unchanged: no store)
-      if (nw[0] != w4[0] || nw[1] != w4[1] || nw[2] != w4[2] || nw[3] != w4[3])
-        vol[VIDX(zb, h0 + u)] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-      neg_any = neg_any || neg;
-    }
-  }
-  if (!COUNT_ONLY && neg_any && ((flag_word >> (fbit & 31)) & 1u) == 0u) mark_brick_negative(flags, vp, x0, y, zb);
-  return cnt;
-}
-
-// (round 6) One LIGHT lane-block (pass A: "the light class") -- all four planes inside the lane's range, every pixel of its box
-// inside the image and in front of the camera, and every pixel WITH depth a truncation distance or more behind the block: a voxel
-// is rewritten with F = 1 when its pixel has depth and left alone when it has none.  What is needed per voxel is the
-// specification's pixel (the same expressions as detail_entry's, so the same bits) and whether the scaled depth there is 0.
-// Afterwards the block is classified again: when all 16 voxels hold +1 with a weight, its summary byte says so (pass A had
-// cleared it), and the next free-space observation of the block moves that byte instead of the volume.
-// `have`: the lane holds an entry.  Returns the voxels rewritten.
-template <bool COUNT_ONLY>
-static __device__ __forceinline__ unsigned light_entry(bool have, int x0, int y, int zb, uint4* __restrict__ vol,
-                                                       const float* __restrict__ scaled, const DetailPose& P, const VolParams& vp,
-                                                       int W, int H, const Intr& in, unsigned char* __restrict__ uni) {
-  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
-  uint4 q[4];
-  if (!COUNT_ONLY) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      q[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (have) q[u] = vol[VIDX(zb, u)];
-    }
-  }
-  float ax[4], ay[4], az[4];
-  const float gy = ((float)y + 0.5f) * vp.cell[1] - P.ty;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - P.tx;
-    ax[j] = P.i00 * gx + P.i01 * gy;
-    ay[j] = P.i10 * gx + P.i11 * gy;
-    az[j] = P.i20 * gx + P.i21 * gy;
-  }
-  const int last = W * H - 1;
-  float D[4][4];
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    int pix[2][4];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int u = 2 * half + v;
-      const float gz = ((float)(vp.zs0 + zb + u) + 0.5f) * vp.cell[2] - P.tz;
-      const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float camz = az[j] + bz;
-        const float inv_z = hsk_rcp_exact(camz);
-        const float fu = ((ax[j] + bx) * in.fx) * inv_z + in.cx;
-        const float fv = ((ay[j] + by) * in.fy) * inv_z + in.cy;
-        const int uu = (int)rintf(fu), vv = (int)rintf(fv);
-        pix[v][j] = min(max(vv * W + uu, 0), last);  // (inside the image by the class; the clamp only guards the address)
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < 2; ++v)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) D[2 * half + v][j] = scaled[pix[v][j]];
-    if (half == 0) asm volatile("" ::: "memory");  // (the first planes' gathers travel under the last planes' projections)
-  }
-  unsigned cnt = 0;
-  if (COUNT_ONLY) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cnt += (have && D[u][j] != 0.0f) ? 1u : 0u;
-    return cnt;
-  }
-  bool gen_any = false;
-  unsigned nw[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool upd = have && D[u][j] != 0.0f;
-      const bool unseen = (w4[j] >> 16) == 0u;
-      const bool simple = unseen || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
-      const unsigned ws = unseen ? (0x10000u | (unsigned)HSK_DIVISOR) : min(w4[j] + 0x10000u, cap);
-      nw[u][j] = (upd && simple) ? ws : w4[j];
-      gen_any = gen_any || (upd && !simple);
-    }
-  }
-  if (__ballot(gen_any) != 0ull) {  // a voxel that was inside the band in an earlier frame: the running mean with F = 1 (update_vector_free4)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool upd = have && D[u][j] != 0.0f;
-        const unsigned wp = w4[j] >> 16;
-        const bool simple = wp == 0u || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR;
-        const int tp = (int)(short)(w4[j] & 0xffffu);
-        const float Wp = (float)wp;
-        const float Fn = hsk_div_small_exact(hsk_tsdf_unpack(tp) * Wp + 1.0f, Wp + 1.0f);
-        int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
-        fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
-        const unsigned wg = ((unsigned)fixed & 0xffffu) | (min(wp + 1u, (unsigned)HSK_MAX_WEIGHT) << 16);
-        nw[u][j] = (upd && !simple) ? wg : nw[u][j];
-      }
-    }
-  }
-  // (F = 1 cannot turn a non-negative value negative: no brick flag can newly be due)
-  uint4 r[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    r[u] = make_uint4(nw[u][0], nw[u][1], nw[u][2], nw[u][3]);
-    if (have && (r[u].x != q[u].x || r[u].y != q[u].y || r[u].z != q[u].z || r[u].w != q[u].w)) vol[VIDX(zb, u)] = r[u];
-  }
-  if (uni != nullptr && have) {
-    const unsigned code = hsk_sum_classify(r);
-    if (code != 0u) uni[hsk_sum_index(vp, x0, y, zb)] = (unsigned char)code;
-  }
-  return 0u;
 }
 
 #ifdef HSK_PA_TIMING
@@ -1145,21 +897,49 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       const bool ask = free2v & !whole & (box_s[sidx] != 0u);
       if (__ballot(ask) != 0ull) {
         unsigned bad = 1u, allbad = 0u;
-        if (ask) {
-          const unsigned bx = box_s[sidx];
-          const int iu0 = (int)(bx & 2047u), iv0 = (int)((bx >> 11) & 2047u), wd = (int)((bx >> 22) & 31u), ht = (int)((bx >> 27) & 3u);
-          const unsigned* __restrict__ row = vmask + (size_t)iv0 * mpitch + (iu0 >> 5);
-          const unsigned long long sel = ((1ull << (wd + 1)) - 1ull) << (iu0 & 31);  // (wd + 1 <= 32 columns from bit iu0 & 31: never beyond the row's two words)
-          unsigned long long any = 0ull, all = ~0ull;
+        const unsigned bx = box_s[sidx];
+        const int iu0 = (int)(bx & 2047u), iv0 = (int)((bx >> 11) & 2047u), wd = (int)((bx >> 22) & 31u), ht = (int)((bx >> 27) & 3u);
+        // (round 6) A box of at most 17 columns -- nearly every one: four voxels across -- lies inside the 32 pixels that start
+        // at the 16-px boundary below it, and the mask's rows are arrays of 16-bit halves: ONE 32-bit load at a halfword
+        // address per row of the box, and only the rows the box has (it was two words for each of four rows, the last row
+        // repeated: eight loads a block where two or three do -- under SURVEY.md 8(d)'s 2 % dropout nearly every free block asks)
+        const bool narrow = ask & (wd <= 16);
+        if (__ballot(narrow) != 0ull) {
+          const unsigned short* __restrict__ row16 = (const unsigned short*)vmask + (size_t)iv0 * (size_t)(2 * mpitch) + (iu0 >> 4);
+          const unsigned sel = (unsigned)(((1ull << (wd + 1)) - 1ull) << (iu0 & 15));
+          unsigned any = 0u, all = ~0u;
 #pragma unroll
           for (int h = 0; h < 4; ++h) {
-            const unsigned* __restrict__ rp = row + (size_t)min(h, ht) * mpitch;
-            const unsigned long long w2 = (unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32);
-            any |= w2 & sel;
-            all &= w2 | ~sel;
+            const bool rowh = narrow & (ht >= h);
+            if (h != 0 && __ballot(rowh) == 0ull) break;  // wave-uniform
+            if (rowh) {
+              unsigned w2;
+              __builtin_memcpy(&w2, row16 + (size_t)h * (size_t)(2 * mpitch), 4);  // (one global_load_dword at a 2-byte-aligned address)
+              any |= w2 & sel;
+              all &= w2 | ~sel;
+            }
           }
-          bad = any != 0ull ? 1u : 0u;
-          allbad = all == ~0ull ? 1u : 0u;
+          if (narrow) {
+            bad = any != 0u ? 1u : 0u;
+            allbad = all == ~0u ? 1u : 0u;
+          }
+        }
+        const bool wide = ask & (wd > 16);
+        if (__ballot(wide) != 0ull) {
+          if (wide) {
+            const unsigned* __restrict__ row = vmask + (size_t)iv0 * mpitch + (iu0 >> 5);
+            const unsigned long long sel = ((1ull << (wd + 1)) - 1ull) << (iu0 & 31);  // (wd + 1 <= 32 columns from bit iu0 & 31: never beyond the row's two words)
+            unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              const unsigned* __restrict__ rp = row + (size_t)min(h, ht) * mpitch;
+              const unsigned long long w2 = (unsigned long long)rp[0] | ((unsigned long long)rp[1] << 32);
+              any |= w2 & sel;
+              all &= w2 | ~sel;
+            }
+            bad = any != 0ull ? 1u : 0u;
+            allbad = all == ~0ull ? 1u : 0u;
+          }
         }
         whole = whole | (ask & (bad == 0u));
         // (round 6) every pixel of the box is a hole -- the inside of a shadow, of an absorbing surface's silhouette: no voxel
@@ -1240,6 +1020,9 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
     // (round 6: a queue is filled from both ends -- the per-voxel entries from its head, the light ones from its tail; the
     // two counts are the halves of ONE 64-bit counter, so a wave still draws one ticket)
     unsigned long long bo[NS], bl[NS];
+    unsigned lcode[NS];  // what a light entry carries in its top four bits: pending observations pass B is to add (0: none)
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) lcode[sidx] = 0u;
     unsigned n_other = 0u, n_light = 0u;
     unsigned long long base_all = 0ull;
 #pragma unroll
@@ -1274,7 +1057,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
       bool rd[NS];
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) {
-        const bool fr = actv[sidx] & free44_s[sidx], ot = actv[sidx] & (other_s[sidx] | light_s[sidx]);
+        const bool fr = actv[sidx] & free44_s[sidx], lt = actv[sidx] & light_s[sidx], ot = (actv[sidx] & other_s[sidx]) | lt;
         const unsigned sm = sum8[sidx];
         const int sbit = 8 * sidx;  // where the group's summary sits in new16
         unsigned wstore = 0u;  // weight to store into all 16 voxels (0: none)
@@ -1295,7 +1078,11 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
         // (b) needs the words: a free block in state 0, or a rim block whose pending count is full; a rim block with
         //     pending observations on its way to pass B; a rim block the frame does not touch whose count, with the chunk's
         //     pushed into it, no longer fits the byte
-        rd[sidx] = (fr && (sm == 0u || sm >= HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED) || sm > HSK_SUM_MAX;
+        // (round 6: a LIGHT rim block with up to HSK_LIGHT_PEND pending observations keeps them: its queue entry carries the
+        // count and pass B, which reads and rewrites the words anyway, adds it -- the block's read-modify-write happens once,
+        // on a dense wave, instead of twice, the first time inside a mixed wave of this kernel)
+        lcode[sidx] = (lt && sm > HSK_SUM_RAGGED && sm <= HSK_SUM_RAGGED + HSK_LIGHT_PEND) ? sm - HSK_SUM_RAGGED : 0u;
+        rd[sidx] = (fr && (sm == 0u || sm >= HSK_SUM_MAX)) || (ot && sm > HSK_SUM_RAGGED && lcode[sidx] == 0u) || sm > HSK_SUM_MAX;
       }
       // (one group at a time: this path is the exception now, and four vectors live instead of eight keep the kernel at
       // seven waves per SIMD)
@@ -1373,7 +1160,7 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
         queue[(size_t)qi * qcap + b0 + (unsigned)__popcll(bo[sidx] & ((1ull << lane) - 1ull))] = id | (pm << 28);
       }
       // (a light block lies with all four planes in the lane's range -- in_all is part of its class: the id alone, from the tail)
-      if (light_s[sidx]) queue[(size_t)qi * qcap + (qcap - 1u) - (l0 + (unsigned)__popcll(bl[sidx] & ((1ull << lane) - 1ull)))] = id;
+      if (light_s[sidx]) queue[(size_t)qi * qcap + (qcap - 1u) - (l0 + (unsigned)__popcll(bl[sidx] & ((1ull << lane) - 1ull)))] = id | (lcode[sidx] << 28);
       b0 += (unsigned)__popcll(bo[sidx]);
       l0 += (unsigned)__popcll(bl[sidx]);
     }
@@ -1387,69 +1174,52 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Pass B (second form, round 2): the queued lane-blocks, per-voxel path -- built round three facts measured on round 1's
-// form (profiles/r01/final_pmc_summary.txt, profiles/r02/integrate_analysis.md):
-// it spent half its wave cycles parked on memory and a quarter of its instructions on branches and lane-mask
-// bookkeeping (171 basic blocks, 535 s_and/s_or, 37 spilled SGPRs), all of it in service of "approximate first, exact
-// where a decision is close".  With hsk_rcp_exact / hsk_sqrt_exact / hsk_div_small_exact the specification's correctly
-// rounded operations cost 3 / 5 / 6 instructions, so every voxel simply takes the exact path: no decision-boundary
-// tests, no fallback loops.  The U planes of a trip issue their volume vectors FIRST (their addresses need only the
-// queue entry), then the 4U depth gathers, so both round trips overlap the projection arithmetic.  Two wave-uniform
-// branches remain per plane: the general running mean (skipped when every rewritten voxel of the wave is free space
-// onto a stored +1 or an unseen voxel: saturating add on the packed word) and the store (skipped when nothing changed).
-// Domain of the shortcuts: hsk_rcp_exact needs a normal camz -- the specification itself asks for camz >= FLT_MIN
-// (deviation D6: a voxel whose camera-space depth is a denormal number counts as not in front of the camera); a huge
-// reciprocal makes the pixel coordinate overflow the image bounds, as the specification's 1e6 guard does.  The root
-// of a value below 2^-102 is inexact but finite and far below half an ulp of any non-zero depth, so sdf is unaffected;
-// the root of 0 (voxel centre ON the camera centre: NaN from the shortcut) belongs to a voxel with camz = 0.
+// Pass B, third form (round 6): A LANE IS ONE PLANE OF ONE LANE-BLOCK -- four voxels, one 16-B vector -- and the four lanes
+// of a quad are the four planes of one queue entry.  The second form gave a lane the whole lane-block: every load or store
+// instruction of a wave then touched 64 different 64-B blocks, 16 bytes of each, four instructions in a row going back to
+// the same 64 blocks -- "the memory side's acceptance rate for scattered 64-B blocks" was half of the kernel
+// (profiles/r04/integrate_notes.md), 93 vector registers held it at five waves per SIMD, and knocking the arithmetic out of
+// its light class bought nothing (profiles/r06/integrate_notes.md: the light entries cost what the per-voxel ones do).
+// Here an instruction of a wave covers 16 blocks WHOLE (a quad's four vectors are 64 contiguous bytes: one request where
+// there were four quarter requests), a trip is a quarter as long and there are four times as many, and the register count
+// falls to what eight waves per SIMD allow.  What the four planes of an entry share -- the x-y terms of the projection --
+// is computed by each of the four lanes (a dozen multiply-adds of ~200); what they must agree on -- the brick flag, the
+// light class's summary byte -- is settled by quad shuffles.  The arithmetic per voxel is the second form's, expression for
+// expression: the same bits.
 // ------------------------------------------------------------------------------------------------------
-#ifndef DETAIL2_U
-#define DETAIL2_U 4
+#ifndef DETAIL3_WPE
+#define DETAIL3_WPE 8
 #endif
-#ifndef DETAIL2_WPE
-#define DETAIL2_WPE 5
+#ifndef DETAIL3_GX
+#define DETAIL3_GX 8  // DETAIL3_GX x 256 blocks of 4 waves: one resident round of the chip at 8 waves per SIMD
 #endif
-#ifndef DETAIL2_GX
-#define DETAIL2_GX 5  // DETAIL2_GX x 256 queues x 4 waves: one resident round of the chip at 8 waves per SIMD
-#endif
-
-#ifdef HSK_PB_TIMING
-// timing build (tools/pb_timing.sh): per wave of pass B, s_memrealtime stamps: start, prologue done, after each trip (up to 4)
-__device__ unsigned long long g_pb_times[8192 * 8];
-extern "C" int hsk_debug_pb_times(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pb_times), (size_t)n * 8);
+static __device__ __forceinline__ unsigned quad_or(unsigned v) {
+  v |= (unsigned)__shfl_xor((int)v, 1, 64);
+  return v | (unsigned)__shfl_xor((int)v, 2, 64);
 }
-#define PB_STAMP(k) do { if (!COUNT_ONLY && lane == 0 && pb_wave < 8192u) g_pb_times[pb_wave * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PB_STAMP(k) do { } while (0)
-#endif
+static __device__ __forceinline__ unsigned quad_and(unsigned v) {
+  v &= (unsigned)__shfl_xor((int)v, 1, 64);
+  return v & (unsigned)__shfl_xor((int)v, 2, 64);
+}
+static __device__ __forceinline__ unsigned quad_min(unsigned v) {
+  v = min(v, (unsigned)__shfl_xor((int)v, 1, 64));
+  return min(v, (unsigned)__shfl_xor((int)v, 2, 64));
+}
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const TrackState* __restrict__ st,
-                                                                        const unsigned* __restrict__ qcount,
-                                                                        const unsigned* __restrict__ queue_all, unsigned qcap, int W,
-                                                                        int H, uint4* __restrict__ vol,
-                                                                        const float* __restrict__ scaled, Intr in, VolParams vp,
-                                                                        unsigned long long* __restrict__ counter,
+__global__ __launch_bounds__(256, DETAIL3_WPE) void k_integrate_detail3(const TrackState* __restrict__ st, const unsigned* __restrict__ qcount,
+                                                                        const unsigned* __restrict__ queue_all, unsigned qcap, int W, int H,
+                                                                        uint4* __restrict__ vol, const float* __restrict__ scaled, Intr in,
+                                                                        VolParams vp, unsigned long long* __restrict__ counter,
                                                                         unsigned* __restrict__ flags, unsigned long long qmag_x,
                                                                         unsigned long long qmag_y, unsigned char* __restrict__ uni) {
   if (!COUNT_ONLY && st->lost) return;
   const int lane = threadIdx.x & 63;
-#ifdef HSK_PB_TIMING
-  const unsigned pb_wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (!COUNT_ONLY && lane == 0 && pb_wave < 8192u)
-    for (int q = 0; q < 8; ++q) g_pb_times[pb_wave * 8 + q] = 0ull;
-  int pb_trip = 0;
-#endif
-  PB_STAMP(0);
-  // The HSK_NQUEUES queues are walked as ONE list (their lengths differ by 1.6x: a grid that strides over each queue
-  // by itself ends with the longest queue's last round, a third of the chip idle).  Every block scans the 256 counters
-  // once (LDS prefix array); an entry's queue is then found by bisection.
-  // (round 6: two lists -- the per-voxel entries at the heads of the queues, the light ones at their tails; counter words 0 / 1)
+  // the two lists (per-voxel entries at the heads of the queues, light ones at their tails): prefix sums of both counts
   __shared__ unsigned pre[HSK_NQUEUES + 1], pre2[HSK_NQUEUES + 1];
   {
     static_assert(HSK_NQUEUES == 256, "one counter per thread of the block");
     const uint2 c = *(const uint2*)&qcount[threadIdx.x * HSK_QCOUNT_STRIDE];
-    unsigned incl = c.x, incl2 = c.y;  // inclusive scans inside the wave, then across the four waves
+    unsigned incl = c.x, incl2 = c.y;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const unsigned v = (unsigned)__shfl_up((int)incl, o, 64), v2 = (unsigned)__shfl_up((int)incl2, o, 64);
@@ -1475,65 +1245,153 @@ __global__ __launch_bounds__(256, DETAIL2_WPE) void k_integrate_detail2(const Tr
     __syncthreads();
   }
   const unsigned n = pre[HSK_NQUEUES], n2 = pre2[HSK_NQUEUES];
-  const unsigned stride = gridDim.x * blockDim.x;
-  unsigned long long cnt = 0;
-  PB_STAMP(1);
+  const unsigned nwaves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned stride = nwaves * 16u;  // entries a round of the grid takes: 16 per wave
+  const unsigned cap = ((unsigned)HSK_MAX_WEIGHT << 16) | (unsigned)HSK_DIVISOR;
   const DetailPose P = detail_pose(st);
-  const int qx = vp.X / 4;
-  auto entry_at = [&](unsigned g) -> unsigned {  // g-th entry of the concatenated queues (0 beyond the end)
-    if (g >= n) return 0u;
-    unsigned lo = 0, hi = HSK_NQUEUES;  // pre[lo] <= g < pre[hi]
+  const int qx = vp.X / 4, u = lane & 3;
+  const int last = W * H - 1;
+  unsigned long long cnt = 0;
+  // g-th entry of a concatenated list (0 beyond its end): its queue by bisection over the prefix sums, heads count up, tails down
+  auto entry_at = [&](const unsigned* __restrict__ pr, unsigned total, bool tail, unsigned g) -> unsigned {
+    if (g >= total) return 0u;
+    unsigned lo = 0, hi = HSK_NQUEUES;  // pr[lo] <= g < pr[hi]
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const unsigned mid = (lo + hi) >> 1;
-      if (pre[mid] <= g) lo = mid; else hi = mid;
+      if (pr[mid] <= g) lo = mid; else hi = mid;
     }
-    return queue_all[(size_t)lo * qcap + (g - pre[lo])];
+    const unsigned r = g - pr[lo];
+    return queue_all[(size_t)lo * qcap + (tail ? (qcap - 1u) - r : r)];
   };
-  // the entry of the NEXT trip is fetched while the current one is worked on (its address needs nothing but the trip index)
-  unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
-  unsigned id_next = entry_at(e0 + lane);
-  for (; e0 < n; e0 += stride) {  // wave-uniform trip count
-    const unsigned id = id_next;
-    id_next = entry_at(e0 + stride + lane);
-    const unsigned lb = id & 0x0fffffffu;
-    // lb = ((zb / 4) * Y + y) * qx + x0 / 4, taken apart by multiplications (qmag = floor(2^40 / d) + 1: exact for every
-    // lb below 2^40 / d, i.e. for every volume the 28-bit ids admit; three integer divisions were ~75 instructions a trip)
+  // one trip: the lane's plane of its quad's entry.  LIGHT: the class of pass A's free blocks over holes (every plane in
+  // range, F = 1 wherever the pixel has depth, `code` = pending observations of a rim block to add first; the block's
+  // summary byte is rewritten from the new words); else the specification's per-voxel rule, `code` = the planes in range.
+  auto work = [&](bool have, unsigned id, bool LIGHT) {
+    const unsigned lb = id & 0x0fffffffu, code = id >> 28;
+    // lb = ((zb / 4) * Y + y) * qx + x0 / 4, taken apart by multiplications (qmag = floor(2^40 / d) + 1: exact for every id)
     const unsigned row = (unsigned)(((unsigned long long)lb * qmag_x) >> 40);
     const unsigned zq = (unsigned)(((unsigned long long)row * qmag_y) >> 40);
     const int x0 = (int)(lb - row * (unsigned)qx) * 4, y = (int)(row - zq * (unsigned)vp.Y);
     const int zb = (int)zq * 4;
-    cnt += detail_entry<COUNT_ONLY, DETAIL2_U>(id >> 28, x0, y, zb, vol, scaled, P, vp, W, H, in, flags);
-#ifdef HSK_PB_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (pb_trip < 5) PB_STAMP(2 + pb_trip);
-    ++pb_trip;
-#endif
-  }
-  // ---- the light list (round 6): the waves start on it where the per-voxel list left them; an entry is a lane-block id
-  if (n2 != 0u) {
-    auto light_at = [&](unsigned g) -> unsigned {
-      if (g >= n2) return 0xffffffffu;
-      unsigned lo = 0, hi = HSK_NQUEUES;  // pre2[lo] <= g < pre2[hi]
+    const bool inr = have && (LIGHT || ((code >> u) & 1u) != 0u);
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (!COUNT_ONLY && inr) q = vol[VIDX(zb, u)];
+    unsigned flag_word = 0u;
+    const int fbit = ((zb >> vp.bshift) * (vp.Y >> vp.bshift) + (y >> vp.bshift)) * (vp.X >> vp.bshift) + (x0 >> vp.bshift);
+    if (!COUNT_ONLY && !LIGHT && inr) flag_word = flags[fbit >> 5];
+    const float gy = ((float)y + 0.5f) * vp.cell[1] - P.ty;
+    const float gz = ((float)(vp.zs0 + zb + u) + 0.5f) * vp.cell[2] - P.tz;
+    const float bx = P.i02 * gz, by = P.i12 * gz, bz = P.i22 * gz;
+    const float gz2 = gz * gz;
+    int pix[4];
+    float pn[4];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (pre2[mid] <= g) lo = mid; else hi = mid;
+    for (int j = 0; j < 4; ++j) {
+      const float gx = ((float)(x0 + j) + 0.5f) * vp.cell[0] - P.tx;
+      const float axj = P.i00 * gx + P.i01 * gy, ayj = P.i10 * gx + P.i11 * gy, azj = P.i20 * gx + P.i21 * gy;
+      pn[j] = gx * gx + gy * gy;
+      const float camz = azj + bz;
+      const float inv_z = hsk_rcp_exact(camz);
+      const float fu = ((axj + bx) * in.fx) * inv_z + in.cx;
+      const float fv = ((ayj + by) * in.fy) * inv_z + in.cy;
+      const int uu = (int)rintf(fu), vv = (int)rintf(fv);
+      // (the light class has every pixel inside the image and in front of the camera by its classification: the clamp only
+      // guards the address)
+      const bool ok = LIGHT ? true : (inr && camz >= 1.17549435e-38f && (unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H);
+      pix[j] = ok ? min(max(vv * W + uu, 0), last) : -1;
+    }
+    float D[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) D[j] = scaled[max(pix[j], 0)];
+    // the observation: F in [-1, 1] for a voxel the rule rewrites, -4 for one it leaves alone
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float Ds = pix[j] >= 0 ? D[j] : 0.0f;
+      if (LIGHT) {
+        D[j] = (inr && Ds != 0.0f) ? 1.0f : -4.0f;
+      } else {
+        const float sdf = Ds - hsk_sqrt_exact(gz2 + pn[j]);
+        const float f = sdf * vp.tau_inv;
+        D[j] = (Ds != 0.0f && sdf >= -vp.tau) ? (f < 1.0f ? f : 1.0f) : -4.0f;
       }
-      return queue_all[(size_t)lo * qcap + (qcap - 1u) - (g - pre2[lo])];
-    };
-    // (the waves that came last out of the list above go first into this one: the grid is walked from its other end)
-    unsigned g0 = (gridDim.x - 1u - blockIdx.x) * blockDim.x + (threadIdx.x & ~63u);
-    unsigned lid_next = light_at(g0 + lane);
+    }
+    if (COUNT_ONLY) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cnt += D[j] > -2.0f ? 1u : 0u;
+      return;
+    }
+    // running mean, repack, store
+    uint4 q1 = q;
+    if (LIGHT && code != 0u) hsk_vector_add_weight(q1, code);  // (a rim block's pending observations: all 16 voxels hold +1 with a weight)
+    const unsigned w4[4] = {q1.x, q1.y, q1.z, q1.w};
+    unsigned nw[4];
+    bool gen[4], gen_any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool upd = D[j] > -2.0f;
+      const bool unseen = (w4[j] >> 16) == 0u;
+      // free space (F == 1) onto a stored +1, or onto an unseen voxel: the mean is +1 exactly, only the weight moves
+      const bool simple = D[j] == 1.0f && (unseen || (w4[j] & 0xffffu) == (unsigned)HSK_DIVISOR);
+      const unsigned ws = unseen ? (0x10000u | (unsigned)HSK_DIVISOR) : min(w4[j] + 0x10000u, cap);
+      nw[j] = (upd && simple) ? ws : w4[j];
+      gen[j] = upd && !simple;
+      gen_any = gen_any || gen[j];
+    }
+    bool neg = false;
+    if (__ballot(gen_any) != 0ull) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tp = (int)(short)(w4[j] & 0xffffu);
+        const unsigned wp = w4[j] >> 16;
+        const float Wp = (float)wp;
+        const float Fn = hsk_div_small_exact(hsk_tsdf_unpack(tp) * Wp + D[j], Wp + 1.0f);
+        int fixed = (int)(Fn * 32767.0f);  // truncation toward zero
+        fixed = min(max(fixed, -HSK_DIVISOR), HSK_DIVISOR);
+        const unsigned wg = ((unsigned)fixed & 0xffffu) | (min(wp + 1u, (unsigned)HSK_MAX_WEIGHT) << 16);
+        nw[j] = gen[j] ? wg : nw[j];
+        neg = neg || (gen[j] && fixed < 0);
+      }
+    }
+    // (saturated free space -- +1 at the weight cap -- comes back unchanged: no store)
+    if (inr && (nw[0] != q.x || nw[1] != q.y || nw[2] != q.z || nw[3] != q.w)) vol[VIDX(zb, u)] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+    if (!LIGHT) {
+      // the brick of the lane-block (its 4 planes lie in one brick): one lane of the quad marks it when any plane went negative
+      const unsigned negq = quad_or(neg ? 1u : 0u), fw = quad_or(flag_word);
+      if (negq != 0u && u == 0 && ((fw >> (fbit & 31)) & 1u) == 0u) mark_brick_negative(flags, vp, x0, y, zb);
+    } else if (uni != nullptr) {
+      // the block's state from its 16 new words (hsk_sum_classify across the quad): all equal -> the uniform code; all +1 with
+      // a weight -> a rim block without pending observations; else nothing is known (pass A left the byte at 0)
+      const unsigned word = nw[0];
+      const unsigned same = (nw[1] == word && nw[2] == word && nw[3] == word) ? 1u : 0u;
+      const unsigned w_first = (unsigned)__shfl((int)word, lane & ~3, 64);
+      const unsigned all_same = quad_and((same != 0u && word == w_first) ? 1u : 0u);
+      const unsigned a = quad_and(nw[0] & nw[1] & nw[2] & nw[3]), o = quad_or(nw[0] | nw[1] | nw[2] | nw[3]);
+      const unsigned m = quad_min(min(min(nw[0], nw[1]), min(nw[2], nw[3])));
+      const unsigned ragged = ((a & 0x7fffu) == 0x7fffu && (o & 0x8000u) == 0u && m >= 0x10000u && (o >> 16) <= (unsigned)HSK_MAX_WEIGHT) ? HSK_SUM_RAGGED : 0u;
+      const unsigned state = all_same != 0u ? hsk_uniform_code(w_first) : ragged;
+      if (have && u == 0 && state != 0u) uni[hsk_sum_index(vp, x0, y, zb)] = (unsigned char)state;
+    }
+  };
+  // ---- the per-voxel list: wave w takes entries 16 w .. 16 w + 15 of every round; the next trip's entry is fetched under
+  // the current one (its address needs nothing but the trip index)
+  {
+    unsigned e0 = wave * 16u;
+    unsigned id_next = entry_at(pre, n, false, e0 + (unsigned)(lane >> 2));
+    for (; e0 < n; e0 += stride) {  // wave-uniform trip count
+      const unsigned id = id_next;
+      id_next = entry_at(pre, n, false, e0 + stride + (unsigned)(lane >> 2));
+      work(e0 + (unsigned)(lane >> 2) < n, id, false);
+    }
+  }
+  // ---- the light list: the waves that came last out of the list above go first into this one
+  if (n2 != 0u) {
+    unsigned g0 = (nwaves - 1u - wave) * 16u;
+    unsigned id_next = entry_at(pre2, n2, true, g0 + (unsigned)(lane >> 2));
     for (; g0 < n2; g0 += stride) {
-      const unsigned lid = lid_next;
-      lid_next = light_at(g0 + stride + lane);
-      const bool have = lid != 0xffffffffu;
-      const unsigned lb = have ? lid : 0u;
-      const unsigned row = (unsigned)(((unsigned long long)lb * qmag_x) >> 40);
-      const unsigned zq = (unsigned)(((unsigned long long)row * qmag_y) >> 40);
-      const int x0 = (int)(lb - row * (unsigned)qx) * 4, y = (int)(row - zq * (unsigned)vp.Y);
-      cnt += light_entry<COUNT_ONLY>(have, x0, y, (int)zq * 4, vol, scaled, P, vp, W, H, in, uni);
+      const unsigned id = id_next;
+      id_next = entry_at(pre2, n2, true, g0 + stride + (unsigned)(lane >> 2));
+      work(g0 + (unsigned)(lane >> 2) < n2, id, true);
     }
   }
   if (COUNT_ONLY) {
@@ -1640,7 +1498,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
   const unsigned gmagic = grid.x > 1u ? (unsigned)(0x100000000ull / grid.x) + 1u : 0u;
   // (pass B takes a queued lane-block id apart by multiplications: floor(2^40 / d) + 1 for d = X / 4 and d = Y)
   const unsigned long long qmag_x = (1ull << 40) / (unsigned long long)(vp.X / 4) + 1ull, qmag_y = (1ull << 40) / (unsigned long long)vp.Y + 1ull;
-  const dim3 detail_grid(DETAIL2_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
+  const dim3 detail_grid(DETAIL3_GX * HSK_NQUEUES);  // one resident round of the chip, striding over the concatenated queues
   if (count_only) {
     if (vp.zchunk == 16)
       hipLaunchKernelGGL((k_integrate<true, 4>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
@@ -1648,7 +1506,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
     else
       hipLaunchKernelGGL((k_integrate<true, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, (double*)nullptr, (unsigned char*)nullptr, dil,
                          W, H, tw, th, grid.y, (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
-    hipLaunchKernelGGL(k_integrate_detail2<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
+    hipLaunchKernelGGL(k_integrate_detail3<true>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags, qmag_x, qmag_y, (unsigned char*)nullptr);
   } else {
     if (vp.zchunk == 16)
@@ -1657,7 +1515,7 @@ void launch_integrate(hipStream_t s, void* vol, const float* scaled, const Track
     else
       hipLaunchKernelGGL((k_integrate<false, 2>), grid, block, 0, s, st, (const unsigned*)cflag, wvz, zchunk, grid.x, gmagic, fin.slots, uni, dil, W, H, tw, th, grid.y,
                          (uint4*)vol, scaled, vp, in, counter, flags, qdata, qcount, qcap, ftab, fw, fh, qtab, kc, (const int2*)zint, vmask, hsk_mask_pitch32(W));
-    hipLaunchKernelGGL(k_integrate_detail2<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
+    hipLaunchKernelGGL(k_integrate_detail3<false>, detail_grid, dim3(256), 0, s, st, qcount, qdata, qcap, W, H, (uint4*)vol, scaled, in, vp,
                        counter, flags, qmag_x, qmag_y, uni);
   }
 }

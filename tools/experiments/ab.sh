@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/ab.sh "<extra hipcc defines>" tag   -- rebuild the kernels with defines and run a short bench (GPU box)
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/ab.sh "<extra hipcc defines>" tag   -- rebuild the kernels with defines and run a short bench (GPU box)
 cd ${GRAFT_REPO_ROOT:-.}
 touch housescan_amd/csrc/integrate.hip housescan_amd/csrc/raycast.hip housescan_amd/csrc/extract.hip housescan_amd/csrc/kernels_image.hip
 make -s -C housescan_amd/csrc FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-function -Wno-bitwise-instead-of-logical $1" 2>&1 | grep -E "error"

@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/ab1024.sh "<defines>" ... -- rebuild with each define set, bench 512^3 and 1024^3 (GPU box)
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/ab1024.sh "<defines>" ... -- rebuild with each define set, bench 512^3 and 1024^3 (GPU box)
 cd ${GRAFT_REPO_ROOT:-.}
 for v in "$@"; do
   touch housescan_amd/csrc/integrate.hip housescan_amd/csrc/raycast.hip housescan_amd/csrc/extract.hip housescan_amd/csrc/kernels_image.hip

@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/ab_files.sh REPS lib_a.so lib_b.so ...  -- like ab_repeat.sh for libraries built beforehand (e.g. one from
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/ab_files.sh REPS lib_a.so lib_b.so ...  -- like ab_repeat.sh for libraries built beforehand (e.g. one from
 # another commit), benched REPS times in turn
 cd ${GRAFT_REPO_ROOT:-.}
 reps=$1; shift

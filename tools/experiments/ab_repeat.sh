@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/ab_repeat.sh REPS "<defines A>" "<defines B>" ...  -- each variant built once, benched REPS times in turn
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/ab_repeat.sh REPS "<defines A>" "<defines B>" ...  -- each variant built once, benched REPS times in turn
 # (no profiler attached: the stage times come from the library's own HIP events), variants interleaved so that box
 # drift hits them alike
 cd ${GRAFT_REPO_ROOT:-.}

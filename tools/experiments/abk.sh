@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/abk.sh tag "<defines A>" "<defines B>" ... [-- bench args]
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/abk.sh tag "<defines A>" "<defines B>" ... [-- bench args]
 # For each set of -D switches: rebuild the kernels on the GPU box, run a short bench under rocprofv3 --kernel-trace
 # and print the frame rate, the stage times and the integrate kernels' average durations.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

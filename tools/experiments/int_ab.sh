@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/int_ab.sh tag "<defines A>" "<defines B>" ...   (env VOL=512|1024)
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/int_ab.sh tag "<defines A>" "<defines B>" ...   (env VOL=512|1024)
 # integrate-only A/B: rebuild with each set of -D switches, run tools/int_bench.py under rocprofv3, print kernel averages
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT

@@ -1,6 +1,6 @@
 #!/bin/bash
-source "$(dirname "$0")/restore_default.sh"
-# usage: tools/rooms_ab.sh REPS "<defines A>" "<defines B>" ... -- as ab_repeat.sh, for the concurrent-room figures (2 and 4 rooms on one GPU)
+source "$(dirname "$0")/../restore_default.sh"
+# usage: tools/experiments/rooms_ab.sh REPS "<defines A>" "<defines B>" ... -- as ab_repeat.sh, for the concurrent-room figures (2 and 4 rooms on one GPU)
 cd ${GRAFT_REPO_ROOT:-.}
 reps=$1; shift
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical"

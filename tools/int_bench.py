@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Integrate-only bench on a fixed stream: hsk_integrate with the ground-truth poses of the synthetic stream (no
 tracking, so timing experiments that give wrong voxels cannot derail it).  Run under rocprofv3 --kernel-trace --stats
-(tools/int_ab.sh) and read the integrate kernels' average durations.  usage: int_bench.py [volume] [first] [count]"""
+(tools/experiments/int_ab.sh) and read the integrate kernels' average durations.  usage: int_bench.py [volume] [first] [count]"""
 import os
 import sys
 
