@@ -93,6 +93,7 @@ SYMBOLS = {
     "hsk_set_profiling": (C.c_int, [_P, C.c_int]),
     "hsk_stage_ms": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
     "hsk_icp_level_ms": (C.c_int, [_P, _D]),
+    "hsk_submit_host_us": (C.c_int, [_P, _D, C.POINTER(C.c_uint64), C.c_int]),
     "hsk_integrate_queue_entries": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hsk_integrate_light_entries": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "hsk_integrate_coarse_counts": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -122,6 +122,10 @@ struct hsk_ctx {
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   bool graph_ready = false;
+  // use_graph = 2: the main-stream chain of a PIPELINED frame (19 ICP launches + 3 integrate + raycast) as one graph per
+  // image-buffer set -- the host's cost of a frame is then one launch where it was 23 (what limits several rooms on one GPU)
+  hipGraph_t pgraph[2] = {};
+  hipGraphExec_t pgexec[2] = {};
   // profiling
   bool prof = false;
   bool prof_levels = false;  // profiling level 2: also an event at every ICP level (they cost about 4 us each)
@@ -129,6 +133,10 @@ struct hsk_ctx {
   hipEvent_t ev_icp[HSK_NLEVELS + 1] = {};  // profiling: start of each ICP level (coarsest first) and the end of the last
   double icp_level_ms[HSK_NLEVELS] = {};    // ... summed per level, index = level (0 = finest)
   double stage_ms[HSK_NSTAGES] = {};
+  // host time of the pipelined submissions, by phase (hsk_submit_host_us): staging copy, copy + preprocessing enqueue, the
+  // wait for the preprocessing, the main-stream chain's enqueue; and the submissions counted
+  double submit_us[4] = {};
+  unsigned long long submit_n = 0;
   uint64_t prof_frames = 0;
 };
 
@@ -214,6 +222,10 @@ static void free_all(hsk_ctx* k) {
   (void)hipSetDevice(k->cfg.device_id);
   if (k->gexec) (void)hipGraphExecDestroy(k->gexec);
   if (k->graph) (void)hipGraphDestroy(k->graph);
+  for (auto& g : k->pgexec)
+    if (g) (void)hipGraphExecDestroy(g);
+  for (auto& g : k->pgraph)
+    if (g) (void)hipGraphDestroy(g);
   for (auto& g : k->sgexec)
     if (g) (void)hipGraphExecDestroy(g);
   for (auto& g : k->sgraph)
@@ -633,7 +645,7 @@ static int frame_common(hsk_ctx* k, float pose_out[16], int* tracked) {
     }
   } else if (k->prof) {
     enqueue_tracked_frame(k, true);
-  } else if (k->cfg.use_graph) {
+  } else if (k->cfg.use_graph == 1) {
     if (!k->graph_ready) {
       HIPCHK(k, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       enqueue_tracked_frame(k, false);
@@ -702,7 +714,7 @@ static int stage_depth_host(hsk_ctx* k, const uint16_t* depth) {
 // frame than a hipGraph launch followed by a copy and a stream synchronisation (2206 -> 2450 frames/s).  use_graph = 1
 // keeps that older form; the first frame of a scan, the gated and the profiled modes always take frame_common.
 static bool sync_via_ring(const hsk_ctx* k) {
-  return !k->cfg.use_graph && k->frame > 0 && !k->pending_reset && !(k->cfg.integrate_move_thresh > 0.0f) && !k->prof;
+  return k->cfg.use_graph != 1 && k->frame > 0 && !k->pending_reset && !(k->cfg.integrate_move_thresh > 0.0f) && !k->prof;
 }
 static int submit_frame(hsk_ctx* k, const void* src, hipMemcpyKind kind, int w, int h);
 
@@ -805,7 +817,9 @@ extern "C" int hsk_submit_frame(hsk_ctx* k, const uint16_t* depth, int w, int h)
   const size_t px = (size_t)w * h;
   uint16_t* stage = k->h_stage + (size_t)(k->stage_turn % (HSK_MAX_IN_FLIGHT + 1)) * px;
   k->stage_turn += 1;
+  const auto t0 = std::chrono::steady_clock::now();
   memcpy(stage, depth, px * 2);
+  k->submit_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return submit_frame(k, stage, hipMemcpyHostToDevice, w, h);
 }
 
@@ -867,21 +881,48 @@ static int submit_frame(hsk_ctx* k, const void* depth_dev, hipMemcpyKind kind, i
     e = hipEventRecord(k->ev_src, k->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(k->pstream, k->ev_src, 0);
   }
+  const auto tp0 = std::chrono::steady_clock::now();
   if (e == hipSuccess) e = hipMemcpyAsync(k->B().d_raw, depth_dev, (size_t)w * h * 2, kind, k->pstream);
   if (e == hipSuccess) {
     enqueue_preprocess(k, k->pstream);
     e = hipEventRecord(k->ev_pre[set], k->pstream);
   }
+  const auto tp1 = std::chrono::steady_clock::now();
   // The frame's own work needs the preprocessing.  A hipStreamWaitEvent on the main stream would be the obvious form,
   // but a cross-stream wait costs ~19 us of stalled queue at every frame boundary even when the event fired long ago
   // (2330 -> 2440 frames/s without it).  The host waits instead: it is a frame ahead of the GPU, the preprocessing takes
   // ~60 us, and kernels enqueued after the host has seen it complete need no device-side dependency.
   if (e == hipSuccess) e = hipEventSynchronize(k->ev_pre[set]);
+  const auto tp2 = std::chrono::steady_clock::now();
   if (e == hipSuccess) {
     // Eager launches, on purpose: the host runs a frame ahead here, so their launch cost is hidden, while replaying
     // the frame from a hipGraph left ~8 us more idle GPU between consecutive frames (2330 vs 2285 frames/s measured).
     // The graph stays on the synchronous path, where the launch cost is exposed.
-    enqueue_tracked_rest(k);
+    if (k->cfg.use_graph == 2 && k->own_stream) {
+      // (the chain's arguments depend on the buffer set only: the kernels read the pose from the tracker state, the ICP's
+      // iteration index restarts with every frame, the ring slot comes through the pinned fifo)
+      if (!k->pgexec[set]) {
+        e = hipStreamBeginCapture(k->stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+          enqueue_tracked_rest(k);
+          e = hipStreamEndCapture(k->stream, &k->pgraph[set]);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&k->pgexec[set], k->pgraph[set], nullptr, nullptr, 0);
+      } else {
+        k->weights_pending = true;  // (what enqueue_integrate notes on the host side)
+        k->vol_epoch += 1;
+      }
+      if (e == hipSuccess) e = hipGraphLaunch(k->pgexec[set], k->stream);
+    } else {
+      enqueue_tracked_rest(k);
+    }
+  }
+  {
+    const auto tp3 = std::chrono::steady_clock::now();
+    k->submit_us[1] += std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+    k->submit_us[2] += std::chrono::duration<double, std::micro>(tp2 - tp1).count();
+    k->submit_us[3] += std::chrono::duration<double, std::micro>(tp3 - tp2).count();
+    k->submit_n += 1;
   }
   k->set_used[set] = true;
   k->cur = 0;
@@ -1563,6 +1604,18 @@ extern "C" int hsk_integrate_coarse_counts(hsk_ctx* k, uint64_t counts[4]) {
   }
   free(h);
   HIPCHK(k, e);
+  return HSK_OK;
+}
+// host microseconds the pipelined submissions have spent, by phase, and how many there were (reset != 0: counted from now on)
+extern "C" int hsk_submit_host_us(hsk_ctx* k, double sum_us[4], uint64_t* n_submissions, int reset) {
+  if (!k) return HSK_ERR_ARG;
+  if (sum_us)
+    for (int i = 0; i < 4; ++i) sum_us[i] = k->submit_us[i];
+  if (n_submissions) *n_submissions = k->submit_n;
+  if (reset) {
+    for (auto& v : k->submit_us) v = 0.0;
+    k->submit_n = 0;
+  }
   return HSK_OK;
 }
 extern "C" int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]) {

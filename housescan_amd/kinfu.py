@@ -151,6 +151,14 @@ class KinfuTracker:
         self._ck(self.lib.hsk_integrate_queue_entries(self.h, C.byref(n)))
         return n.value
 
+    def submit_host_us(self, reset=False):
+        """host microseconds the pipelined submissions have spent by phase (staging copy, upload + preprocessing enqueue, wait
+        for the preprocessing, main chain enqueue) and their count"""
+        us = (C.c_double * 4)()
+        n = C.c_uint64()
+        self._ck(self.lib.hsk_submit_host_us(self.h, us, C.byref(n), int(reset)))
+        return list(us), n.value
+
     def integrate_light_entries(self):
         """lane-blocks of the last integrate's light class (free space with holes in the depth image under it)"""
         n = C.c_uint64()

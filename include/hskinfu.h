@@ -57,7 +57,9 @@ typedef struct {
   /* z-slab sharding (multi-GPU): this context stores planes [own_z0 - halo, own_z1 + halo) clipped to the
    * volume and OWNS raycast steps whose far sample lies in [own_z0, own_z1).  Single device: 0, vol_z, 0. */
   int own_z0, own_z1, halo;
-  int use_graph;                /* 1 = replay synchronous frames from one hipGraph; 0 (default) = eager  */
+  int use_graph;                /* 1 = replay synchronous frames from one hipGraph; 0 (default) = eager;
+                                   2 = the main-stream chain of PIPELINED frames (hsk_submit_frame*) from one hipGraph per
+                                   image-buffer set: 23 launches become one -- for hosts that scan several rooms at once */
 } hsk_config;
 
 /* identity of the sources this library was built from (first 16 hex digits of their sha256; "+exp" appended when it
@@ -253,6 +255,10 @@ int hsk_stage_ms(hsk_ctx* k, double sum_ms[HSK_NSTAGES], uint64_t* n_frames, int
 int hsk_icp_level_ms(hsk_ctx* k, double sum_ms[HSK_LEVELS]);
 /* lane-blocks (4 x 1 x 4 voxels) the last integrate's classification pass could not settle and handed to its per-voxel
  * pass (a measure of the classification's slack: bench.py reports it beside V_upd); synchronises the context's stream */
+/* host microseconds the pipelined submissions (hsk_submit_frame[_dev]) have spent so far, by phase: [0] the copy of a host frame
+   into the pinned staging ring, [1] enqueueing the upload and the preprocessing on the second stream, [2] waiting for that
+   preprocessing, [3] enqueueing the frame's main-stream chain; n_submissions: how many.  reset != 0: counted afresh from now. */
+int hsk_submit_host_us(hsk_ctx* k, double sum_us[4], uint64_t* n_submissions, int reset);
 int hsk_integrate_queue_entries(hsk_ctx* k, uint64_t* n_entries);
 /* ... and the lane-blocks of the last integrate's LIGHT class: free space with holes in the depth image under it (each voxel is
    rewritten with F = 1 or left alone according to whether its pixel has depth); not counted by hsk_integrate_queue_entries */
