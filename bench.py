@@ -194,7 +194,7 @@ def issue_util_block(volume, total, window_first, stream="scripted"):
         return {"note": why}
     out = {"note": "SQ_INSTS_VALU x 2 / (1024 SIMDs x cycles), SQ_INSTS_SALU / (256 x cycles), cycles = mean kernel duration x 2.4 GHz; "
                    "chip-wide averages over the launch: the CUs inside the frustum are busier than that"}
-    for label, prefix in (("pass_a", "void k_integrate<false"), ("pass_b", "void k_integrate_detail2<false"), ("k_column_zrange", "k_column_zrange")):
+    for label, prefix in (("pass_a", "void k_integrate<false"), ("pass_b", "void k_integrate_detail3<false"), ("k_column_zrange", "k_column_zrange")):
         pn = [k for k in per if k.startswith(prefix)]
         dn = [k for k in dur if k.startswith(prefix)]
         if not pn or not dn:
@@ -207,7 +207,7 @@ def issue_util_block(volume, total, window_first, stream="scripted"):
     return out
 
 
-INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false", "void k_integrate_detail2<false")   # (name prefixes: pass A is k_integrate<false, 2 | 4>)
+INTEGRATE_KERNELS = ("k_column_zrange", "void k_integrate<false", "void k_integrate_detail3<false")   # (name prefixes: pass A is k_integrate<false, 2 | 4>)
 
 
 def pmc_traffic(volume, total, window_first, timeout_s=240, with_raycast=True, stream="scripted"):
@@ -285,6 +285,14 @@ def readout_block(trk, n, with_download=True):
                 first[name] = ms
             else:
                 out[name], out[key] = ms, cnt
+    # (the tetrahedra form against the cubes form.  It emits four times the triangles, so its floor is its
+    # OUTPUT: 36 B per triangle through PCIe into pageable host memory -- what the two figures below say.  The .ply path of
+    # upstream's export, and of tools/stitch_rooms_demo.py, is the cubes form; the tetrahedra form is the watertight variant.)
+    for name, key in (("extract_mesh_ms", "mesh_triangles"), ("extract_mesh_cubes_ms", "mesh_cubes_triangles")):
+        if out.get(name):
+            out[name.replace("_ms", "_output_GBps")] = round(out[key] * 36 / (out[name] * 1e-3) / 1e9, 1)
+    out["mesh_note"] = ("hsk_extract_mesh_cubes (marching cubes) is the .ply path; hsk_extract_mesh (marching tetrahedra) emits ~4x the triangles and is "
+                        "bound by its output through PCIe (extract_mesh_output_GBps against download_GBps_pageable_host)")
     out["first_call_ms"] = first
     out["prepare_readout_ms"] = prepare_ms
     out["first_call_note"] = ("first_call_ms follows hsk_prepare_readout (prepare_readout_ms, once per context, from the worker thread that created "
@@ -303,45 +311,42 @@ def readout_block(trk, n, with_download=True):
     return out
 
 
-def concurrent_rooms(hsk, n, dev_frames, local_rank, counts=(2, 4)):
-    """M independent rooms on ONE GPU at once (M contexts in this process, a host thread and a stream pair each; BASELINE
-    configs[4] scans four 512^3 rooms concurrently): one room's frame is a chain of dependent stages that leaves most of the
-    chip idle for half of its time (19 ICP iterations at one wave per SIMD), so rooms interleave -- frames/s in all"""
-    import threading
-    total = len(dev_frames)
+def concurrent_rooms(n, local_rank, counts=(1, 2, 4), frames=126):
+    """M independent rooms on ONE GPU at once (BASELINE configs[4] scans four 512^3 rooms concurrently), driven from C THREADS
+    in a process without Python: tools/rooms_native.c is compiled and run as a child process per M --
+    a POSIX thread and an hsk_ctx per room, 120 timed frames each through hsk_submit_frame / hsk_wait_frame (host pointers,
+    one frame ahead), on the room scan (camera inside, the rooms of synth.cpp) and on the open scene of 8(d).  (Rounds 4-5 drove
+    the rooms from Python threads of THIS process for 20 frames: that measured the interpreter and whatever streams torch
+    holds -- a process's streams share four hardware queues -- as much as the library.)"""
+    exe_dir = tempfile.mkdtemp(prefix="hsk_rooms_")
+    exe = os.path.join(exe_dir, "rooms_native")
+    lib_dir = os.path.join(ROOT, "housescan_amd")
     out = {}
-    for M in counts:
-        trks = [hsk.KinfuTracker(n=n, device_id=local_rank) for _ in range(M)]
-        lost = [0] * M
-        for t in trks:
-            for k in range(min(6, total - 2)):
-                t.process_frame_dev(dev_frames[k].data_ptr())
-        first = min(6, total - 2)
-        gate = threading.Barrier(M + 1)
-
-        def run(i):
-            t = trks[i]
-            gate.wait()
-            t.submit_frame_dev(dev_frames[first].data_ptr())
-            for k in range(first + 1, total):
-                t.submit_frame_dev(dev_frames[k].data_ptr())
-                lost[i] += not t.wait_frame()[1]
-            lost[i] += not t.wait_frame()[1]
-            t.synchronize()   # (the last wait returns with the pose: that frame's integrate and raycast are part of the work timed)
-
-        threads = [threading.Thread(target=run, args=(i,)) for i in range(M)]
-        for th in threads:
-            th.start()
-        gate.wait()
-        t0 = time.perf_counter()
-        for th in threads:
-            th.join()
-        dt = time.perf_counter() - t0
-        for t in trks:
-            t.close()
-        out["%d_rooms" % M] = {"frames_per_s_in_all": round(M * (total - first) / dt, 1), "per_room": round((total - first) / dt, 1), "lost_frames": int(sum(lost))}
-    out["note"] = ("M independent %d^3 rooms scanned at once on ONE GPU (contexts of one process, a host thread each, %d pipelined frames per room): "
-                   "the stages of different rooms overlap, those of one room cannot" % (n, total - first))
+    try:
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "rooms_native.c"),
+                               "-L" + lib_dir, "-lhskinfu", "-ldl", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        env = dict(os.environ)
+        if local_rank:
+            env["HIP_VISIBLE_DEVICES"] = str(local_rank)
+        for stream in ("room", "open"):
+            blk = {}
+            for M in counts:
+                r = subprocess.run([exe, str(M), str(n), str(frames), stream, "1", "host", "0"], env=env, capture_output=True, text=True, timeout=300)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not line:
+                    blk["%d_rooms" % M] = {"failed": (r.stderr or r.stdout)[-300:]}
+                    continue
+                j = json.loads(line[0])
+                blk["%d_rooms" % M] = {k: j[k] for k in ("frames_per_s_in_all", "per_room", "lost_frames", "host_us_per_frame_in_submit", "host_us_per_frame_in_wait")}
+            out["room_scan_camera_inside" if stream == "room" else "open_scene_8d"] = blk
+    except (OSError, subprocess.SubprocessError) as e:
+        out["failed"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(exe_dir, ignore_errors=True)
+    out["note"] = ("M independent %d^3 rooms at once on ONE GPU, tools/rooms_native.c (C threads, no Python in the process, %d timed frames per room, "
+                   "host pointers): the stages of different rooms overlap, those of one room cannot; what limits four rooms is the chip, not the host "
+                   "(profiles/r06/rooms_notes.md: one hipGraph per frame, more hardware queues, CU partitions and a process per room all measured)" % (n, frames - 6))
     return out
 
 
@@ -404,10 +409,24 @@ def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, s
         first, submit = (lambda i: trk.process_frame(host_frames[i])), (lambda i: trk.submit_frame(host_frames[i]))
     else:
         first, submit = (lambda i: trk.process_frame_dev(dev_frames[i].data_ptr())), (lambda i: trk.submit_frame_dev(dev_frames[i].data_ptr()))
-    for i in range(1 + Wm):
-        first(i)
+    # warm-up THROUGH THE API THAT IS TIMED: frame 0 (the scan's first frame is always synchronous), then the Wm warm-up frames
+    # by the synchronous call, or pipelined like the timed ones (one frame ahead, all collected before the clock starts)
+    first(0)
+    if sync_api or Wm < 2:
+        for i in range(1, 1 + Wm):
+            first(i)
+    else:
+        submit(1)
+        for i in range(2, 1 + Wm):
+            submit(i)
+            trk.wait_frame()
+        trk.wait_frame()
+    trk.synchronize()
     torch.cuda.synchronize()
     stamps = []
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()   # (the interpreter's collector out of the timed region: a generation-2 pass over this process's heap is milliseconds)
     t0 = time.perf_counter()
     if sync_api:
         for i in range(1 + Wm, total):
@@ -429,6 +448,8 @@ def timed_single(hsk, torch, n, K, Wm, ahead, dev_frames, local_rank, graph=0, s
             stamps.append(time.perf_counter())
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     per = np.diff(np.array([t0] + stamps)) * 1e3
     return trk, pose, lost, elapsed, per
 
@@ -487,7 +508,7 @@ def roofline_block(n, ms, nf, v_mean, traffic, traffic_info):
     touched_mib = alg_bytes / 2 / (1 << 20)  # the voxels a frame rewrites, 4 B each
     block = {
         "bound": "hbm",
-        "kernel": "integrate stage: k_column_zrange + k_integrate<false> (pass A) + k_integrate_detail2<false> (pass B), one event pair",
+        "kernel": "integrate stage: k_column_zrange + k_integrate<false> (pass A) + k_integrate_detail3<false> (pass B), one event pair",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic, "hbm_GBps": None if traffic is None else round(traffic / t_int / 1e9, 1),
         "hbm_frac": None if traffic is None else round(traffic / t_int / 1e9 / HBM_PEAK_GBS, 4),
@@ -641,7 +662,12 @@ def run_single(args, hsk, torch, local_rank):
     iters = [10, 5, 4]
     out["icp_us_per_iter"] = {"fine_640x480": round(icp_ms[0] / nf / iters[0] * 1e3, 2), "mid_320x240": round(icp_ms[1] / nf / iters[1] * 1e3, 2),
                               "coarse_160x120": round(icp_ms[2] / nf / iters[2] * 1e3, 2),
-                              "note": "latency-bound (19 dependent launches): microseconds per iteration, not a roofline fraction"}
+                              "note": "latency-bound (19 dependent launches): microseconds per iteration, not a roofline fraction.  AT THE FLOOR OF ONE "
+                                      "LAUNCH PER ITERATION (round 6, closed): of a fine iteration's 6.6 us, 1.25 are the boundary between two dependent "
+                                      "launches, and tools/probes/launch_gap_probe.hip finds that boundary the same whether the 19 launches are eager or ONE "
+                                      "hipGraph and whether the accumulators live in coarse-grained, fine-grained or uncached memory (profiles/r06/icp_notes.md); "
+                                      "forms with fewer boundaries (XCD-local or chip-wide barriers inside a launch, the coarse level fused) were priced in "
+                                      "rounds 4-5 and lose"}
     t_ray = ms[3] / nf * 1e-3
     out["raycast"] = {"rays_per_s": round(W * H / t_ray, 0), "us": round(t_ray * 1e6, 1)}
     if ray_pmc is not None:
@@ -669,7 +695,7 @@ def run_single(args, hsk, torch, local_rank):
         out["holes_%d" % n] = stream_block(args, hsk, torch, n, local_rank, out["value"], "holes")
         out["noise_%d" % n] = stream_block(args, hsk, torch, n, local_rank, out["value"], "noise")
     if not args.no_rooms and n <= 512:
-        out["concurrent_rooms_one_gpu"] = concurrent_rooms(hsk, n, dev_frames, local_rank)
+        out["concurrent_rooms_one_gpu"] = concurrent_rooms(n, local_rank)
     # ---- SURVEY.md 8(d) cfg2 / BASELINE configs[1]: the 300-frame scripted stream at 256^3, from a recorded file ----
     if not args.no_trajectory:
         tmpd = tempfile.mkdtemp(prefix="hsk_stream_")

@@ -19,18 +19,8 @@ __global__ void k_resolve(const int* __restrict__ keys_local, const int* __restr
     bits[(3 + c) * P + i] = mine ? __float_as_int(nmap[c * P + i]) : 0;
   }
 }
-__global__ void k_adopt(const int* __restrict__ keys_min, const int* __restrict__ bits, float* __restrict__ vmap,
-                        float* __restrict__ nmap, int P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int km = keys_min[i];
-  const bool hit = (km != HSK_KEY_NONE_I) && ((km & 1) == 0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    vmap[c * P + i] = hit ? __int_as_float(bits[c * P + i]) : HSK_NANF;
-    nmap[c * P + i] = hit ? __int_as_float(bits[(3 + c) * P + i]) : HSK_NANF;
-  }
-}
+// (k_adopt -- the composite into the model maps of level 0 -- lives in kernels_image.hip since round 6, fused with the model
+// pyramid and the pose report: k_adopt_pyramid)
 // Direct exchange (hskinfu_group's one-hop form, SURVEY.md 8(e) "xGMI fit"): the slab that won a pixel stores the bit
 // patterns of its vertex / normal straight into EVERY device's composite buffer (its own included) -- peer-mapped
 // memory, one hop over xGMI -- and nothing where it lost: a pixel has at most one winner among all slabs (a march step is
@@ -61,8 +51,5 @@ void launch_resolve_push(hipStream_t s, const int* keys_local, const int* keys_m
 void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                     int* bits, int P) {
   hipLaunchKernelGGL(k_resolve, dim3((P + 255) / 256), dim3(256), 0, s, keys_local, keys_min, vmap, nmap, bits, P);
-}
-void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vmap, float* nmap, int P) {
-  hipLaunchKernelGGL(k_adopt, dim3((P + 255) / 256), dim3(256), 0, s, keys_min, bits, vmap, nmap, P);
 }
 

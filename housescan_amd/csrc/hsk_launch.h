@@ -33,7 +33,9 @@ void launch_raycast(hipStream_t s, const void* vol, const TrackState* st, const 
 bool raycast_can_fuse_pyramid(const VolParams& vp, int W, int H);
 void launch_resolve(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                     int* bits, int P);
-void launch_adopt(hipStream_t s, const int* keys_min, const int* bits, float* vmap, float* nmap, int P);
+// the end of a z-slab frame in ONE launch: k_adopt + k_resize_maps2 (+ the report into the host ring) fused (kernels_image.hip)
+void launch_adopt_pyramid(hipStream_t s, const int* keys_min, const int* bits, int W, int H, float* v0, float* n0, float* v1, float* n1,
+                          float* v2, float* n2, const TrackState* st, const RingOut* ring);
 void launch_resolve_push(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                          const PushDests& dst, int P);
 void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,

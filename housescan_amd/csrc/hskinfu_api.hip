@@ -417,7 +417,20 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     CK(hipMalloc((void**)&k->d_vmod[l], P * 12));
     CK(hipMalloc((void**)&k->d_nmod[l], P * 12));
   }
-  CK(hipStreamCreateWithFlags(&k->pstream, hipStreamNonBlocking));
+  {
+    // The second stream (upload + preprocessing of the NEXT frame) at the LOWEST priority (round 6).  Not for the priority: streams
+    // of different priorities come from different pools of hardware queues, so this stream can never be mapped onto the
+    // hardware queue of the context's main stream -- HIP spreads a process's streams over four queues in turn, and with one
+    // more stream alive in the process (an idle second context, the host application's own) the two streams of a context met
+    // on one queue: the preprocessing then waited behind the previous frame's whole chain, 4440 -> 3730 frames/s
+    // (tools/host_frames_probe.py --idle-ctx).  The main stream at the HIGHEST priority as well was measured too: four rooms
+    // on one GPU fall from 7200 to 4700-5100 frames/s in all (profiles/r06/rooms_notes.md: more overlap, longer chains).
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      CK(hipStreamCreateWithPriority(&k->pstream, hipStreamNonBlocking, lo));
+    else
+      CK(hipStreamCreateWithFlags(&k->pstream, hipStreamNonBlocking));
+  }
   for (auto& e : k->ev_pre) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : k->ev_free) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&k->ev_src, hipEventDisableTiming));
@@ -1804,7 +1817,6 @@ extern "C" int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, co
   if (!keys_min_dev || !maps_bits_dev) return fail(k, HSK_ERR_ARG, "composite buffers are null");
   if (k->ring_count >= HSK_MAX_IN_FLIGHT) return fail(k, HSK_ERR_STATE, "too many frames in flight: call hsk_wait_frame first");
   HIPCHK(k, hipSetDevice(k->cfg.device_id));
-  launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0], k->lv[0].W * k->lv[0].H);
   // the frame's last kernel reports the tracker state into the ring slot assigned here (no copy node, no event record
   // for the pose: see hsk_submit_frame_dev)
   const int slot = (k->ring_head + k->ring_count) % (HSK_MAX_IN_FLIGHT + 1);
@@ -1814,8 +1826,9 @@ extern "C" int hsk_mgpu_frame_end_async(hsk_ctx* k, const void* keys_min_dev, co
   ((volatile TrackState*)&k->h_ring[slot])->ring_mark = 0u;
   ((volatile TrackState*)&k->h_ring[slot])->pose_mark = 0u;
   const RingOut ring = {k->d_ring_view, k->d_fifo_view, k->d_ring_seq};
-  launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1], k->d_vmod[2],
-                      k->d_nmod[2], k->d_st, &ring);
+  // (round 6: adopt, the model pyramid and the report in ONE launch -- they were two, with level 0 written and read back between them)
+  launch_adopt_pyramid(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->lv[0].W, k->lv[0].H, k->d_vmod[0], k->d_nmod[0],
+                       k->d_vmod[1], k->d_nmod[1], k->d_vmod[2], k->d_nmod[2], k->d_st, &ring);
   HIPCHK(k, hipEventRecord(k->ev_free[k->cur], k->stream));  // the prefetch of the frame after next waits on it (second stream)
   k->set_used[k->cur] = true;
   k->ring_kind[slot] = 0;
@@ -1832,10 +1845,8 @@ extern "C" int hsk_mgpu_frame_end(hsk_ctx* k, const void* keys_min_dev, const vo
   if (!first && k->ring_count > 0) return fail(k, HSK_ERR_STATE, "frames are in flight: collect them with hsk_wait_frame first");
   if (!first) {
     if (!keys_min_dev || !maps_bits_dev) return fail(k, HSK_ERR_ARG, "composite buffers are null");
-    launch_adopt(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->d_vmod[0], k->d_nmod[0],
-                 k->lv[0].W * k->lv[0].H);
-    launch_resize_maps2(k->stream, k->d_vmod[0], k->d_nmod[0], k->lv[0].W, k->lv[0].H, k->d_vmod[1], k->d_nmod[1],
-                        k->d_vmod[2], k->d_nmod[2], k->d_st);
+    launch_adopt_pyramid(k->stream, (const int*)keys_min_dev, (const int*)maps_bits_dev, k->lv[0].W, k->lv[0].H, k->d_vmod[0], k->d_nmod[0],
+                         k->d_vmod[1], k->d_nmod[1], k->d_vmod[2], k->d_nmod[2], k->d_st, nullptr);
   }
   // the frame's image buffers are free again once everything enqueued so far has run
   HIPCHK(k, hipEventRecord(k->ev_free[k->cur], k->stream));

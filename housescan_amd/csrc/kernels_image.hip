@@ -557,6 +557,122 @@ void launch_resize_maps2(hipStream_t s, const float* v0, const float* n0, int W,
                      ring ? *ring : quiet);
 }
 
+// The END of a z-slab frame in one launch (round 6; it was k_adopt, then k_resize_maps2: 15 us of a multi-GPU frame's critical
+// path): the composite of the exchange -- the MIN key of every pixel and, where that key is a hit, the
+// winner's vertex / normal bits -- becomes the model maps of all three levels, and the tracker state is reported into the
+// host ring.  Blocks [0, nb0) write level 0 (k_adopt's selection), [nb0, nb0 + nb1) level 1, the rest level 2 -- the upper
+// levels straight from the composite, with the same selection and k_resize_maps2's arithmetic, operand for operand: the bits
+// of adopting first and resizing afterwards, without the launch boundary between them and without re-reading level 0.
+struct CompositeIn {
+  const int* keys_min;
+  const int* bits;
+  size_t P;
+};
+static __device__ __forceinline__ bool comp_hit(const CompositeIn& C, size_t i) {
+  const int km = C.keys_min[i];
+  return (km != HSK_KEY_NONE_I) && ((km & 1) == 0);
+}
+// resize_tap with level 0 read through the composite: m = 0 the vertex map, 1 the normal map
+static __device__ __forceinline__ void comp_tap(const CompositeIn& C, int m, int W, int x, int y, float& a, float& b, float& c) {
+  const size_t i00 = (size_t)(2 * y) * W + 2 * x, i01 = i00 + 1, i10 = i00 + W, i11 = i10 + 1;
+  const size_t idx[4] = {i00, i01, i10, i11};
+  float t[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool hit = comp_hit(C, idx[q]);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) t[q][ch] = hit ? __int_as_float(C.bits[(size_t)(3 * m + ch) * C.P + idx[q]]) : HSK_NANF;
+  }
+  a = b = c = HSK_NANF;
+  if (!(hsk_isnan(t[0][0]) || hsk_isnan(t[1][0]) || hsk_isnan(t[2][0]) || hsk_isnan(t[3][0]))) {
+    a = (((t[0][0] + t[1][0]) + t[2][0]) + t[3][0]) / 4.0f;
+    b = (((t[0][1] + t[1][1]) + t[2][1]) + t[3][1]) / 4.0f;
+    c = (((t[0][2] + t[1][2]) + t[2][2]) + t[3][2]) / 4.0f;
+    if (m == 1) {
+      const float inv = 1.0f / sqrtf(hsk_dot3(a, b, c, a, b, c));
+      a = a * inv;
+      b = b * inv;
+      c = c * inv;
+    }
+  }
+}
+__global__ void k_adopt_pyramid(CompositeIn C, int W, int H, float* __restrict__ v0, float* __restrict__ n0, float* __restrict__ v1,
+                                float* __restrict__ n1, float* __restrict__ v2, float* __restrict__ n2,
+                                const TrackState* __restrict__ st, int nb0, int nb1, RingOut ring) {
+  if (ring.slots && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) {
+    // last kernel of a pipelined slab frame: report the tracker state into the host ring (see k_raycast)
+    const unsigned n = *ring.seq;
+    *ring.seq = n + 1u;
+    TrackState* dst = ring.slots + ring.slot_fifo[n % HSK_RING_FIFO];
+    const int* src_w = (const int*)st;
+    int* dst_w = (int*)dst;
+    for (unsigned i = 0; i < (unsigned)(offsetof(TrackState, ring_mark) / 4); ++i) dst_w[i] = src_w[i];
+    __threadfence_system();
+    __hip_atomic_store(&dst->pose_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->ring_mark, (n + 1u) | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const int w1 = W >> 1, h1 = H >> 1, w2 = W >> 2, h2 = H >> 2;
+  const size_t P0 = (size_t)W * H, P1 = (size_t)w1 * h1, P2 = (size_t)w2 * h2;
+  if ((int)blockIdx.x < nb0) {  // level 0: k_adopt (whatever the frame's verdict, as before)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
+    if (i >= P0) return;
+    const bool hit = comp_hit(C, i);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      v0[ch * P0 + i] = hit ? __int_as_float(C.bits[(size_t)ch * P0 + i]) : HSK_NANF;
+      n0[ch * P0 + i] = hit ? __int_as_float(C.bits[(size_t)(3 + ch) * P0 + i]) : HSK_NANF;
+    }
+    return;
+  }
+  if (st->lost) return;
+  if ((int)blockIdx.x < nb0 + nb1) {
+    const int bw = (w1 + 63) / 64, bi = blockIdx.x - nb0;
+    const int x = (bi % bw) * 64 + threadIdx.x, y = (bi / bw) * 4 + threadIdx.y;
+    if (x >= w1 || y >= h1) return;
+    const size_t o = (size_t)y * w1 + x;
+    float a, b, c;
+    comp_tap(C, 0, W, x, y, a, b, c);
+    v1[o] = a; v1[P1 + o] = b; v1[2 * P1 + o] = c;
+    comp_tap(C, 1, W, x, y, a, b, c);
+    n1[o] = a; n1[P1 + o] = b; n1[2 * P1 + o] = c;
+    return;
+  }
+  const int bw = (w2 + 63) / 64, bi = blockIdx.x - nb0 - nb1;
+  const int x = (bi % bw) * 64 + threadIdx.x, y = (bi / bw) * 4 + threadIdx.y;
+  if (x >= w2 || y >= h2) return;
+  const size_t o = (size_t)y * w2 + x;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float* dst = m == 0 ? v2 : n2;
+    float t[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) comp_tap(C, m, W, 2 * x + (q & 1), 2 * y + (q >> 1), t[q][0], t[q][1], t[q][2]);
+    float a = HSK_NANF, b = HSK_NANF, c = HSK_NANF;
+    if (!(hsk_isnan(t[0][0]) || hsk_isnan(t[1][0]) || hsk_isnan(t[2][0]) || hsk_isnan(t[3][0]))) {
+      a = (((t[0][0] + t[1][0]) + t[2][0]) + t[3][0]) / 4.0f;
+      b = (((t[0][1] + t[1][1]) + t[2][1]) + t[3][1]) / 4.0f;
+      c = (((t[0][2] + t[1][2]) + t[2][2]) + t[3][2]) / 4.0f;
+      if (m == 1) {
+        const float inv = 1.0f / sqrtf(hsk_dot3(a, b, c, a, b, c));
+        a = a * inv;
+        b = b * inv;
+        c = c * inv;
+      }
+    }
+    dst[o] = a;
+    dst[P2 + o] = b;
+    dst[2 * P2 + o] = c;
+  }
+}
+void launch_adopt_pyramid(hipStream_t s, const int* keys_min, const int* bits, int W, int H, float* v0, float* n0, float* v1, float* n1,
+                          float* v2, float* n2, const TrackState* st, const RingOut* ring) {
+  const size_t P0 = (size_t)W * H;
+  const int nb0 = (int)((P0 + 255) / 256), nb1 = ((W / 2 + 63) / 64) * ((H / 2 + 3) / 4), nb2 = ((W / 4 + 63) / 64) * ((H / 4 + 3) / 4);
+  const RingOut quiet = {nullptr, nullptr, nullptr};
+  const CompositeIn C = {keys_min, bits, P0};
+  hipLaunchKernelGGL(k_adopt_pyramid, dim3(nb0 + nb1 + nb2), dim3(64, 4), 0, s, C, W, H, v0, n0, v1, n1, v2, n2, st, nb0, nb1, ring ? *ring : quiet);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // ICP (A.5).  Per pixel: transform, project into the previous camera, gate, build the 7-vector row.  The
 // 27 products are formed in binary64 (exact) and snapped to multiples of 2^-26, which makes every partial

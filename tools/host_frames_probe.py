@@ -12,6 +12,15 @@ n = int(pos[0]) if pos else 512
 frames = int(pos[1]) if len(pos) > 1 else 300
 warm = int(sys.argv[sys.argv.index("--warm-sync") + 1]) if "--warm-sync" in sys.argv else 0
 fr = [hsk.synth_depth(hsk.synth_pose(k)) for k in range(frames)]
+idle = None
+if "--idle-ctx" in sys.argv:   # a second context, alive and idle, beside the one that is fed (bench.py keeps its first tracker for the read-outs)
+    idle = hsk.KinfuTracker(n=n)
+    for k in range(4):
+        idle.process_frame(fr[k])
+    idle.synchronize()
+if "--torch" in sys.argv:
+    import torch
+    x = torch.zeros(1 << 20, device="cuda"); torch.cuda.synchronize()
 trk = hsk.KinfuTracker(n=n)
 for k in range(1 + warm):
     trk.process_frame(fr[k])

@@ -21,12 +21,12 @@ for k, d in sorted(acc.items()):
         print(f"   {c:28s} mean={sum(v)/len(v):16.1f}  n={len(v)}")
 
 # traffic file for bench.py's roofline.traffic: the integrate stage = pass A (k_integrate<false>) + pass B
-# (k_integrate_detail2<false>), one dispatch of each per frame
+# (k_integrate_detail3<false>), one dispatch of each per frame
 import json, os
 fetch = write = 0.0
 parts = []
 for k, d in acc.items():
-    if (k.startswith("void k_integrate<false") or k.startswith("void k_integrate_detail2<false")) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    if (k.startswith("void k_integrate<false") or k.startswith("void k_integrate_detail3<false")) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 1024 * 2   # gfx950: FETCH_SIZE reads 1/2 of wide streams
         w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024
         fetch += f

@@ -27,6 +27,22 @@ done
 # ... on the noise run (sigma = 1.2 mm z^2, 2 % dropout), where the hole-aware paths of integrate do their work
 (cd $ROOT && timeout 1200 python3 tools/long_parity.py 512 300 --noise 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_noise_512.txt)
 cat $OUT/long_parity_noise_512.txt
+# (round 6) ... on the ROOM SCAN -- camera inside the volume: the level turn, the up turn and the start of the down turn of room 0 --
+# and on the stream with holes as a sensor makes them
+(cd $ROOT && timeout 1500 python3 tools/long_parity.py 512 520 --room 0 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_room_512.txt)
+cat $OUT/long_parity_room_512.txt
+(cd $ROOT && timeout 1500 python3 tools/long_parity.py 256 721 --room 1 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_room_256_whole_scan.txt)
+cat $OUT/long_parity_room_256_whole_scan.txt
+(cd $ROOT && timeout 1200 python3 tools/long_parity.py 512 300 --holes 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_holes_512.txt)
+cat $OUT/long_parity_holes_512.txt
+# ... kernel medians on the four streams (tools/noise_kstats.sh) and the rooms from C threads with their kernel overlap
+for st in scripted holes noise room0; do
+  (cd $ROOT && timeout 600 tools/noise_kstats.sh 512 40 $st > $OUT/kernel_medians_512_$st.txt 2>&1)
+done
+(cd $ROOT && ROOMS="1 2 4 8" TRACE=4 timeout 900 tools/rooms_native.sh 512 240 room 1 host 0 > $OUT/rooms_native_room.txt 2>&1)
+(cd $ROOT && ROOMS="1 2 4" timeout 900 tools/rooms_native.sh 512 240 open 1 host 0 > $OUT/rooms_native_open.txt 2>&1)
+(cd $ROOT && ROOMS="1 4" timeout 900 tools/rooms_native.sh 512 240 room 1 host 2 > $OUT/rooms_native_room_graph.txt 2>&1)
+(cd $ROOT && timeout 120 tools/probes/launch_gap_probe > $OUT/launch_gap_probe.txt 2>&1)
 # the read-out kernels (not in the bench's timed region): kernel stats + host times at both sizes
 for v in 512 1024; do
   (cd $ROOT && timeout 900 tools/readout_profile.sh $v > $OUT/readout_$v.txt 2>&1)

@@ -29,7 +29,9 @@ typedef struct {
   hsk_ctx* k;
   uint16_t* depth;  /* frames x w x h, host */
   void* depth_dev;  /* the same on the device (dev mode) */
-  int w, h, lost, rc;
+  int w, h, lost, rc, v0;
+  hsk_config cfg;
+  int (*upload)(void*, const void*, size_t, int);
   double t_submit, t_wait, t_total;
   pthread_barrier_t* gate;
 } room_t;
@@ -51,6 +53,18 @@ static void* run_room(void* arg) {
   float pose[16];
   int tracked = 0;
   const size_t px = (size_t)r->w * r->h;
+  /* the room's frames, rendered by its own thread (the rooms render side by side: seconds instead of half a minute) */
+  for (int f = 0; f < r->frames; ++f) {
+    float gt[16];
+    if (r->inside) {
+      hsk_synth_room_pose((r->room + r->v0) & 3, f, 720, gt);
+      hsk_synth_room_render((r->room + r->v0) & 3, gt, r->w, r->h, r->cfg.fx, r->cfg.fy, r->cfg.cx, r->cfg.cy, r->depth + (size_t)f * px);
+    } else {
+      hsk_synth_pose(25 * (r->room + r->v0) + f, gt);
+      hsk_synth_render(gt, r->w, r->h, r->cfg.fx, r->cfg.fy, r->cfg.cx, r->cfg.cy, r->depth + (size_t)f * px);
+    }
+  }
+  if (r->dev && r->upload && r->upload(r->depth_dev, r->depth, (size_t)r->frames * px * 2, 1 /* hipMemcpyHostToDevice */) != 0) r->rc = HSK_ERR_STATE;
   /* frame 0 and five warm-up frames, synchronously */
   for (int f = 0; f < 6 && r->rc == HSK_OK; ++f) r->rc = hsk_process_frame(r->k, r->depth + (size_t)f * px, r->w, r->h, pose, &tracked);
   hsk_synchronize(r->k);
@@ -117,24 +131,18 @@ int main(int argc, char** argv) {
     R[r].w = cfg.width; R[r].h = cfg.height; R[r].gate = &gate;
     const size_t px = (size_t)cfg.width * cfg.height;
     R[r].depth = (uint16_t*)malloc((size_t)frames * px * 2);
-    for (int f = 0; f < frames; ++f) {
-      if (inside) {
-        hsk_synth_room_pose((r + v0) & 3, f, 720, gt);
-        hsk_synth_room_render((r + v0) & 3, gt, cfg.width, cfg.height, cfg.fx, cfg.fy, cfg.cx, cfg.cy, R[r].depth + (size_t)f * px);
-      } else {
-        hsk_synth_pose(25 * (r + v0) + f, gt);
-        hsk_synth_render(gt, cfg.width, cfg.height, cfg.fx, cfg.fy, cfg.cx, cfg.cy, R[r].depth + (size_t)f * px);
-      }
-    }
+    R[r].cfg = cfg;
+    R[r].v0 = v0;
     if (hsk_create(&cfg, &R[r].k) != HSK_OK) {
       fprintf(stderr, "hsk_create: %s\n", hsk_last_error(NULL));
       return 1;
     }
     if (dev) {
-      if (p_malloc(&R[r].depth_dev, (size_t)frames * px * 2) != 0 || p_memcpy(R[r].depth_dev, R[r].depth, (size_t)frames * px * 2, 1 /* hipMemcpyHostToDevice */) != 0) {
-        fprintf(stderr, "dev mode: upload failed\n");
+      if (p_malloc(&R[r].depth_dev, (size_t)frames * px * 2) != 0) {
+        fprintf(stderr, "dev mode: allocation failed\n");
         return 1;
       }
+      R[r].upload = p_memcpy;
     }
   }
   if (getenv("ROOMS_START_FILE")) { /* several PROCESSES (tools/rooms_procs.sh) start their timed regions together */
