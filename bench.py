@@ -731,6 +731,8 @@ def run_single(args, hsk, torch, local_rank):
         if not args.no_traffic:
             blk["issue_util"] = issue_util_block(1024, tot2, 1 + W2)
         out["roofline_1024"] = blk
+        if not args.no_noise:   # the room scan at the north_star's size too
+            out["room_1024"] = stream_block(args, hsk, torch, 1024, local_rank, round(K2 / el2, 2), "room0", max_steps=40)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, hsk)
     return out

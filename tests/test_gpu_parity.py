@@ -926,6 +926,60 @@ def test_noisy_stream_512_vs_oracle(hsk, oracle):
     ot.close()
 
 
+def test_pipelined_frames_from_a_graph_match_eager(hsk, synth_frames):
+    """use_graph = 2 (round 6): the main-stream chain of a pipelined frame -- 19 ICP launches, 3 integrate, the raycast -- replayed
+    from one hipGraph per image-buffer set.  Every pose, the verdicts (a garbage frame in the stream loses tracking and restarts
+    the scan), the TSDF and the model maps equal the eager form's; hsk_submit_host_us counts the submissions of both."""
+    n = 128
+    frames = [synth_frames(k)[1] for k in range(14)]
+    frames[8] = np.zeros_like(frames[8])              # no valid pixel: a singular system, tracking lost, the scan restarts
+    res = []
+    for g in (0, 2):
+        trk = hsk.KinfuTracker(n=n, use_graph=g)
+        out = []
+        trk.submit_frame(frames[0])
+        for d in frames[1:]:
+            trk.submit_frame(d)
+            out.append(trk.wait_frame())
+        out.append(trk.wait_frame())
+        us, cnt = trk.submit_host_us()
+        assert cnt >= 8 and all(u >= 0.0 for u in us) and us[3] > 0.0
+        res.append((out, trk.download_tsdf(), [trk.download_map(2, l) for l in range(3)], us, cnt))
+        trk.close()
+    (a, va, ma, _, ca), (b, vb, mb, _, cb) = res
+    assert ca == cb
+    assert any(not ok for _, ok in a[1:]), "the garbage frame must lose tracking"
+    for k, ((pa, oa), (pb, ob)) in enumerate(zip(a, b)):
+        assert oa == ob, k
+        assert_same_bits(pa, pb, f"graph vs eager pose {k}")
+    assert_same_bits(va, vb, "graph vs eager tsdf")
+    for l in range(3):
+        assert_same_bits(ma[l], mb[l], f"graph vs eager model vmap {l}")
+
+
+def test_prepare_readout_then_products(hsk, oracle, synth_frames):
+    """hsk_prepare_readout (round 6): everything a read-out allocates on first use made up front; the products that follow are
+    the oracle's, the call is idempotent, and the light class counts nothing on a render without holes"""
+    n = 128
+    trk = hsk.KinfuTracker(n=n)
+    trk.prepare_readout()
+    trk.prepare_readout(1 << 20)
+    ot = oracle.Tracker(oracle.default_config(n))
+    for k in range(5):
+        d = synth_frames(k)[1]
+        trk.process_frame(d)
+        ot.process(d)
+    assert trk.integrate_light_entries() == 0 and trk.integrate_queue_entries() > 0
+    cloud, total = trk.extract_cloud()
+    want, wtotal = oracle.extract_cloud(oracle.default_config(n), ot.volume())
+    assert total == wtotal
+    assert_same_bits(cloud, want, "cloud after prepare_readout")
+    tri, nt = trk.extract_mesh(cubes=True)
+    assert nt > 0 and len(tri) == nt
+    trk.close()
+    ot.close()
+
+
 def test_sensor_holes_stream_512_vs_oracle(hsk, oracle):
     """HOLES AS A SENSOR MAKES THEM on the measured path: hsk_synth_render_sensor -- no return from grazing
     rays, shadow bands behind depth discontinuities, the range cut, an absorbing block, sigma = 1.2 mm z^2 -- i.e. CONTIGUOUS
