@@ -52,6 +52,7 @@ def slab_halo_planes(n, size_m=3.0, trunc=0.03):
 
 # single-GPU stage times (ICP, integrate, raycast; us) the multi-GPU prediction is priced from: this round's, and round 3's
 # (what DESIGN.md section 6's table was first written with: kept beside it as predicted_us_r03)
+STAGE_US_R06 = {512: (112.0, 57.0, 57.0), 1024: (113.0, 214.0, 69.0)}
 STAGE_US_R05 = {512: (112.0, 58.0, 57.0), 1024: (113.0, 205.0, 73.0)}
 STAGE_US_R03 = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}
 
@@ -59,20 +60,20 @@ STAGE_US_R03 = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}
 def predicted_us(n, G, stage_us=None):
     """the frame time of G z-slabs priced from the CURRENT single-GPU stage times and xGMI link rates
     (arithmetic, never measured) -- carried in the line so that the first multi-GPU run adjudicates it"""
-    base = (stage_us or STAGE_US_R05).get(n)
+    base = (stage_us or STAGE_US_R06).get(n)
     if base is None or G < 2:
         return None
     icp, integ, ray = base
     integ_g = integ * (1.0 / G + 2.0 * slab_halo_planes(n) / n)
     ray_g = ray / G + 2.0
     exch = {2: 30.0, 4: 38.0, 8: 45.0}.get(G, 30.0 + 2.5 * (G - 2))
-    adopt = 15.0
+    adopt = 15.0 if stage_us in (STAGE_US_R03, STAGE_US_R05) else 9.0   # (round 6: the frame's end is one launch, k_adopt_pyramid)
     frame = icp + integ_g + ray_g + exch + adopt
     return {"icp": icp, "integrate": round(integ_g, 1), "raycast": round(ray_g, 1), "slab_work_us": round(icp + integ_g + ray_g, 1),
             "exchange_us": exch, "adopt_us": adopt, "frame_us": round(frame, 1), "frames_per_s": round(1e6 / frame, 1),
             "single_gpu_frame_us": icp + integ + ray,
             "source": "DESIGN.md section 6 (direct exchange; replicated ICP; from %s single-GPU stage times and ~100 GB/s per xGMI link)"
-                      % ("round 3's" if stage_us is STAGE_US_R03 else "round 5's")}
+                      % ("round 3's" if stage_us is STAGE_US_R03 else ("round 5's" if stage_us is STAGE_US_R05 else "round 6's"))}
 
 
 def plane_crcs(vol):

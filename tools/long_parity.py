@@ -33,8 +33,8 @@ else:
         gts, fr = hsk.synth_noisy_frames(frames)
         what = " NOISY stream (1.2 mm z^2, 2 % dropout)"
     elif holes:
-        gts, fr = hsk.synth_sensor_frames(frames)
-        what = " SENSOR-HOLES stream (grazing rays, shadow bands, range cut, 1.2 mm z^2; %.1f %% of the pixels invalid)" % (100.0 * np.mean([(d == 0).mean() for d in fr]))
+        gts, fr = hsk.synth_sensor_frames(frames, absorbing=True)
+        what = " SENSOR-HOLES stream (grazing rays, shadow bands, range cut, absorbing block, 1.2 mm z^2; %.1f %% of the pixels invalid)" % (100.0 * np.mean([(d == 0).mean() for d in fr]))
     else:
         gts = [hsk.synth_pose(k) for k in range(frames)]
         fr = [hsk.synth_depth(p) for p in gts]
