@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """After tools/profile_round.sh and the round's bench lines have run on the GPU box (gpurun_out/round, gpurun_out/final):
-copy the judged artefacts into profiles/rNN/ and print the numbers the READMEs quote.   usage: tools/collect_round.py r05"""
+copy the judged artefacts into profiles/rNN/ and print the numbers the READMEs quote.   usage: tools/collect_round.py r06"""
 import csv, json, os, shutil, sys, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 R, F, P = (os.path.join(ROOT, p) for p in ("gpurun_out/round", "gpurun_out/final", "profiles/" + rnd))
 os.makedirs(P, exist_ok=True)
 for src, dst in (("kernel_stats.csv", "final_kernel_stats.csv"), ("kernel_stats_1024.csv", "kernel_stats_1024.csv"), ("pmc_summary.txt", "final_pmc_summary.txt"),
@@ -11,9 +11,10 @@ for src, dst in (("kernel_stats.csv", "final_kernel_stats.csv"), ("kernel_stats_
                  ("bench_profiled_1024.json", "bench_1024_under_rocprof.json"), ("readout_kernel_stats_512.csv", None), ("readout_kernel_stats_1024.csv", None),
                  ("readout_512.txt", None), ("readout_1024.txt", None)):
     shutil.copy(os.path.join(R, src), os.path.join(P, dst or src))
-for f in glob.glob(os.path.join(R, "long_parity_*.txt")):
-    shutil.copy(f, P)
-for f in ("bench_default_200steps.json", "bench_driver_window_20steps.json", "bench_sync_api_quick.json", "bench_gpus2_share_gpu.json", "fuzz_campaign.txt", "gputest_final.txt"):
+for pat in ("long_parity_*.txt", "kernel_medians_512_*.txt", "rooms_native_*.txt", "launch_gap_probe.txt"):
+    for f in glob.glob(os.path.join(R, pat)):
+        shutil.copy(f, P)
+for f in ("bench_default_200steps.json", "bench_driver_window_20steps.json", "bench_sync_api_quick.json", "bench_gpus2_share_gpu.json", "fuzz_campaign.txt", "chunk_stress.txt", "gputest_final.txt"):
     shutil.copy(os.path.join(F, f), P)
 g8 = os.path.join(F, "bench_gpus8_share_gpu.json")
 if os.path.exists(g8):
@@ -26,6 +27,11 @@ if os.path.exists(g8):
 for f in ("bench_default_200steps", "bench_driver_window_20steps"):
     j = json.loads(open(os.path.join(F, f + ".json")).read().strip().splitlines()[-1])
     r, n, b = j["roofline"], j.get("noise_512", {}), j.get("roofline_1024", {})
+    print("   api", j.get("device_frames_fps"), j.get("host_frames_pipelined_fps"), j.get("sync_process_frame_fps"))
+    for blk in ("room_512", "room_1024", "holes_512"):
+        x = j.get(blk)
+        if x:
+            print("  ", blk, x["frames_per_s"], x["frames_per_s_host_frames"], x["vs_clean_render"], x["stage_us"], x["integrate"]["frac"], x["integrate"].get("hbm_frac"))
     print(f, j["value"], "frames/s, build", j.get("build_id"), {k: v for k, v in j["stage_us"].items() if k in ("preprocess", "icp", "integrate", "raycast")},
           "frac", r["frac"], "hbm_frac", r["hbm_frac"], "queue", r["pass_b_queue_entries_mean"])
     print("   issue_util", {k: (v["us"], v["valu"], v["salu"]) for k, v in r.get("issue_util", {}).items() if k != "note"})
@@ -36,7 +42,7 @@ for f in ("bench_default_200steps", "bench_driver_window_20steps"):
         print("   readout 1024", {k: v for k, v in b.get("readout_ms", {}).items() if k.endswith("_ms") or k.endswith("host")})
     print("   readout", {k: v for k, v in j.get("readout_ms", {}).items() if k.endswith("_ms") or k.endswith("host")})
     cr = j.get("concurrent_rooms_one_gpu", {})
-    print("   rooms", cr.get("2_rooms", {}).get("frames_per_s_in_all"), cr.get("4_rooms", {}).get("frames_per_s_in_all"), "pcie", j.get("pcie_inclusive_pipelined_fps"),
+    print("   rooms", {k: {m: v[m].get("frames_per_s_in_all") for m in v} for k, v in cr.items() if isinstance(v, dict)},
           "integrate+flush", r.get("integrate_plus_flush_every_frame_us"), r.get("frac_with_flush_every_frame"))
 print("sync api", json.loads(open(os.path.join(F, "bench_sync_api_quick.json")).read().strip().splitlines()[-1])["value"])
 for f in ("final_kernel_stats.csv", "kernel_stats_1024.csv"):
