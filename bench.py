@@ -600,6 +600,7 @@ def stream_block(args, hsk, torch, n, local_rank, clean_fps, stream, with_counte
 
 
 def run_single(args, hsk, torch, local_rank):
+    t_wall0 = time.perf_counter()
     K, Wm, n = args.steps, args.warmup, args.volume
     total = 1 + Wm + K
     poses_gt, frames = make_frames(hsk, 0, total)
@@ -735,6 +736,7 @@ def run_single(args, hsk, torch, local_rank):
             out["room_1024"] = stream_block(args, hsk, torch, 1024, local_rank, round(K2 / el2, 2), "room0", max_steps=40)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, hsk)
+    out["bench_wall_s"] = round(time.perf_counter() - t_wall0, 1)   # (everything this invocation did after its imports: timed region, replays, counter passes, other streams, rooms, 1024^3, CPU baseline)
     return out
 
 

@@ -426,10 +426,13 @@ extern "C" int hsk_create(const hsk_config* c, hsk_ctx** out) {
     // (tools/host_frames_probe.py --idle-ctx).  The main stream at the HIGHEST priority as well was measured too: four rooms
     // on one GPU fall from 7200 to 4700-5100 frames/s in all (profiles/r06/rooms_notes.md: more overlap, longer chains).
     int lo = 0, hi = 0;
+    bool made = false;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-      CK(hipStreamCreateWithPriority(&k->pstream, hipStreamNonBlocking, lo));
-    else
+      made = hipStreamCreateWithPriority(&k->pstream, hipStreamNonBlocking, lo) == hipSuccess;
+    if (!made) {  // (no priorities here: a plain stream, as before)
+      (void)hipGetLastError();
       CK(hipStreamCreateWithFlags(&k->pstream, hipStreamNonBlocking));
+    }
   }
   for (auto& e : k->ev_pre) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : k->ev_free) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -49,6 +49,38 @@ def test_group_matches_single_context(hsk, synth_frames, slabs, flags):
     ref.close()
 
 
+@pytest.mark.parametrize("stream,slabs,flags", [("noise", 3, 4), ("holes", 8, 4), ("noise", 2, 0)])
+def test_group_on_streams_with_holes(hsk, stream, slabs, flags):
+    """round 6: the light class of pass A / pass B (free space over holes in the depth image: queue tails, pending counts in the
+    entries, summary bytes rewritten by pass B) inside SLAB contexts -- stored planes that start at own_z0 - halo, slabs thinner
+    than a pass-A chunk -- and the fused frame end (k_adopt_pyramid): a group on the noise run and on the sensor-holes stream,
+    256^3, direct exchange (4) and staged composites (0), equals one context: poses, every owned plane, the model maps"""
+    n, count = 256, 8
+    frames = hsk.synth_noisy_frames(count)[1] if stream == "noise" else hsk.synth_sensor_frames(count, absorbing=True)[1]
+    ref = hsk.KinfuTracker(n=n)
+    want = [ref.process_frame(d) for d in frames]
+    assert ref.integrate_light_entries() > 1000, "the stream must exercise the light class"
+    grp = hsk.KinfuGroup(hsk.default_config(n), device_ids=[0] * slabs, flags=flags)
+    got = [grp.process_frame(frames[0]), grp.process_frame(frames[1])]
+    grp.submit_frame(frames[2])
+    for d in frames[3:]:
+        grp.submit_frame(d)
+        got.append(grp.wait_frame())
+    got.append(grp.wait_frame())
+    for k, ((p, ok), (pr, okr)) in enumerate(zip(got, want)):
+        assert ok == okr == (k > 0)
+        assert_same_bits(p, pr, f"{stream} group pose frame {k} ({slabs} slabs, flags {flags})")
+    assert_same_bits(grp.download_tsdf(), ref.download_tsdf(), f"{stream} group tsdf ({slabs} slabs)")
+    assert sum(grp.slab(i).integrate_light_entries() for i in range(slabs)) > 1000, "the slabs' own light class must have run"
+    for i in (0, slabs - 1):
+        s = grp.slab(i)
+        for level in range(3):
+            assert_same_bits(s.download_map(2, level), ref.download_map(2, level), f"slab {i} model vmap {level}")
+            assert_same_bits(s.download_map(3, level), ref.download_map(3, level), f"slab {i} model nmap {level}")
+    grp.close()
+    ref.close()
+
+
 def test_group_eight_slabs_256(hsk, synth_frames):
     """configs[3]'s eight-way partition through the group call (256^3 here; the 1024^3 partition is composed slab by
     slab in test_gpu_configs.py)"""
