@@ -83,6 +83,8 @@ def test_launcher_bare_and_under_torchrun(tmp_path, torchrun):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["headline_form"] == "direct" and out["value"] == 1200.0
     assert out["matches_single_gpu"] is True and out["ranks_seen"] == 2 and out["steps"] == 20 and out["warmup"] == 5
     assert out["rooms_weak"]["value"] == 1980.0 and out["rooms_weak"]["scaling"] == "weak"
+    assert out["value_weak"] == 1980.0 and "scaling: weak" in out["value_weak_note"]   # (round 6: the form that scales, at the top level)
+    assert out["predicted_us"]["adopt_us"] == 9.0 and out["predicted_us_r03"]["adopt_us"] == 15.0
     assert set(out["forms"]) == {"rccl", "rccl_icp_allreduce", "direct"} and out["forms"]["rccl_icp_allreduce"]["value"] == 700.0
     assert out["launcher"]["failed_forms"] == {} and out["speedup_vs_single_gpu"] == 1.2
     assert out["predicted_us"]["frame_us"] > 0 and out["stage_us"]["exchange_us"] == 30.0
