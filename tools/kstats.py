@@ -2,10 +2,10 @@
 of a scan takes a 1 ms pass B into every mean).  usage: kstats.py <out dir> [top n]"""
 import csv, glob, sys
 import statistics
-f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_stats.csv'))[-1]
+f = sorted(glob.glob(sys.argv[1] + '/**/*_kernel_stats.csv', recursive=True))[-1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 med = {}
-tr = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))
+tr = sorted(glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True))
 if tr:
     per = {}
     for r in csv.DictReader(open(tr[-1])):
