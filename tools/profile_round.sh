@@ -42,6 +42,7 @@ done
 (cd $ROOT && ROOMS="1 2 4 8" TRACE=4 timeout 900 tools/rooms_native.sh 512 240 room 1 host 0 > $OUT/rooms_native_room.txt 2>&1)
 (cd $ROOT && ROOMS="1 2 4" timeout 900 tools/rooms_native.sh 512 240 open 1 host 0 > $OUT/rooms_native_open.txt 2>&1)
 (cd $ROOT && ROOMS="1 4" timeout 900 tools/rooms_native.sh 512 240 room 1 host 2 > $OUT/rooms_native_room_graph.txt 2>&1)
+[ -x $ROOT/tools/probes/launch_gap_probe ] || (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $ROOT/tools/probes/launch_gap_probe.hip -o $ROOT/tools/probes/launch_gap_probe 2>/dev/null)
 (cd $ROOT && timeout 120 tools/probes/launch_gap_probe > $OUT/launch_gap_probe.txt 2>&1)
 # the read-out kernels (not in the bench's timed region): kernel stats + host times at both sizes
 for v in 512 1024; do
