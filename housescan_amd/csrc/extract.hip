@@ -607,3 +607,17 @@ void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigne
   }
 }
 
+// The code object of this file is loaded when one of its kernels is first used (deferred loading): 0.7 ms that the first
+// product of a process would otherwise pay on whatever thread asks for it.  hsk_prepare_readout asks here instead.
+int extract_warm() {
+  hipFuncAttributes a;
+  hipError_t e = hipFuncGetAttributes(&a, (const void*)k_extract<false>);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)k_extract<true>);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)k_extract_mesh_mc<false>);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)k_extract_mesh_mc<true>);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)k_extract_mesh<false>);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)k_extract_mesh<true>);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)k_scan_rows_sum);
+  return (int)e;
+}
+

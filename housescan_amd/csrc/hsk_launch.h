@@ -38,6 +38,7 @@ void launch_adopt_pyramid(hipStream_t s, const int* keys_min, const int* bits, i
                           float* v2, float* n2, const TrackState* st, const RingOut* ring);
 void launch_resolve_push(hipStream_t s, const int* keys_local, const int* keys_min, const float* vmap, const float* nmap,
                          const PushDests& dst, int P);
+int extract_warm();   // loads extract.hip's code object (hsk_prepare_readout); a hipError_t
 void launch_extract(hipStream_t s, const void* vol, const VolParams& vp, unsigned* row_count,
                     unsigned long long* row_offset, unsigned long long* total, float* xyz, unsigned long long cap,
                     int pass, const unsigned* flags);

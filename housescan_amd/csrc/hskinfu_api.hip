@@ -1513,6 +1513,7 @@ extern "C" int hsk_prepare_readout(hsk_ctx* k, size_t product_bytes) {
   if (r == HSK_OK) r = ensure_row_tables(k);
   if (r == HSK_OK) r = ensure_cube_table(k);
   if (r == HSK_OK) r = ensure_product_bytes(k, product_bytes ? product_bytes : (size_t)48 << 20);
+  if (r == HSK_OK) HIPCHK(k, (hipError_t)extract_warm());  // (the read-out kernels' code object: 0.7 ms of a process's first product)
   return r;
 }
 

@@ -2,7 +2,7 @@
 """Long-horizon parity: FRAMES frames of the scripted synthetic stream through the pipelined tracker at N^3 against the CPU
 oracle's tracker -- every pose and the final TSDF bit for bit.  (The pytest suite holds shorter runs at these sizes: the
 oracle takes 0.14 s per frame at 512^3 and 0.5 s at 1024^3 on 16 cores.)
-usage: tools/long_parity.py N FRAMES [--noise | --holes | --room V [--first K] [--scan F]]
+usage: tools/long_parity.py N FRAMES [--noise | --holes | --room V [--first K] [--scan F] [--sensor]]
 --noise: SURVEY.md 8(d)'s noise run instead of the exact render (sigma = 1.2 mm z^2 on every pixel, 2 % dropout; seeds 1234 / 5678)
 --holes: the scripted stream with holes as a sensor makes them (hsk.synth_sensor_frames: grazing rays, shadow bands, range cut, sigma)
 --room V: the ROOM SCAN -- camera inside the volume: frames K .. K + FRAMES - 1 of the F-frame (default 720) three-turn scan of
@@ -22,10 +22,13 @@ if room is not None:
     first = int(opts[opts.index("--first") + 1]) if "--first" in opts else 0
     scan = int(opts[opts.index("--scan") + 1]) if "--scan" in opts else 720
     gts = [hsk.synth_room_pose(room, first + k, scan) for k in range(frames)]
-    fr = [hsk.synth_room_depth(room, p) for p in gts]
+    if "--sensor" in opts:   # the room as a structured-light sensor sees it: grazing rays, shadow bands, absorbing furniture, noise
+        fr = [hsk.synth_sensor_depth(p, scene=room, seed=1234 + first + i, absorbing=True)[0] for i, p in enumerate(gts)]
+    else:
+        fr = [hsk.synth_room_depth(room, p) for p in gts]
     cfg_o = oracle.default_config(n, omp=True, init_R=gts[0][:3, :3], init_t=gts[0][:3, 3])
     trk = hsk.KinfuTracker(n=n, init_pose=gts[0])
-    what = f" ROOM SCAN (camera inside the volume): room {room}, frames {first}..{first + frames - 1} of a {scan}-frame three-turn scan"
+    what = f" ROOM SCAN (camera inside the volume{', as a SENSOR sees it: %.1f %% of the pixels invalid' % (100.0 * np.mean([(d == 0).mean() for d in fr])) if '--sensor' in opts else ''}): room {room}, frames {first}..{first + frames - 1} of a {scan}-frame three-turn scan"
 else:
     cfg_o = oracle.default_config(n, omp=True)
     trk = hsk.KinfuTracker(n=n)

@@ -35,6 +35,13 @@ cat $OUT/long_parity_room_512.txt
 cat $OUT/long_parity_room_256_whole_scan.txt
 (cd $ROOT && timeout 1200 python3 tools/long_parity.py 512 300 --holes 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_holes_512.txt)
 cat $OUT/long_parity_holes_512.txt
+# ... the other two rooms (level turn and into the up turn), and a room as a SENSOR sees it (holes inside the volume's own frustum)
+for v in 2 3; do
+  (cd $ROOT && timeout 1200 python3 tools/long_parity.py 512 300 --room $v 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_room${v}_512.txt)
+  cat $OUT/long_parity_room${v}_512.txt
+done
+(cd $ROOT && timeout 1200 python3 tools/long_parity.py 512 300 --room 0 --sensor 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_room_sensor_512.txt)
+cat $OUT/long_parity_room_sensor_512.txt
 # ... kernel medians on the four streams (tools/noise_kstats.sh) and the rooms from C threads with their kernel overlap
 for st in scripted holes noise room0; do
   (cd $ROOT && timeout 600 tools/noise_kstats.sh 512 40 $st > $OUT/kernel_medians_512_$st.txt 2>&1)
