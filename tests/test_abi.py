@@ -127,3 +127,17 @@ def test_bilateral_tables_exact(hsk):
     k = np.arange(512)
     ref_c = np.exp(-((k * k).astype(np.float32) * c2).astype(np.float64)).astype(np.float32)
     assert np.array_equal(ws, ref_s) and np.array_equal(wc, ref_c)
+
+
+def test_native_rooms_harness_builds_against_the_header(tmp_path, hsk):
+    """tools/rooms_native.c (bench.py's concurrent_rooms_one_gpu block compiles and runs it on the GPU box) is plain C11 against
+    include/hskinfu.h and links with nothing but the library, libdl and pthreads"""
+    from housescan_amd import _lib
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "rooms_native")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-pthread", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "rooms_native.c"), "-L" + lib_dir, "-lhskinfu", "-ldl", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=60)   # (0 rooms: the argument check, no GPU touched)
+    assert r.returncode == 2
+
