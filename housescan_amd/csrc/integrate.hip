@@ -1191,8 +1191,10 @@ __global__ __launch_bounds__(256, NS == 4 ? INTEGRATE_WPE_LONG : INTEGRATE_WPE) 
 #define DETAIL3_WPE 8
 #endif
 #ifndef DETAIL3_GX
-#define DETAIL3_GX 8  // DETAIL3_GX x 256 blocks of 4 waves: one resident round of the chip at 8 waves per SIMD
-#endif
+#define DETAIL3_GX 16  // DETAIL3_GX x 256 blocks of 4 waves: TWO resident rounds of the chip at 8 waves per SIMD -- the second round
+#endif                 // rebalances the first (tools/experiments/detail3_ab.sh, pass B medians at 8 / 12 / 16 / 24 / 32 / 48: 512^3 21.6 /
+                       // 21.4 / 21.7-22.0 / 23.1 / 23.2 / 25.7 us, noise 49.4 / 50.0 / 47.2-47.5 / 48.8 / 48.7 / 51.6, 1024^3 121.7-122.8 /
+                       // 115.3 / 114.5-116.5 / 113.7 / 113.3 / 114.0)
 static __device__ __forceinline__ unsigned quad_or(unsigned v) {
   v |= (unsigned)__shfl_xor((int)v, 1, 64);
   return v | (unsigned)__shfl_xor((int)v, 2, 64);
