@@ -52,7 +52,7 @@ def slab_halo_planes(n, size_m=3.0, trunc=0.03):
 
 # single-GPU stage times (ICP, integrate, raycast; us) the multi-GPU prediction is priced from: this round's, and round 3's
 # (what DESIGN.md section 6's table was first written with: kept beside it as predicted_us_r03)
-STAGE_US_R06 = {512: (112.0, 57.0, 57.0), 1024: (113.0, 214.0, 69.0)}
+STAGE_US_R06 = {512: (112.0, 57.0, 57.0), 1024: (113.0, 200.0, 68.0)}
 STAGE_US_R05 = {512: (112.0, 58.0, 57.0), 1024: (113.0, 205.0, 73.0)}
 STAGE_US_R03 = {512: (120.0, 71.0, 59.0), 1024: (124.0, 345.0, 95.0)}
 
