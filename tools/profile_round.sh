@@ -66,6 +66,9 @@ done
 # ... and with every configuration field off its default (non-cubic, non-power-of-two volume, fx != fy, other gates and iteration counts)
 (cd $ROOT && timeout 1200 python3 tools/long_parity_nondefault.py 300 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_nondefault.txt)
 cat $OUT/long_parity_nondefault.txt
+# ... the same configuration on frames as a sensor returns them: the light class of pass A / pass B away from every default
+(cd $ROOT && timeout 1200 python3 tools/long_parity_nondefault.py 300 --holes 2>&1 | grep -v amdgpu.ids | tail -4 > $OUT/long_parity_nondefault_holes.txt)
+cat $OUT/long_parity_nondefault_holes.txt
 # the raw per-dispatch CSVs exceed what gpurun copies back (64 MiB): only the summaries travel
 rm -rf $OUT/trace $OUT/pmc/p[0-9]*
 tail -5 $OUT/pmc_summary.txt
