@@ -33,6 +33,12 @@ FAKE_WORKER = textwrap.dedent('''
     hb("imported")
     what = plan.get("%s@%d" % (args.child, args.volume), plan.get(args.child, {}))
     open(os.path.join(os.environ["FAKE_TRACE"], "%s_%d_%d_%d" % (args.child.replace(":", "_"), args.volume, rank, os.getpid())), "w").write(str(world))
+    if rank == 0:
+        # a real rank 0 cannot finish a step before its peers have started it (they meet in the step's first barrier); the stand-in
+        # waits for their trace files, so that a slow start of a peer (a loaded machine) cannot be mistaken for a missing worker
+        pre, t0 = "%s_%d_" % (args.child.replace(":", "_"), args.volume), time.time()
+        while len([f for f in os.listdir(os.environ["FAKE_TRACE"]) if f.startswith(pre)]) < world and time.time() - t0 < 60:
+            time.sleep(0.02)
     if what.get("fail") and rank == what.get("fail_rank", 0):
         sys.stderr.write("scripted failure of %s\\n" % args.child)
         sys.exit(7)
